@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline measurement for the MI355X prover hot path.
+
+Workload (BASELINE.json configs[1]): batched FFT, 2^20 points x 1024 rows of 16-byte
+field elements (16 GiB resident in HBM), one "step" = one pass of the batch through
+lfgpu_fp128_fft (FFT<Fp128>::fftb, reference lib/algebra/fft.h:185-195).  The same batch
+through the GF(2^128) LCH14 additive FFT (lib/gf2k/lch14.h:106-124) is reported as
+secondary keys.  N > 1: rows are independent, each rank owns its own 1024 rows (weak
+scaling, no data-path collective); value = all ranks' elements / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(logn, budget_s=12.0):
+    """Reference CPU path (oracle/_ref = the real reference compiled in the build container,
+    1 thread) on a bounded sample of the same workload; falls back to the C port."""
+    import numpy as np
+    import oracle_lib as ol
+
+    n = 1 << logn
+    o = ol.oracle()
+    r = ol.ref()
+    a = np.zeros((n, 2), dtype=np.uint64)
+    o.lfo_fp_bogorng_fill(1234569, n, ol.P(a))
+    rows, t0 = 0, time.perf_counter()
+    while True:
+        x = a.copy()
+        if r is not None:
+            r.ref_fp_fft(0, n, ol.P(x))
+        else:
+            o.lfo_fp_fftb(ol.P(x), n, o.lfo_fp_omega32(), 1 << 32)
+        rows += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or rows >= 128:
+            break
+    return {"value": rows * n / dt, "unit": "field-elems/s", "cores": 1,
+            "kind": "reference" if r is not None else "port",
+            "sample": "%d rows of 2^%d Fp128 points through FFT<Fp128>::fftb, 1 thread, %.1f s" % (rows, logn, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=1024)
+    ap.add_argument("--logn", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    gpu = pkg.LfGpu(local_rank)  # raises if liblfgpu.so is missing: no CPU fallback
+    stream = torch.cuda.current_stream()
+    gpu.set_stream(stream.cuda_stream)
+
+    rows, logn = args.rows, args.logn
+    n = 1 << logn
+    nelem = rows * n
+    # synthetic witness rows: uniform 128-bit values < p are valid Montgomery images
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234569 + rank)
+    A = torch.randint(-2**63, 2**63 - 1, (nelem, 2), dtype=torch.int64, device="cuda", generator=g)
+    A[:, 1] &= 0x7FFFFFFFFFFFFFFF  # hi limb < 2^63 < p_hi
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- correctness guard (untimed): row 0 of one fftb against the oracle
+    import oracle_lib as ol
+    o = ol.oracle()
+    row0 = A[:n].cpu().numpy().view(np.uint64).copy()
+    gpu.fp128_fft(A.data_ptr(), rows, n)
+    torch.cuda.synchronize()
+    got0 = A[:n].cpu().numpy().view(np.uint64)
+    o.lfo_fp_fftb(ol.P(row0), n, o.lfo_fp_omega32(), 1 << 32)
+    if not (got0 == row0).all():
+        raise SystemExit("bench: GPU fftb row 0 differs from the oracle -- refusing to report a number")
+
+    for _ in range(args.warmup):
+        gpu.fp128_fft(A.data_ptr(), rows, n)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        gpu.fp128_fft(A.data_ptr(), rows, n)
+    ev1.record(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    launches_per_step = 1 if logn <= 13 else 2  # fp_fft_tile passes (fft.hip)
+    kern_ms = dev_ms / (args.steps * launches_per_step)
+    algo_bytes_per_launch = 2.0 * nelem * 16 / launches_per_step
+    achieved = algo_bytes_per_launch / (kern_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "FFT field-elems/s (batched FFT 2^%d x %d rows, Fp128)" % (logn, rows),
+        "value": world * nelem * args.steps / dt,
+        "unit": "field-elems/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u128 (Fp128 Montgomery, 4 x u32 limbs)",
+        "data": "synthetic",
+        "config": {"workload": "batched FFT 2^%d points x %d rows per GPU, Fp128 fftb, in place in HBM" % (logn, rows),
+                   "field": "Fp128 p=2^128-2^108+1", "rows_per_gpu": rows, "n": n, "parallelism": "rows sharded x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "fp_fft_tile", "launches_per_step": launches_per_step, "avg_launch_ms": kern_ms,
+                     "note": "integer-ALU-bound (no 64-bit multiplier on CDNA4): see DESIGN.md"},
+    }
+
+    if rank == 0 and not args.no_secondary:
+        # secondary: same batch through the GF(2^128) LCH14 additive FFT (GF2_128<5>, l = logn)
+        k = 5 if logn > 16 else 4
+        for _ in range(1):
+            gpu.gf2128_lch14_fft(A.data_ptr(), rows, logn, subfield_log_bits=k)
+        torch.cuda.synchronize()
+        s2 = max(1, args.steps // 4)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(s2):
+            gpu.gf2128_lch14_fft(A.data_ptr(), rows, logn, subfield_log_bits=k)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / s2
+        out["gf2128_lch14_fft"] = {"field_elems_per_s": nelem / (ms * 1e-3), "ms_per_step": ms,
+                                   "algo_GBps": 2.0 * nelem * 16 / (ms * 1e-3) / 1e9}
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(logn)
+        print(json.dumps(out), flush=True)
+    gpu.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/*
+ * lfgpu.h -- C ABI of the MI355X (gfx950) prover hot path for longfellow-zk.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Every entry point names the reference interface it replaces
+ * (paths relative to the reference checkout, /root/reference in the build
+ * container).  Header-only C++ adapters that present the reference's template
+ * seams (ReedSolomonFactory, MerkleCommitment, ProverLayers round body) on top
+ * of this ABI are in include/lfgpu_adapters.h; INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - All functions return LFGPU_OK (0) or an error code; nothing aborts
+ *    (the reference's check() -> abort(), lib/util/panic.h:27-37, becomes a
+ *    status).  lfgpu_last_error() returns a message for the last failure.
+ *  - Field elements are the reference's in-memory Elt images, 16 bytes:
+ *      field 4 (GF2_128): 2 x u64 LE, polynomial basis (lib/gf2k/gf2_128.h:64-89)
+ *      field 6 (Fp128)  : 2 x u64 LE, Montgomery form R = 2^128 (lib/algebra/fp_generic.h:66-78)
+ *    so adapters can pass &tableau_[0] straight through.
+ *  - Pointers named d_* are DEVICE pointers (HIP); h_* are host pointers.
+ *    The *_host variants stage through device memory owned by the context.
+ *  - Work is enqueued on the context's stream; functions that return data to
+ *    host memory synchronise that stream before returning.
+ *  - ld / strides are in ELEMENTS (16 bytes), not bytes.
+ */
+#ifndef LFGPU_H_
+#define LFGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFGPU_OK 0
+#define LFGPU_ERR_ARG 1         /* bad argument (null, size, alignment) */
+#define LFGPU_ERR_HIP 2         /* HIP runtime error */
+#define LFGPU_ERR_UNSUPPORTED 3 /* valid request outside what this build covers */
+#define LFGPU_ERR_NOMEM 4
+#define LFGPU_ERR_ASSERT 5      /* a reference check() would have failed (e.g. assert-zero term) */
+
+#define LFGPU_FIELD_GF2_128 4 /* FieldID, lib/proto/circuit_io.h:24-36 */
+#define LFGPU_FIELD_FP128 6
+
+typedef struct lfgpu_ctx lfgpu_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+int lfgpu_init(int device, lfgpu_ctx** out);
+int lfgpu_shutdown(lfgpu_ctx* ctx);
+const char* lfgpu_last_error(const lfgpu_ctx* ctx);
+int lfgpu_set_stream(lfgpu_ctx* ctx, void* hip_stream); /* NULL = default stream */
+int lfgpu_sync(lfgpu_ctx* ctx);
+/* device-memory helpers so that C / ctypes / cgo callers need no HIP runtime */
+int lfgpu_malloc(lfgpu_ctx* ctx, size_t bytes, void** d_out);
+int lfgpu_free(lfgpu_ctx* ctx, void* d_ptr);
+int lfgpu_memcpy_h2d(lfgpu_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int lfgpu_memcpy_d2h(lfgpu_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* ---- K1: prime-field FFT ------------------------------------------------
+ * Replaces FFT<Fp128>::fftb / fftf (lib/algebra/fft.h:185-201).
+ * In-place, `rows` independent length-n (power of two) transforms; row r starts
+ * at d_A + r*ld.  dir 0 = backward  A[j] = sum_k A[k] w_n^{jk}, dir 1 = forward
+ * (w -> w^-1); unscaled.  omega is a root of unity of order omega_order (power
+ * of two >= n) in Montgomery form, exactly the (omega_j, j) arguments of fftb. */
+int lfgpu_fp128_fft(lfgpu_ctx* ctx, int dir, size_t rows, size_t n, const uint64_t omega[2],
+                    uint64_t omega_order, void* d_A, size_t ld);
+
+/* ---- K2: additive (LCH14) FFT over GF(2^128) ------------------------------
+ * Replaces LCH14<GF2_128<k>>::FFT / IFFT (lib/gf2k/lch14.h:106-144).
+ * subfield_log_bits = k of GF2_128<k> (4 or 5; l <= 2^k).  dir 0 = FFT, 1 = IFFT.
+ * In-place on `rows` arrays of 2^l elements, row r at d_B + r*ld. */
+int lfgpu_gf2128_lch14_fft(lfgpu_ctx* ctx, int subfield_log_bits, int dir, size_t rows, unsigned l,
+                           uint64_t coset, void* d_B, size_t ld);
+
+/* ---- K3 / K4: Reed-Solomon row encode -------------------------------------
+ * Replaces LCH14ReedSolomon::interpolate (lib/gf2k/lch14_reed_solomon.h:49-103)
+ * and ReedSolomon::interpolate (lib/algebra/reed_solomon.h:93-110) applied to
+ * every row of a tableau: y[0..n) valid -> fills y[n..m), in place, row r at
+ * d_T + r*ld.  This is the InterpolatorFactory seam of LigeroProver
+ * (lib/ligero/ligero_prover.h:34,175,184,210,237,295). */
+int lfgpu_gf2128_rs_encode_rows(lfgpu_ctx* ctx, int subfield_log_bits, size_t nrow, size_t n, size_t m,
+                                void* d_T, size_t ld);
+int lfgpu_fp128_rs_encode_rows(lfgpu_ctx* ctx, size_t nrow, size_t n, size_t m, const uint64_t omega[2],
+                               uint64_t omega_order, void* d_T, size_t ld);
+
+/* ---- K5 + K6: Merkle column commitment ------------------------------------
+ * Replaces MerkleCommitment::commit (lib/merkle/merkle_commitment.h:50-64) with
+ * LigeroCommon::column_hash as updhash (lib/ligero/ligero_param.h:432-439) and
+ * MerkleTree::build_tree (lib/merkle/merkle_tree.h:109-114):
+ *   leaf_j = SHA256(nonce_j || ser(T[0][col0+j]) || ... || ser(T[nrow-1][col0+j]))
+ *   layers[i] = SHA256(layers[2i] || layers[2i+1]),  i = ncols-1 .. 1
+ * d_nonces: ncols*32 bytes (drawn by the caller from its RandomEngine in leaf
+ * order, merkle_commitment.h:54).  d_layers: 2*ncols*32 bytes, heap layout of
+ * MerkleTree::layers_ (leaves at [ncols, 2*ncols), root at [1]); stays on the
+ * device for lfgpu_merkle_open.  root_out: 32 host bytes. */
+int lfgpu_column_commit(lfgpu_ctx* ctx, int field, size_t nrow, size_t ld, size_t col0, size_t ncols,
+                        const void* d_T, const void* d_nonces, void* d_layers, uint8_t root_out[32]);
+/* MerkleTree::build_tree alone: d_layers[ncols..2*ncols) hold the leaves. */
+int lfgpu_merkle_build_tree(lfgpu_ctx* ctx, size_t n, void* d_layers, uint8_t root_out[32]);
+/* MerkleTree::generate_compressed_proof (lib/merkle/merkle_tree.h:122-143):
+ * copies the sibling digests of the opening of pos[0..np) to h_path (capacity
+ * path_cap digests) and writes their count to *npath. */
+int lfgpu_merkle_open(lfgpu_ctx* ctx, size_t n, const void* d_layers, const size_t* pos, size_t np,
+                      uint8_t* h_path, size_t path_cap, size_t* npath);
+
+/* ---- K7 / K8 / K9: sumcheck round body -------------------------------------
+ * Replaces the per-round body of ProverLayers::layer (lib/sumcheck/prover_layers.h:230-263). */
+/* loop of ProverLayers::evaluations (:365-388): a0 = sum QW[2i] W[2i],
+ * a2 = sum (QW[2i+1]-QW[2i]) (W[2i+1]-W[2i]) (+ odd tail).  Outputs to host. */
+int lfgpu_sumcheck_partials(lfgpu_ctx* ctx, int field, size_t n, const void* d_QW, const void* d_W,
+                            uint64_t a0[2], uint64_t a2[2]);
+/* QW[h[hand]] += v * Wother[h[1-hand]] over the HQUAD terms (:235-243).
+ * d_hc: n x {u32 h0, u32 h1}; d_vc: n elements; d_QW (nqw elements) is cleared first. */
+int lfgpu_qw_scatter(lfgpu_ctx* ctx, int field, size_t n, const void* d_hc, const void* d_vc, int hand,
+                     const void* d_Wother, size_t nqw, void* d_QW);
+/* Dense::bind with n1 = 1 (lib/arrays/dense.h:70-87): out[i] = in[2i] + r (in[2i+1]-in[2i]);
+ * d_out may equal d_in.  New length (n0+1)/2. */
+int lfgpu_dense_bind(lfgpu_ctx* ctx, int field, size_t n0, const uint64_t r[2], const void* d_in,
+                     void* d_out);
+/* HQuad::bind_h (lib/sumcheck/hquad.h:90-123): order-preserving pairwise merge;
+ * outputs to (d_hc_out, d_vc_out), *n_out = new count. */
+int lfgpu_hquad_bind_h(lfgpu_ctx* ctx, int field, size_t n, const void* d_hc, const void* d_vc,
+                       const uint64_t r[2], int hand, void* d_hc_out, void* d_vc_out, size_t* n_out);
+
+/* ---- K12: Ligero row combinations -----------------------------------------
+ * y[j] += sum_i u[i] * T[i][j], j < n  (low_degree_proof, lib/ligero/ligero_prover.h:281-291;
+ * Blas::axpy lib/algebra/blas.h:62-68).  h_u: nrows host elements. */
+int lfgpu_rows_axpy(lfgpu_ctx* ctx, int field, size_t nrows, size_t n, void* d_y, const uint64_t* h_u,
+                    const void* d_T, size_t ld);
+/* req[i][j] = T[i][col0 + idx[j]]  (compute_req :346-351; Blas::gather blas.h:104-110) */
+int lfgpu_gather_columns(lfgpu_ctx* ctx, size_t nrow, size_t ld, size_t col0, const void* d_T,
+                         const size_t* h_idx, size_t nreq, void* d_req);
+
+/* ---- host-buffer conveniences (what the header-only adapters call) ---------- */
+int lfgpu_fp128_fft_host(lfgpu_ctx* ctx, int dir, size_t n, const uint64_t omega[2], uint64_t omega_order,
+                         void* h_A);
+int lfgpu_gf2128_lch14_fft_host(lfgpu_ctx* ctx, int subfield_log_bits, int dir, unsigned l, uint64_t coset,
+                                void* h_B);
+int lfgpu_gf2128_rs_encode_rows_host(lfgpu_ctx* ctx, int subfield_log_bits, size_t nrow, size_t n, size_t m,
+                                     void* h_T, size_t ld);
+int lfgpu_column_commit_host(lfgpu_ctx* ctx, int field, size_t nrow, size_t ld, size_t col0, size_t ncols,
+                             const void* h_T, const uint8_t* h_nonces, uint8_t* h_layers,
+                             uint8_t root_out[32]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFGPU_H_ */

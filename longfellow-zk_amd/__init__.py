@@ -1,0 +1,225 @@
+"""longfellow-zk_amd -- MI355X-native prover hot path for longfellow-zk.
+
+Host-side mirror (Python/ctypes) of the C ABI in include/lfgpu.h.  The compute
+lives in hand-written HIP kernels (csrc/*.hip, built into liblfgpu.so by
+__graft_entry__.build()).  There is NO CPU fallback: if the library is missing
+or the GPU is absent every call raises.
+
+The directory name contains a hyphen, so import it through
+``__graft_entry__.load_package()`` (importlib) rather than ``import``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblfgpu.so")
+
+FIELD_GF2_128 = 4  # FieldID, reference lib/proto/circuit_io.h:24-36
+FIELD_FP128 = 6
+
+# 2^32-order root of unity of Fp128 (reference lib/algebra/fp_p128.h:48-56), canonical value
+FP128_OMEGA32 = 164956748514267535023998284330560247862
+FP128_P = 2**128 - 2**108 + 1
+
+ABI_SYMBOLS = [
+    "lfgpu_init", "lfgpu_shutdown", "lfgpu_last_error", "lfgpu_set_stream", "lfgpu_sync", "lfgpu_malloc",
+    "lfgpu_free", "lfgpu_memcpy_h2d", "lfgpu_memcpy_d2h", "lfgpu_fp128_fft", "lfgpu_gf2128_lch14_fft",
+    "lfgpu_gf2128_rs_encode_rows", "lfgpu_fp128_rs_encode_rows", "lfgpu_column_commit", "lfgpu_merkle_build_tree",
+    "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
+    "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_fp128_fft_host", "lfgpu_gf2128_lch14_fft_host",
+    "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
+]
+
+
+class LfGpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen liblfgpu.so and declare the ABI.  Raises (never falls back) when missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LfGpuError("%s not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u64, ci = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
+    pu64 = C.POINTER(C.c_uint64)
+    sig = {
+        "lfgpu_init": [ci, C.POINTER(vp)], "lfgpu_shutdown": [vp], "lfgpu_set_stream": [vp, vp], "lfgpu_sync": [vp],
+        "lfgpu_malloc": [vp, sz, C.POINTER(vp)], "lfgpu_free": [vp, vp],
+        "lfgpu_memcpy_h2d": [vp, vp, vp, sz], "lfgpu_memcpy_d2h": [vp, vp, vp, sz],
+        "lfgpu_fp128_fft": [vp, ci, sz, sz, pu64, u64, vp, sz],
+        "lfgpu_gf2128_lch14_fft": [vp, ci, ci, sz, C.c_uint, u64, vp, sz],
+        "lfgpu_gf2128_rs_encode_rows": [vp, ci, sz, sz, sz, vp, sz],
+        "lfgpu_fp128_rs_encode_rows": [vp, sz, sz, sz, pu64, u64, vp, sz],
+        "lfgpu_column_commit": [vp, ci, sz, sz, sz, sz, vp, vp, vp, vp],
+        "lfgpu_merkle_build_tree": [vp, sz, vp, vp],
+        "lfgpu_merkle_open": [vp, sz, vp, vp, sz, vp, sz, C.POINTER(sz)],
+        "lfgpu_sumcheck_partials": [vp, ci, sz, vp, vp, pu64, pu64],
+        "lfgpu_qw_scatter": [vp, ci, sz, vp, vp, ci, vp, sz, vp],
+        "lfgpu_dense_bind": [vp, ci, sz, pu64, vp, vp],
+        "lfgpu_hquad_bind_h": [vp, ci, sz, vp, vp, pu64, ci, vp, vp, C.POINTER(sz)],
+        "lfgpu_rows_axpy": [vp, ci, sz, sz, vp, vp, vp, sz],
+        "lfgpu_gather_columns": [vp, sz, sz, sz, vp, vp, sz, vp],
+        "lfgpu_fp128_fft_host": [vp, ci, sz, pu64, u64, vp],
+        "lfgpu_gf2128_lch14_fft_host": [vp, ci, ci, C.c_uint, u64, vp],
+        "lfgpu_gf2128_rs_encode_rows_host": [vp, ci, sz, sz, sz, vp, sz],
+        "lfgpu_column_commit_host": [vp, ci, sz, sz, sz, sz, vp, vp, vp, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = ci, args
+    L.lfgpu_last_error.restype, L.lfgpu_last_error.argtypes = C.c_char_p, [vp]
+    _lib = L
+    return L
+
+
+def _u64x2(v):
+    """int (canonical 128-bit image) or sequence of two u64 -> (c_uint64 * 2)"""
+    if isinstance(v, int):
+        v = (v & (2**64 - 1), v >> 64)
+    return (C.c_uint64 * 2)(int(v[0]), int(v[1]))
+
+
+def fp128_to_montgomery(x):
+    return (x * (1 << 128)) % FP128_P
+
+
+def fp128_from_montgomery(x):
+    return (x * pow(1 << 128, -1, FP128_P)) % FP128_P
+
+
+class LfGpu:
+    """One context per process / GPU (lfgpu_ctx).  Pointer arguments are raw device
+    addresses (e.g. torch.Tensor.data_ptr()); strides are in 16-byte elements."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.lfgpu_init(int(device), C.byref(h))
+        if rc != 0:
+            raise LfGpuError("lfgpu_init(device=%d) failed with code %d (no usable MI355X?)" % (device, rc))
+        self.h = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lfgpu_shutdown(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise LfGpuError("lfgpu error %d: %s" % (rc, self.L.lfgpu_last_error(self.h).decode()))
+
+    def set_stream(self, stream):
+        self._ck(self.L.lfgpu_set_stream(self.h, C.c_void_p(int(stream))))
+
+    def sync(self):
+        self._ck(self.L.lfgpu_sync(self.h))
+
+    # --- K1 FFT<Fp128>::fftb / fftf (reference lib/algebra/fft.h:185-201)
+    def fp128_fft(self, d_ptr, rows, n, ld=None, forward=False, omega=None, omega_order=1 << 32):
+        omega = _u64x2(fp128_to_montgomery(FP128_OMEGA32) if omega is None else omega)
+        self._ck(self.L.lfgpu_fp128_fft(self.h, 1 if forward else 0, rows, n, omega, omega_order, C.c_void_p(d_ptr),
+                                        n if ld is None else ld))
+
+    # --- K2 LCH14::FFT / IFFT (reference lib/gf2k/lch14.h:106-144)
+    def gf2128_lch14_fft(self, d_ptr, rows, l, coset=0, ld=None, inverse=False, subfield_log_bits=4):
+        self._ck(self.L.lfgpu_gf2128_lch14_fft(self.h, subfield_log_bits, 1 if inverse else 0, rows, l, coset,
+                                               C.c_void_p(d_ptr), (1 << l) if ld is None else ld))
+
+    # --- K3 LCH14ReedSolomon::interpolate over rows (reference lib/gf2k/lch14_reed_solomon.h:49-103)
+    def gf2128_rs_encode_rows(self, d_ptr, nrow, n, m, ld=None, subfield_log_bits=4):
+        self._ck(self.L.lfgpu_gf2128_rs_encode_rows(self.h, subfield_log_bits, nrow, n, m, C.c_void_p(d_ptr),
+                                                    m if ld is None else ld))
+
+    # --- K4 ReedSolomon::interpolate over rows (reference lib/algebra/reed_solomon.h:93-110)
+    def fp128_rs_encode_rows(self, d_ptr, nrow, n, m, ld=None, omega=None, omega_order=1 << 32):
+        omega = _u64x2(fp128_to_montgomery(FP128_OMEGA32) if omega is None else omega)
+        self._ck(self.L.lfgpu_fp128_rs_encode_rows(self.h, nrow, n, m, omega, omega_order, C.c_void_p(d_ptr),
+                                                   m if ld is None else ld))
+
+    # --- K5+K6 MerkleCommitment::commit (reference lib/merkle/merkle_commitment.h:50-64)
+    def column_commit(self, field, nrow, ld, col0, ncols, d_T, d_nonces, d_layers):
+        root = (C.c_uint8 * 32)()
+        self._ck(self.L.lfgpu_column_commit(self.h, field, nrow, ld, col0, ncols, C.c_void_p(d_T),
+                                            C.c_void_p(d_nonces), C.c_void_p(d_layers), root))
+        return bytes(root)
+
+    def merkle_build_tree(self, n, d_layers):
+        root = (C.c_uint8 * 32)()
+        self._ck(self.L.lfgpu_merkle_build_tree(self.h, n, C.c_void_p(d_layers), root))
+        return bytes(root)
+
+    def merkle_open(self, n, d_layers, pos):
+        pos_a = (C.c_size_t * len(pos))(*pos)
+        cap = max(1, len(pos) * 64)
+        buf = (C.c_uint8 * (32 * cap))()
+        npath = C.c_size_t()
+        self._ck(self.L.lfgpu_merkle_open(self.h, n, C.c_void_p(d_layers), pos_a, len(pos), buf, cap, C.byref(npath)))
+        raw = bytes(buf)
+        return [raw[32 * i:32 * i + 32] for i in range(npath.value)]
+
+    # --- K7 loop of ProverLayers::evaluations (reference lib/sumcheck/prover_layers.h:365-388)
+    def sumcheck_partials(self, field, n, d_QW, d_W):
+        a0, a2 = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        self._ck(self.L.lfgpu_sumcheck_partials(self.h, field, n, C.c_void_p(d_QW), C.c_void_p(d_W), a0, a2))
+        return (a0[0], a0[1]), (a2[0], a2[1])
+
+    # --- K8 QW scatter (reference lib/sumcheck/prover_layers.h:239-243)
+    def qw_scatter(self, field, n, d_hc, d_vc, hand, d_Wother, nqw, d_QW):
+        self._ck(self.L.lfgpu_qw_scatter(self.h, field, n, C.c_void_p(d_hc), C.c_void_p(d_vc), hand,
+                                         C.c_void_p(d_Wother), nqw, C.c_void_p(d_QW)))
+
+    # --- K9 Dense::bind / HQuad::bind_h (reference lib/arrays/dense.h:70-87, lib/sumcheck/hquad.h:90-123)
+    def dense_bind(self, field, n0, r, d_in, d_out):
+        self._ck(self.L.lfgpu_dense_bind(self.h, field, n0, _u64x2(r), C.c_void_p(d_in), C.c_void_p(d_out)))
+        return (n0 + 1) // 2
+
+    def hquad_bind_h(self, field, n, d_hc, d_vc, r, hand, d_hc_out, d_vc_out):
+        n_out = C.c_size_t()
+        self._ck(self.L.lfgpu_hquad_bind_h(self.h, field, n, C.c_void_p(d_hc), C.c_void_p(d_vc), _u64x2(r), hand,
+                                           C.c_void_p(d_hc_out), C.c_void_p(d_vc_out), C.byref(n_out)))
+        return n_out.value
+
+    # --- K12 row combinations (reference lib/ligero/ligero_prover.h:281-291,346-351)
+    def rows_axpy(self, field, nrows, n, d_y, u_host, d_T, ld):
+        self._ck(self.L.lfgpu_rows_axpy(self.h, field, nrows, n, C.c_void_p(d_y), C.c_void_p(u_host.ctypes.data),
+                                        C.c_void_p(d_T), ld))
+
+    def gather_columns(self, nrow, ld, col0, d_T, idx, d_req):
+        idx_a = (C.c_size_t * len(idx))(*idx)
+        self._ck(self.L.lfgpu_gather_columns(self.h, nrow, ld, col0, C.c_void_p(d_T), idx_a, len(idx),
+                                             C.c_void_p(d_req)))
+
+    # --- host-buffer conveniences (numpy uint64[...,2] arrays, modified in place)
+    def fp128_fft_host(self, a, forward=False, omega=None, omega_order=1 << 32):
+        omega = _u64x2(fp128_to_montgomery(FP128_OMEGA32) if omega is None else omega)
+        self._ck(self.L.lfgpu_fp128_fft_host(self.h, 1 if forward else 0, a.shape[0], omega, omega_order,
+                                             C.c_void_p(a.ctypes.data)))
+
+    def gf2128_lch14_fft_host(self, a, l, coset=0, inverse=False, subfield_log_bits=4):
+        self._ck(self.L.lfgpu_gf2128_lch14_fft_host(self.h, subfield_log_bits, 1 if inverse else 0, l, coset,
+                                                    C.c_void_p(a.ctypes.data)))
+
+    def gf2128_rs_encode_rows_host(self, T, nrow, n, m, ld, subfield_log_bits=4):
+        self._ck(self.L.lfgpu_gf2128_rs_encode_rows_host(self.h, subfield_log_bits, nrow, n, m,
+                                                         C.c_void_p(T.ctypes.data), ld))
+
+    def column_commit_host(self, field, T, nrow, ld, col0, ncols, nonces, layers=None):
+        root = (C.c_uint8 * 32)()
+        self._ck(self.L.lfgpu_column_commit_host(self.h, field, nrow, ld, col0, ncols, C.c_void_p(T.ctypes.data),
+                                                 C.c_void_p(nonces.ctypes.data),
+                                                 C.c_void_p(layers.ctypes.data) if layers is not None else None, root))
+        return bytes(root)

@@ -1,0 +1,189 @@
+// core.hip -- context, memory helpers, host-side field constants.
+#include "ctx.h"
+
+int lf_fail(lfgpu_ctx* c, int code, const char* fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+static int grow(lfgpu_ctx* c, void** buf, size_t* cap, size_t bytes, void** out) {
+  if (bytes > *cap) {
+    if (*buf) {
+      LF_HIP(c, hipStreamSynchronize(c->stream));
+      LF_HIP(c, hipFree(*buf));
+      *buf = nullptr;
+      *cap = 0;
+    }
+    hipError_t e = hipMalloc(buf, bytes);
+    if (e != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    *cap = bytes;
+  }
+  *out = *buf;
+  return LFGPU_OK;
+}
+int lf_scratch(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch, &c->scratch_bytes, bytes, out); }
+int lf_scratch2(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch2, &c->scratch2_bytes, bytes, out); }
+
+bool lf_table_lookup(lfgpu_ctx* c, const std::string& key, void** out) {
+  auto it = c->tables.find(key);
+  if (it == c->tables.end()) return false;
+  *out = it->second;
+  return true;
+}
+int lf_table(lfgpu_ctx* c, const std::string& key, const void* host, size_t bytes, void** out) {
+  if (lf_table_lookup(c, key, out)) return LFGPU_OK;
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, bytes ? bytes : 16);
+  if (e != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "hipMalloc(table %zu) failed: %s", bytes, hipGetErrorString(e));
+  // synchronous copy: `host` is usually a temporary
+  LF_HIP(c, hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+  c->tables[key] = d;
+  *out = d;
+  return LFGPU_OK;
+}
+
+// ------------------------------------------------------------------ host field helpers
+elt_t h_gf_inv(elt_t a) {  // a^(2^128-2)
+  elt_t r{1, 0}, s = a;
+  for (int i = 1; i < 128; ++i) {
+    s = gf_mul(s, s);
+    r = gf_mul(r, s);
+  }
+  return r;
+}
+static elt_t h_fp_rsq() {
+  static bool init = false;
+  static elt_t rsq;
+  if (!init) {
+    elt_t r{1, 0};
+    for (int i = 0; i < 256; ++i) r = fp_add(r, r);
+    rsq = r;
+    init = true;
+  }
+  return rsq;
+}
+elt_t h_fp_of_scalar(u64 u) { return fp_mul(elt_t{u, 0}, h_fp_rsq()); }
+elt_t h_fp_inv(elt_t x) {  // x^(p-2)
+  unsigned __int128 e = (((unsigned __int128)FP_P_HI) << 64 | FP_P_LO) - 2;
+  elt_t r = h_fp_of_scalar(1), b = x;
+  while (e) {
+    if (e & 1) r = fp_mul(r, b);
+    b = fp_mul(b, b);
+    e >>= 1;
+  }
+  return r;
+}
+
+// GF2_128<k> ctor + LCH14 ctor constants (lib/gf2k/gf2_128.h:97-116,369-391; lch14.h:45-77)
+const GfHostCtx* lf_gf_ctx(lfgpu_ctx* c, int k) {
+  if (k != 4 && k != 5) return nullptr;
+  GfHostCtx* g = &c->gf[k - 4];
+  if (g->init) return g;
+  g->k = k;
+  g->sub_bits = 1u << k;
+  elt_t r{2, 0};
+  for (unsigned i = k; i < 7; ++i) {
+    elt_t s = r;
+    for (unsigned j = 0; j < (1u << i); ++j) s = gf_mul(s, s);
+    r = gf_mul(r, s);
+  }
+  g->g = r;
+  g->beta[0] = elt_t{1, 0};
+  for (unsigned i = 1; i < g->sub_bits; ++i) g->beta[i] = gf_mul(g->beta[i - 1], r);
+  unsigned sb = g->sub_bits;
+  for (unsigned j = 0; j < sb; ++j) g->w_hat[0][j] = g->beta[j];
+  for (unsigned i = 0; i + 1 < sb; ++i)
+    for (unsigned j = 0; j < sb; ++j)
+      g->w_hat[i + 1][j] = gf_mul(g->w_hat[i][j], gf_add(g->w_hat[i][j], g->w_hat[i][i]));
+  for (unsigned i = 0; i < sb; ++i) {
+    elt_t sc = h_gf_inv(g->w_hat[i][i]);
+    for (unsigned j = 0; j < sb; ++j) g->w_hat[i][j] = gf_mul(sc, g->w_hat[i][j]);
+  }
+  g->init = true;
+  return g;
+}
+// LCH14::twiddle (lch14.h:81-89)
+elt_t h_lch14_twiddle(const GfHostCtx* g, unsigned i, u64 u) {
+  elt_t t{0, 0};
+  for (unsigned k = 0; u != 0 && k < g->sub_bits; ++k, u >>= 1)
+    if (u & 1) t = gf_add(t, g->w_hat[i][k]);
+  return t;
+}
+
+// ------------------------------------------------------------------ C ABI: context
+extern "C" {
+
+int lfgpu_init(int device, lfgpu_ctx** out) {
+  if (!out) return LFGPU_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LFGPU_ERR_HIP;
+  if (device < 0 || device >= ndev) return LFGPU_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return LFGPU_ERR_HIP;
+  lfgpu_ctx* c = new lfgpu_ctx();
+  c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+  if (hipHostMalloc(&c->mailbox_h, 4096) != hipSuccess || hipMalloc(&c->mailbox_d, 4096) != hipSuccess) {
+    delete c;
+    return LFGPU_ERR_NOMEM;
+  }
+  *out = c;
+  return LFGPU_OK;
+}
+
+int lfgpu_shutdown(lfgpu_ctx* c) {
+  if (!c) return LFGPU_ERR_ARG;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (auto& kv : c->tables) hipFree(kv.second);
+  if (c->scratch) hipFree(c->scratch);
+  if (c->scratch2) hipFree(c->scratch2);
+  if (c->mailbox_h) hipHostFree(c->mailbox_h);
+  if (c->mailbox_d) hipFree(c->mailbox_d);
+  delete c;
+  return LFGPU_OK;
+}
+
+const char* lfgpu_last_error(const lfgpu_ctx* c) { return c ? c->err : "null context"; }
+
+int lfgpu_set_stream(lfgpu_ctx* c, void* s) {
+  if (!c) return LFGPU_ERR_ARG;
+  c->stream = (hipStream_t)s;
+  return LFGPU_OK;
+}
+int lfgpu_sync(lfgpu_ctx* c) {
+  if (!c) return LFGPU_ERR_ARG;
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  return LFGPU_OK;
+}
+int lfgpu_malloc(lfgpu_ctx* c, size_t bytes, void** d_out) {
+  if (!c || !d_out) return LFGPU_ERR_ARG;
+  hipError_t e = hipMalloc(d_out, bytes ? bytes : 16);
+  if (e != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  return LFGPU_OK;
+}
+int lfgpu_free(lfgpu_ctx* c, void* d) {
+  if (!c) return LFGPU_ERR_ARG;
+  LF_HIP(c, hipFree(d));
+  return LFGPU_OK;
+}
+int lfgpu_memcpy_h2d(lfgpu_ctx* c, void* d, const void* h, size_t bytes) {
+  if (!c) return LFGPU_ERR_ARG;
+  LF_HIP(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  return LFGPU_OK;
+}
+int lfgpu_memcpy_d2h(lfgpu_ctx* c, void* h, const void* d, size_t bytes) {
+  if (!c) return LFGPU_ERR_ARG;
+  LF_HIP(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  return LFGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,432 @@
+// fft.hip -- K1 (Fp128 radix-2 FFT) and K2 (GF(2^128) LCH14 additive FFT).
+//
+// Both transforms are run as one or two "tile passes".  A pass gives each
+// workgroup a tile of T points x C batch columns (T*C <= 8192 elements = 128 KiB
+// of the CU's 160 KiB LDS), runs log2(T) butterfly stages entirely in LDS and
+// writes the tile back once, so HBM sees one read + one write per pass:
+//   n <= 8192 : one pass, batch = rows
+//   n  > 8192 : n = n1 * n2 (n2 = 1024).  Pass A: n1-point transforms down the
+//               strided dimension (C consecutive columns per tile => coalesced
+//               C*16-byte segments), pass B: n2-point transforms on contiguous rows.
+// Reference: lib/algebra/fft.h:70-201 (Fp128), lib/gf2k/lch14.h:92-144 (LCH14).
+#include <string>
+
+#include "ctx.h"
+
+#define TILE_ELTS 8192u
+#define FFT_THREADS 1024
+
+struct TilePlan {
+  const elt_t* src;
+  elt_t* dst;
+  long long src_row, dst_row;    // grid.y (row) strides, elements
+  long long src_tile, dst_tile;  // grid.x (tile) strides
+  long long sk, sc, dk, dc;      // strides of the point index k and batch index c
+  u32 logT, logC, nbatch;        // nbatch: total batch columns over all tiles (bounds)
+  u32 kfast_src, kfast_dst;      // 1: consecutive lanes walk k (stride-1 side), 0: walk c
+};
+
+__device__ __forceinline__ u32 bitrev(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+// ------------------------------------------------------------------ K1: Fp128
+// W[i << wshift] = w_T^i (i < T/2).  Optional inter-pass twiddle w_n^{j*(col)}
+// = tw_lo[e & 1023] * tw_hi[e >> 10].
+__global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt_t* __restrict__ W, u32 wshift,
+                                                           const elt_t* __restrict__ tw_lo,
+                                                           const elt_t* __restrict__ tw_hi) {
+  extern __shared__ elt_t s[];
+  const u32 T = 1u << p.logT, C = 1u << p.logC, tid = threadIdx.x;
+  const u32 cbase = blockIdx.x << p.logC;
+  const elt_t* src = p.src + (long long)blockIdx.y * p.src_row + (long long)blockIdx.x * p.src_tile;
+  elt_t* dst = p.dst + (long long)blockIdx.y * p.dst_row + (long long)blockIdx.x * p.dst_tile;
+
+  for (u32 e = tid; e < T * C; e += FFT_THREADS) {
+    u32 k, c;
+    if (p.kfast_src) { k = e & (T - 1); c = e >> p.logT; } else { c = e & (C - 1); k = e >> p.logC; }
+    elt_t v = elt_zero();
+    if (cbase + c < p.nbatch) v = ld16(src + (long long)k * p.sk + (long long)c * p.sc);
+    st16(&s[(bitrev(k, p.logT) << p.logC) + c], v);
+  }
+  __syncthreads();
+  for (u32 st = 0; st < p.logT; ++st) {
+    const u32 m = 1u << st;
+    for (u32 e = tid; e < (T >> 1) * C; e += FFT_THREADS) {
+      u32 c = e & (C - 1), b = e >> p.logC;
+      u32 j = b & (m - 1);
+      u32 i0 = ((b >> st) << (st + 1)) + j, i1 = i0 + m;
+      elt_t a0 = ld16(&s[(i0 << p.logC) + c]);
+      elt_t a1 = ld16(&s[(i1 << p.logC) + c]);
+      if (j) a1 = fp_mul(a1, ld16(&W[(size_t)(j << (p.logT - 1 - st)) << wshift]));
+      st16(&s[(i0 << p.logC) + c], fp_add(a0, a1));
+      st16(&s[(i1 << p.logC) + c], fp_sub(a0, a1));
+    }
+    __syncthreads();
+  }
+  for (u32 e = tid; e < T * C; e += FFT_THREADS) {
+    u32 j, c;
+    if (p.kfast_dst) { j = e & (T - 1); c = e >> p.logT; } else { c = e & (C - 1); j = e >> p.logC; }
+    if (cbase + c >= p.nbatch) continue;
+    elt_t v = ld16(&s[(j << p.logC) + c]);
+    if (tw_lo) {
+      u32 ex = j * (cbase + c);
+      if (ex) {
+        elt_t t = ld16(&tw_lo[ex & 1023]);
+        if (ex >> 10) t = fp_mul(t, ld16(&tw_hi[ex >> 10]));
+        v = fp_mul(v, t);
+      }
+    }
+    st16(dst + (long long)j * p.dk + (long long)c * p.dc, v);
+  }
+}
+
+// ------------------------------------------------------------------ K2: LCH14
+// Stage ii of the tile (global stage i = i_lo + ii) uses
+//   tw = tbl[off[ii] + u_local]  (^ base[ii*nb + cbase + c] when base != null)
+// fwd (lch14.h:219-223): b0 ^= tw*b1; b1 ^= b0.   bwd (:225-229): b1 ^= b0; b0 ^= tw*b1.
+struct LchTables {
+  const elt_t* tbl;
+  const elt_t* base;
+  u32 nb;
+  u32 off[16];
+};
+
+__global__ __launch_bounds__(FFT_THREADS) void lch_fft_tile(TilePlan p, int inverse, LchTables t) {
+  extern __shared__ elt_t s[];
+  const u32 T = 1u << p.logT, C = 1u << p.logC, tid = threadIdx.x;
+  const u32 cbase = blockIdx.x << p.logC;
+  const elt_t* src = p.src + (long long)blockIdx.y * p.src_row + (long long)blockIdx.x * p.src_tile;
+  elt_t* dst = p.dst + (long long)blockIdx.y * p.dst_row + (long long)blockIdx.x * p.dst_tile;
+
+  for (u32 e = tid; e < T * C; e += FFT_THREADS) {
+    u32 k, c;
+    if (p.kfast_src) { k = e & (T - 1); c = e >> p.logT; } else { c = e & (C - 1); k = e >> p.logC; }
+    elt_t v = elt_zero();
+    if (cbase + c < p.nbatch) v = ld16(src + (long long)k * p.sk + (long long)c * p.sc);
+    st16(&s[(k << p.logC) + c], v);
+  }
+  __syncthreads();
+  for (u32 step = 0; step < p.logT; ++step) {
+    const u32 ii = inverse ? step : (p.logT - 1 - step);
+    const u32 sz = 1u << ii;
+    for (u32 e = tid; e < (T >> 1) * C; e += FFT_THREADS) {
+      u32 c = e & (C - 1), b = e >> p.logC;
+      u32 v = b & (sz - 1), u = b >> ii;
+      u32 i0 = (u << (ii + 1)) + v, i1 = i0 + sz;
+      elt_t tw = ld16(&t.tbl[t.off[ii] + u]);
+      if (t.base) {
+        u32 cb = cbase + c;
+        if (cb >= t.nb) cb = 0;
+        tw = gf_add(tw, ld16(&t.base[ii * t.nb + cb]));
+      }
+      elt_t b0 = ld16(&s[(i0 << p.logC) + c]);
+      elt_t b1 = ld16(&s[(i1 << p.logC) + c]);
+      if (!inverse) {
+        b0 = gf_add(b0, gf_mul(tw, b1));
+        b1 = gf_add(b1, b0);
+      } else {
+        b1 = gf_add(b1, b0);
+        b0 = gf_add(b0, gf_mul(tw, b1));
+      }
+      st16(&s[(i0 << p.logC) + c], b0);
+      st16(&s[(i1 << p.logC) + c], b1);
+    }
+    __syncthreads();
+  }
+  for (u32 e = tid; e < T * C; e += FFT_THREADS) {
+    u32 j, c;
+    if (p.kfast_dst) { j = e & (T - 1); c = e >> p.logT; } else { c = e & (C - 1); j = e >> p.logC; }
+    if (cbase + c >= p.nbatch) continue;
+    st16(dst + (long long)j * p.dk + (long long)c * p.dc, ld16(&s[(j << p.logC) + c]));
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static int set_lds_limit(lfgpu_ctx* c) {
+  static bool done = false;
+  if (!done) {
+    LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
+    LF_HIP(c, hipFuncSetAttribute((const void*)lch_fft_tile, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
+    done = true;
+  }
+  return LFGPU_OK;
+}
+
+static u32 floor_pow2_log(size_t x) {
+  u32 l = 0;
+  while (((size_t)2 << l) <= x) ++l;
+  return l;
+}
+
+static elt_t fp_reroot(elt_t w, u64 n, u64 r) {  // twiddle.h:47-55
+  while (r < n) {
+    w = fp_mul(w, w);
+    r += r;
+  }
+  return w;
+}
+
+static std::string keyf(const char* fmt, ...) {
+  char buf[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return std::string(buf);
+}
+
+// single-pass plan: T = n points, batch = rows
+static TilePlan plan_single(void* A, size_t rows, u32 logn, size_t ld) {
+  TilePlan p{};
+  u32 logC = 13 - logn;
+  u32 need = lf_log2(rows);
+  if (logC > need) logC = need;
+  p.src = (const elt_t*)A;
+  p.dst = (elt_t*)A;
+  p.src_row = p.dst_row = 0;
+  p.src_tile = p.dst_tile = (long long)ld << logC;
+  p.sk = p.dk = 1;
+  p.sc = p.dc = (long long)ld;
+  p.logT = logn;
+  p.logC = logC;
+  p.nbatch = (u32)rows;
+  p.kfast_src = p.kfast_dst = 1;
+  return p;
+}
+
+extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, const uint64_t omega[2],
+                               uint64_t omega_order, void* d_A, size_t ld) {
+  if (!c || !omega || (!d_A && rows && n)) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: null argument");
+  if (rows == 0 || n <= 1) return LFGPU_OK;
+  if (n & (n - 1)) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: n=%zu is not a power of two", n);
+  if (omega_order < n || (omega_order & (omega_order - 1)))
+    return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: omega_order must be a power of two >= n");
+  if (ld < n) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: ld < n");
+  if (rows > 0x7fffffffu) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: too many rows");
+  const u32 logn = lf_log2(n);
+  if (logn > 20) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "fp128_fft: n > 2^20 not covered yet");
+  LF_HIP(c, hipSetDevice(c->device));
+  LF_TRY(set_lds_limit(c));
+
+  elt_t w{omega[0], omega[1]};
+  if (dir == 1) w = h_fp_inv(w);  // fftf = fftb with omega^-1 (fft.h:198-201)
+  elt_t wn = fp_reroot(w, omega_order, n);
+  const u32 logn2 = logn <= 13 ? logn : 10, logn1 = logn - logn2;
+  const u32 logTw = logn1 > logn2 ? logn1 : logn2;  // root table covers the larger tile
+
+  // root table W[i] = w_Tw^i, i < Tw/2
+  void *dW = nullptr, *dlo = nullptr, *dhi = nullptr;
+  std::string key = keyf("fpW:%llx:%llx:%u:%u", (u64)wn.lo, (u64)wn.hi, logn, logTw);
+  if (!lf_table_lookup(c, key, &dW)) {
+    std::vector<elt_t> W((size_t)1 << (logTw ? logTw - 1 : 0));
+    elt_t wt = fp_reroot(wn, n, (u64)1 << logTw), x = h_fp_of_scalar(1);
+    for (size_t i = 0; i < W.size(); ++i) {
+      W[i] = x;
+      x = fp_mul(x, wt);
+    }
+    LF_TRY(lf_table(c, key, W.data(), W.size() * 16, &dW));
+  }
+  if (logn1 == 0) {
+    TilePlan p = plan_single(d_A, rows, logn, ld);
+    u32 ntiles = (u32)((rows + (1u << p.logC) - 1) >> p.logC);
+    size_t lds = ((size_t)16 << p.logT) << p.logC;
+    hipLaunchKernelGGL(fp_fft_tile, dim3(ntiles, 1), dim3(FFT_THREADS), lds, c->stream, p, (const elt_t*)dW,
+                       logTw - logn, (const elt_t*)nullptr, (const elt_t*)nullptr);
+    LF_HIP(c, hipGetLastError());
+    return LFGPU_OK;
+  }
+  // two passes: inter-pass twiddles w_n^e = lo[e & 1023] * hi[e >> 10]
+  std::string klo = key + ":lo", khi = key + ":hi";
+  if (!lf_table_lookup(c, klo, &dlo) || !lf_table_lookup(c, khi, &dhi)) {
+    std::vector<elt_t> lo(1024), hi((size_t)1 << (logn - 10));
+    elt_t x = h_fp_of_scalar(1);
+    for (size_t i = 0; i < 1024; ++i) {
+      lo[i] = x;
+      x = fp_mul(x, wn);
+    }
+    elt_t w1024 = x;  // wn^1024
+    x = h_fp_of_scalar(1);
+    for (size_t i = 0; i < hi.size(); ++i) {
+      hi[i] = x;
+      x = fp_mul(x, w1024);
+    }
+    LF_TRY(lf_table(c, klo, lo.data(), lo.size() * 16, &dlo));
+    LF_TRY(lf_table(c, khi, hi.data(), hi.size() * 16, &dhi));
+  }
+  void* scratch = nullptr;
+  LF_TRY(lf_scratch(c, rows * n * 16, &scratch));
+  const size_t n1 = (size_t)1 << logn1, n2 = (size_t)1 << logn2;
+  {  // pass A: n1-point transforms over k1 (stride n2), C consecutive k2 per tile
+    TilePlan p{};
+    p.logT = logn1;
+    p.logC = 13 - logn1;
+    if (p.logC > logn2) p.logC = logn2;
+    p.src = (const elt_t*)d_A;
+    p.dst = (elt_t*)scratch;
+    p.src_row = (long long)ld;
+    p.dst_row = (long long)n;
+    p.src_tile = p.dst_tile = 1ll << p.logC;
+    p.sk = p.dk = (long long)n2;
+    p.sc = p.dc = 1;
+    p.nbatch = (u32)n2;
+    p.kfast_src = p.kfast_dst = 0;
+    size_t lds = ((size_t)16 << p.logT) << p.logC;
+    hipLaunchKernelGGL(fp_fft_tile, dim3((u32)(n2 >> p.logC), (u32)rows), dim3(FFT_THREADS), lds, c->stream, p,
+                       (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi);
+    LF_HIP(c, hipGetLastError());
+  }
+  {  // pass B: n2-point transforms on contiguous rows j1; output X[j1 + n1*j2]
+    TilePlan p{};
+    p.logT = logn2;
+    p.logC = 13 - logn2;
+    if (p.logC > logn1) p.logC = logn1;
+    p.src = (const elt_t*)scratch;
+    p.dst = (elt_t*)d_A;
+    p.src_row = (long long)n;
+    p.dst_row = (long long)ld;
+    p.src_tile = (long long)n2 << p.logC;
+    p.dst_tile = 1ll << p.logC;
+    p.sk = 1;
+    p.sc = (long long)n2;
+    p.dk = (long long)n1;
+    p.dc = 1;
+    p.nbatch = (u32)n1;
+    p.kfast_src = 1;
+    p.kfast_dst = 0;
+    size_t lds = ((size_t)16 << p.logT) << p.logC;
+    hipLaunchKernelGGL(fp_fft_tile, dim3((u32)(n1 >> p.logC), (u32)rows), dim3(FFT_THREADS), lds, c->stream, p,
+                       (const elt_t*)dW, logTw - logn2, (const elt_t*)nullptr, (const elt_t*)nullptr);
+    LF_HIP(c, hipGetLastError());
+  }
+  return LFGPU_OK;
+}
+
+// Build (and cache) LCH14 twiddle tables for one tile pass.
+//   with_coset: fold `coset` into tbl (pass A / single pass); otherwise tbl is coset-free
+//   and base[ii*nb + blk] = twiddle(i, coset ^ (blk << logT)) carries coset and block bits.
+static int lch_tables(lfgpu_ctx* c, const GfHostCtx* g, u32 i_lo, u32 logT, u64 coset, bool with_coset, u32 nb,
+                      LchTables* out) {
+  std::string key = keyf("lch:%u:%u:%u:%llx:%d:%u", g->k, i_lo, logT, (u64)coset, (int)with_coset, nb);
+  void *dt = nullptr, *db = nullptr;
+  u32 off = 0;
+  for (u32 ii = 0; ii < logT; ++ii) {
+    out->off[ii] = off;
+    off += 1u << (logT - 1 - ii);
+  }
+  if (!lf_table_lookup(c, key, &dt)) {
+    std::vector<elt_t> tbl(off ? off : 1);
+    for (u32 ii = 0; ii < logT; ++ii) {
+      u32 i = i_lo + ii, cnt = 1u << (logT - 1 - ii);
+      for (u32 u = 0; u < cnt; ++u) {
+        u64 x = (u64)u << (i + 1);
+        if (with_coset) x ^= coset;
+        tbl[out->off[ii] + u] = h_lch14_twiddle(g, i, x);
+      }
+    }
+    LF_TRY(lf_table(c, key, tbl.data(), tbl.size() * 16, &dt));
+  }
+  out->tbl = (const elt_t*)dt;
+  out->base = nullptr;
+  out->nb = nb;
+  if (!with_coset) {
+    std::string kb = key + ":base";
+    if (!lf_table_lookup(c, kb, &db)) {
+      std::vector<elt_t> base((size_t)logT * nb);
+      for (u32 ii = 0; ii < logT; ++ii)
+        for (u32 b = 0; b < nb; ++b)
+          base[(size_t)ii * nb + b] = h_lch14_twiddle(g, i_lo + ii, coset ^ ((u64)b << (i_lo + logT)));
+      LF_TRY(lf_table(c, kb, base.data(), base.size() * 16, &db));
+    }
+    out->base = (const elt_t*)db;
+  }
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx* c, int k, int dir, size_t rows, unsigned l, uint64_t coset,
+                                      void* d_B, size_t ld) {
+  if (!c || (!d_B && rows)) return lf_fail(c, LFGPU_ERR_ARG, "lch14_fft: null argument");
+  const GfHostCtx* g = lf_gf_ctx(c, k);
+  if (!g) return lf_fail(c, LFGPU_ERR_ARG, "lch14_fft: subfield_log_bits must be 4 or 5");
+  if (l > g->sub_bits) return lf_fail(c, LFGPU_ERR_ARG, "lch14_fft: l <= kSubFieldBits violated (lch14.h:107)");
+  if (rows == 0 || l == 0) return LFGPU_OK;
+  if (l > 20) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "lch14_fft: l > 20 not covered yet");
+  if (ld < ((size_t)1 << l)) return lf_fail(c, LFGPU_ERR_ARG, "lch14_fft: ld < 2^l");
+  if (rows > 0x7fffffffu) return lf_fail(c, LFGPU_ERR_ARG, "lch14_fft: too many rows");
+  LF_HIP(c, hipSetDevice(c->device));
+  LF_TRY(set_lds_limit(c));
+  const int inverse = dir ? 1 : 0;
+  if (l <= 13) {
+    TilePlan p = plan_single(d_B, rows, l, ld);
+    LchTables t{};
+    LF_TRY(lch_tables(c, g, 0, l, coset, true, 1, &t));
+    u32 ntiles = (u32)((rows + (1u << p.logC) - 1) >> p.logC);
+    size_t lds = ((size_t)16 << p.logT) << p.logC;
+    hipLaunchKernelGGL(lch_fft_tile, dim3(ntiles, 1), dim3(FFT_THREADS), lds, c->stream, p, inverse, t);
+    LF_HIP(c, hipGetLastError());
+    return LFGPU_OK;
+  }
+  const u32 lo = 10, logn1 = l - lo;
+  const size_t n1 = (size_t)1 << logn1, n2 = (size_t)1 << lo;
+  TilePlan pa{}, pb{};
+  LchTables ta{}, tb{};
+  // pass A: stages i >= lo over k1 (stride n2); twiddle index u = k1 >> (ii+1): no block term
+  pa.logT = logn1;
+  pa.logC = 13 - logn1;
+  if (pa.logC > lo) pa.logC = lo;
+  pa.src = (const elt_t*)d_B;
+  pa.dst = (elt_t*)d_B;
+  pa.src_row = pa.dst_row = (long long)ld;
+  pa.src_tile = pa.dst_tile = 1ll << pa.logC;
+  pa.sk = pa.dk = (long long)n2;
+  pa.sc = pa.dc = 1;
+  pa.nbatch = (u32)n2;
+  pa.kfast_src = pa.kfast_dst = 0;
+  LF_TRY(lch_tables(c, g, lo, logn1, coset, true, 1, &ta));
+  // pass B: stages i < lo on contiguous blocks k1; C consecutive blocks per tile
+  pb.logT = lo;
+  pb.logC = 13 - lo;
+  if (pb.logC > logn1) pb.logC = logn1;
+  pb.src = (const elt_t*)d_B;
+  pb.dst = (elt_t*)d_B;
+  pb.src_row = pb.dst_row = (long long)ld;
+  pb.src_tile = pb.dst_tile = (long long)n2 << pb.logC;
+  pb.sk = pb.dk = 1;
+  pb.sc = pb.dc = (long long)n2;
+  pb.nbatch = (u32)n1;
+  pb.kfast_src = pb.kfast_dst = 1;
+  LF_TRY(lch_tables(c, g, 0, lo, coset, false, (u32)n1, &tb));
+  size_t lds_a = ((size_t)16 << pa.logT) << pa.logC, lds_b = ((size_t)16 << pb.logT) << pb.logC;
+  dim3 ga((u32)(n2 >> pa.logC), (u32)rows), gb((u32)(n1 >> pb.logC), (u32)rows);
+  if (!inverse) {  // FFT: stages l-1 .. 0
+    hipLaunchKernelGGL(lch_fft_tile, ga, dim3(FFT_THREADS), lds_a, c->stream, pa, 0, ta);
+    hipLaunchKernelGGL(lch_fft_tile, gb, dim3(FFT_THREADS), lds_b, c->stream, pb, 0, tb);
+  } else {  // IFFT: stages 0 .. l-1
+    hipLaunchKernelGGL(lch_fft_tile, gb, dim3(FFT_THREADS), lds_b, c->stream, pb, 1, tb);
+    hipLaunchKernelGGL(lch_fft_tile, ga, dim3(FFT_THREADS), lds_a, c->stream, pa, 1, ta);
+  }
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_fp128_fft_host(lfgpu_ctx* c, int dir, size_t n, const uint64_t omega[2], uint64_t omega_order,
+                                    void* h_A) {
+  if (!c || !h_A) return LFGPU_ERR_ARG;
+  void* d = nullptr;
+  LF_TRY(lf_scratch2(c, n * 16, &d));
+  LF_HIP(c, hipMemcpyAsync(d, h_A, n * 16, hipMemcpyHostToDevice, c->stream));
+  LF_TRY(lfgpu_fp128_fft(c, dir, 1, n, omega, omega_order, d, n));
+  LF_HIP(c, hipMemcpyAsync(h_A, d, n * 16, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_gf2128_lch14_fft_host(lfgpu_ctx* c, int k, int dir, unsigned l, uint64_t coset, void* h_B) {
+  if (!c || !h_B) return LFGPU_ERR_ARG;
+  size_t n = (size_t)1 << l;
+  void* d = nullptr;
+  LF_TRY(lf_scratch2(c, n * 16, &d));
+  LF_HIP(c, hipMemcpyAsync(d, h_B, n * 16, hipMemcpyHostToDevice, c->stream));
+  LF_TRY(lfgpu_gf2128_lch14_fft(c, k, dir, 1, l, coset, d, n));
+  LF_HIP(c, hipMemcpyAsync(h_B, d, n * 16, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  return LFGPU_OK;
+}

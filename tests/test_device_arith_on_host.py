@@ -1,0 +1,79 @@
+"""The device arithmetic in longfellow-zk_amd/csrc/fields.h is LF_HD (host+device); here its
+HOST compilation is checked against the oracle, so carry/borrow logic errors surface in the
+CPU-only container before any GPU run.  (The GPU parity tests exercise the device build.)"""
+import ctypes as C
+import hashlib
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from oracle_lib import FP, GF, P, elt, arr
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libhostfields.so")
+SRC = os.path.join(HERE, "host_fields.hip")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _lib():
+    hdr = os.path.join(ol.ROOT, "longfellow-zk_amd", "csrc", "fields.h")
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
+        if not os.path.exists(HIPCC):
+            pytest.skip("hipcc not available")
+        subprocess.check_call([HIPCC, "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
+    return C.CDLL(SO)
+
+
+def _bin(fn, a, b):
+    out = np.zeros(2, dtype=np.uint64)
+    fn(P(a), P(b), P(out))
+    return out
+
+
+def test_fp_ops_match_oracle():
+    L, o = _lib(), ol.oracle()
+    rng = np.random.default_rng(5)
+    xs, ys = ol.rand_elts(rng, 5000, FP), ol.rand_elts(rng, 5000, FP)
+    pm1 = np.array([0, 0xFFFFF00000000000], dtype=np.uint64)
+    edge = [np.array(v, dtype=np.uint64) for v in ([0, 0], [1, 0], pm1, [0xFFFFFFFFFFFFFFFF, 0xFFFFEFFFFFFFFFFF],
+                                                   [0xFFFFFFFFFFFFFFFF, 0], [0, 1], [0, 0xFFFFF00000000000 - 1])]
+    k = 0
+    for a in edge:
+        for b in edge:
+            xs[k], ys[k] = a, b
+            k += 1
+    for x, y in zip(xs, ys):
+        assert (_bin(L.hf_fp_mul, x, y) == arr(o.lfo_fp_mul(elt(x), elt(y)))).all()
+        assert (_bin(L.hf_fp_add, x, y) == arr(o.lfo_fp_add(elt(x), elt(y)))).all()
+        assert (_bin(L.hf_fp_sub, x, y) == arr(o.lfo_fp_sub(elt(x), elt(y)))).all()
+
+
+def test_gf_mul_matches_oracle():
+    L, o = _lib(), ol.oracle()
+    rng = np.random.default_rng(6)
+    xs, ys = ol.rand_elts(rng, 5000), ol.rand_elts(rng, 5000)
+    xs[0] = 0
+    ys[1] = 0
+    xs[2] = [0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF]
+    ys[2] = [0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF]
+    for x, y in zip(xs, ys):
+        assert (_bin(L.hf_gf_mul, x, y) == arr(o.lfo_gf_mul(elt(x), elt(y)))).all()
+
+
+def test_sha_compress_matches_hashlib():
+    L = _lib()
+    rng = np.random.default_rng(7)
+    for nblk in (1, 2, 5):
+        # message of 64*nblk - 9 bytes so the padded message is exactly nblk blocks
+        msg = bytes(rng.integers(0, 256, size=64 * nblk - 9, dtype=np.uint8))
+        padded = msg + b"\x80" + (len(msg) * 8).to_bytes(8, "big")
+        assert len(padded) == 64 * nblk
+        h = np.zeros(8, dtype=np.uint32)
+        buf = np.frombuffer(padded, dtype=np.uint8).copy()
+        L.hf_sha_blocks(P(buf), nblk, P(h))
+        got = b"".join(int(x).to_bytes(4, "big") for x in h)
+        assert got == hashlib.sha256(msg).digest()

@@ -1,0 +1,306 @@
+"""GPU parity: every kernel, called through the C ABI, against the CPU oracle on the same
+seeded inputs -- bit-exact (integer / GF(2) arithmetic, no tolerance)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from oracle_lib import FP, GF, P, elt, arr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_util
+    return gpu_util
+
+
+# ---------------------------------------------------------------- K1 Fp128 FFT
+@pytest.mark.parametrize("n,rows", [(2, 1), (4, 3), (64, 5), (1024, 2), (8192, 3), (1 << 14, 2), (1 << 16, 1), (1 << 17, 2)])
+@pytest.mark.parametrize("forward", [False, True])
+def test_fp128_fft(G, n, rows, forward):
+    o = ol.oracle()
+    a = np.zeros((rows, n, 2), dtype=np.uint64)
+    for r in range(rows):
+        o.lfo_fp_bogorng_fill(1234569 + r, n, P(a[r]))
+    want = a.copy()
+    for r in range(rows):
+        (o.lfo_fp_fftf if forward else o.lfo_fp_fftb)(P(want[r]), n, o.lfo_fp_omega32(), 1 << 32)
+    d = G.to_dev(a)
+    G.gpu().fp128_fft(d.data_ptr(), rows, n, forward=forward)
+    got = G.from_dev(d, np.uint64, (rows, n, 2))
+    assert (got == want).all()
+
+
+def test_fp128_fft_strided_rows_and_noop(G):
+    o = ol.oracle()
+    n, ld, rows = 256, 300, 4
+    a = np.zeros((rows, ld, 2), dtype=np.uint64)
+    o.lfo_fp_bogorng_fill(99, rows * ld, P(a))
+    want = a.copy()
+    for r in range(rows):
+        o.lfo_fp_fftb(P(want[r]), n, o.lfo_fp_omega32(), 1 << 32)
+    d = G.to_dev(a)
+    G.gpu().fp128_fft(d.data_ptr(), rows, n, ld=ld)
+    assert (G.from_dev(d, np.uint64, (rows, ld, 2)) == want).all()
+    # n = 1 and rows = 0 are no-ops (fft.h:187 `if (n > 1)`)
+    G.gpu().fp128_fft(d.data_ptr(), rows, 1, ld=ld)
+    G.gpu().fp128_fft(d.data_ptr(), 0, n, ld=ld)
+    assert (G.from_dev(d, np.uint64, (rows, ld, 2)) == want).all()
+    with pytest.raises(G.pkg.LfGpuError):
+        G.gpu().fp128_fft(d.data_ptr(), 1, 96, ld=ld)  # not a power of two
+
+
+def test_fp128_fft_roundtrip_full_size(G):
+    """size-independent property at a BASELINE-sized row: fftb(fftf(x)) = n*x (fft_test.cc:56-72)"""
+    import torch
+    o = ol.oracle()
+    n = 1 << 20
+    a = np.zeros((n, 2), dtype=np.uint64)
+    o.lfo_fp_bogorng_fill(1234569, n, P(a))
+    d = G.to_dev(a)
+    G.gpu().fp128_fft(d.data_ptr(), 1, n, forward=True)
+    G.gpu().fp128_fft(d.data_ptr(), 1, n, forward=False)
+    got = G.from_dev(d, np.uint64, (n, 2))
+    nn = o.lfo_fp_of_scalar(n)
+    for i in list(range(0, n, 65521))[:64] + [n - 1]:
+        assert (got[i] == arr(o.lfo_fp_mul(elt(a[i]), nn))).all()
+
+
+# ---------------------------------------------------------------- K2 LCH14 FFT
+@pytest.mark.parametrize("k,l,coset,rows", [(4, 1, 0, 3), (4, 4, 16, 2), (4, 10, 0, 3), (4, 10, 5 << 10, 9), (4, 13, 0, 2),
+                                            (4, 14, 0, 2), (4, 16, 0, 1), (5, 17, 3 << 17, 1), (5, 11, 1 << 11, 4)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_lch14_fft(G, k, l, coset, rows, inverse):
+    o = ol.oracle()
+    c = ol.gf_ctx(k)
+    rng = np.random.default_rng(l * 7 + k)
+    a = ol.rand_elts(rng, rows << l).reshape(rows, 1 << l, 2)
+    want = a.copy()
+    for r in range(rows):
+        (o.lfo_lch14_ifft if inverse else o.lfo_lch14_fft)(C.byref(c), l, coset, P(want[r]))
+    d = G.to_dev(a)
+    G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, coset=coset, inverse=inverse, subfield_log_bits=k)
+    assert (G.from_dev(d, np.uint64, a.shape) == want).all()
+
+
+def test_lch14_fft_roundtrip_full_size(G):
+    """IFFT(FFT(x)) = x at l = 20 (GF2_128<5>), the BASELINE row length"""
+    rng = np.random.default_rng(20)
+    a = ol.rand_elts(rng, 1 << 20)
+    d = G.to_dev(a)
+    G.gpu().gf2128_lch14_fft(d.data_ptr(), 1, 20, subfield_log_bits=5)
+    mid = G.from_dev(d, np.uint64, a.shape).copy()
+    assert not (mid == a).all()
+    G.gpu().gf2128_lch14_fft(d.data_ptr(), 1, 20, inverse=True, subfield_log_bits=5)
+    assert (G.from_dev(d, np.uint64, a.shape) == a).all()
+    with pytest.raises(G.pkg.LfGpuError):
+        G.gpu().gf2128_lch14_fft(d.data_ptr(), 1, 17, subfield_log_bits=4)  # l <= kSubFieldBits (lch14.h:107)
+
+
+# ---------------------------------------------------------------- K3 / K4 RS rows
+@pytest.mark.parametrize("k,n,m,nrow", [(4, 1, 7, 2), (4, 5, 5, 2), (4, 21, 128, 8), (4, 100, 128, 3), (4, 64, 64, 1),
+                                        (4, 64, 300, 2), (4, 455, 4096, 20), (4, 909, 4096, 3), (4, 910, 8192, 5),
+                                        (4, 1819, 8192, 2), (4, 682, 4096, 8), (4, 461, 4151, 3), (5, 1000, 5000, 2)])
+def test_gf2128_rs_encode_rows(G, k, n, m, nrow):
+    o = ol.oracle()
+    rng = np.random.default_rng(n * 3 + m)
+    ld = m + 3
+    T = ol.rand_elts(rng, nrow * ld).reshape(nrow, ld, 2)
+    want = T.copy()
+    for r in range(nrow):
+        o.lfo_lch14_rs_interpolate(C.byref(ol.gf_ctx(k)), n, m, P(want[r]))
+    d = G.to_dev(T)
+    G.gpu().gf2128_rs_encode_rows(d.data_ptr(), nrow, n, m, ld=ld, subfield_log_bits=k)
+    assert (G.from_dev(d, np.uint64, T.shape) == want).all()
+
+
+@pytest.mark.parametrize("n,m,nrow", [(1, 4, 2), (3, 8, 2), (21, 128, 4), (100, 257, 3), (455, 4096, 2)])
+def test_fp128_rs_encode_rows(G, n, m, nrow):
+    o = ol.oracle()
+    T = np.zeros((nrow, m, 2), dtype=np.uint64)
+    o.lfo_fp_bogorng_fill(5 + n, nrow * m, P(T))
+    want = T.copy()
+    for r in range(nrow):
+        o.lfo_fp_rs_interpolate(n, m, P(want[r]))
+    d = G.to_dev(T)
+    G.gpu().fp128_rs_encode_rows(d.data_ptr(), nrow, n, m)
+    assert (G.from_dev(d, np.uint64, T.shape) == want).all()
+
+
+# ---------------------------------------------------------------- K5 / K6 Merkle
+@pytest.mark.parametrize("field,nrow,ld,col0,ncols", [(GF, 1, 8, 0, 8), (GF, 2, 8, 1, 1), (GF, 20, 4096, 909, 3187),
+                                                      (GF, 150, 8192, 1819, 6373), (GF, 7, 64, 13, 51),
+                                                      (FP, 5, 40, 9, 31), (FP, 19, 4096, 909, 3187), (FP, 3, 3, 1, 2)])
+def test_column_commit(G, field, nrow, ld, col0, ncols):
+    import torch
+    o = ol.oracle()
+    rng = np.random.default_rng(nrow * ld)
+    T = ol.rand_elts(rng, nrow * ld, field)
+    nonces = rng.integers(0, 256, size=(ncols, 32), dtype=np.uint8)
+    layers = np.zeros((2 * ncols, 32), dtype=np.uint8)
+    root = np.zeros(32, dtype=np.uint8)
+    o.lfo_column_commit(field, nrow, ld, col0, ncols, P(T), P(nonces), P(root), P(layers))
+    dT, dN = G.to_dev(T), G.to_dev(nonces)
+    dL = torch.zeros(2 * ncols * 32, dtype=torch.uint8, device="cuda")
+    got = G.gpu().column_commit(field, nrow, ld, col0, ncols, dT.data_ptr(), dN.data_ptr(), dL.data_ptr())
+    assert got == bytes(root)
+    gl = G.from_dev(dL, np.uint8, (2 * ncols, 32))
+    assert (gl[1:] == layers[1:]).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 1000, 2049, 70000])
+def test_merkle_build_tree_and_open(G, n):
+    o = ol.oracle()
+    rng = np.random.default_rng(n)
+    leaves = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    layers = np.zeros((2 * n, 32), dtype=np.uint8)
+    o.lfo_merkle_build_tree(n, P(leaves), P(layers))
+    dev = np.zeros((2 * n, 32), dtype=np.uint8)
+    dev[n:] = leaves
+    d = G.to_dev(dev)
+    root = G.gpu().merkle_build_tree(n, d.data_ptr())
+    assert root == bytes(layers[1])
+    # compressed opening (merkle_tree.h:122-143) replayed on the host from the oracle's layers
+    pos = sorted(set(int(x) for x in rng.integers(0, n, size=min(n, 7))))
+    tree = [False] * (2 * n)
+    for p_ in pos:
+        tree[p_ + n] = True
+    for i in range(n - 1, 0, -1):
+        tree[i] = tree[2 * i] or tree[2 * i + 1]
+    want = []
+    for i in range(n - 1, 0, -1):
+        if tree[i]:
+            ch = 2 * i
+            if tree[ch]:
+                ch = 2 * i + 1
+            if not tree[ch]:
+                want.append(bytes(layers[ch]))
+    assert G.gpu().merkle_open(n, d.data_ptr(), pos) == want
+
+
+# ---------------------------------------------------------------- K7 / K8 / K9 sumcheck round
+@pytest.mark.parametrize("field", [GF, FP])
+@pytest.mark.parametrize("n", [1, 2, 3, 8, 17, 1000, 1001, 1 << 16, (1 << 18) + 1])
+def test_sumcheck_partials_and_dense_bind(G, field, n):
+    import torch
+    o = ol.oracle()
+    rng = np.random.default_rng(n + field)
+    QW, W = ol.rand_elts(rng, n, field), ol.rand_elts(rng, n, field)
+    a0, a2 = ol.Elt(), ol.Elt()
+    o.lfo_sumcheck_partials(field, n, P(QW), P(W), C.byref(a0), C.byref(a2))
+    dQ, dW = G.to_dev(QW), G.to_dev(W)
+    g0, g2 = G.gpu().sumcheck_partials(field, n, dQ.data_ptr(), dW.data_ptr())
+    assert g0 == (a0.l[0], a0.l[1]) and g2 == (a2.l[0], a2.l[1])
+    r = ol.rand_elts(rng, 1, field)[0]
+    want = np.zeros(((n + 1) // 2, 2), dtype=np.uint64)
+    o.lfo_dense_bind(field, n, elt(r), P(W), P(want))
+    dO = torch.zeros(((n + 1) // 2) * 16, dtype=torch.uint8, device="cuda")
+    G.gpu().dense_bind(field, n, (int(r[0]), int(r[1])), dW.data_ptr(), dO.data_ptr())
+    assert (G.from_dev(dO, np.uint64, want.shape) == want).all()
+    # in place (Dense::bind(r, F) binds *this)
+    G.gpu().dense_bind(field, n, (int(r[0]), int(r[1])), dW.data_ptr(), dW.data_ptr())
+    assert (G.from_dev(dW, np.uint64, (n, 2))[:(n + 1) // 2] == want).all()
+
+
+def _morton(a, b):
+    m = 0
+    for i in range(16):
+        m |= ((a >> i) & 1) << (2 * i) | ((b >> i) & 1) << (2 * i + 1)
+    return m
+
+
+@pytest.mark.parametrize("field", [GF, FP])
+def test_hquad_bind_h_rounds(G, field):
+    import torch
+    o = ol.oracle()
+    rng = np.random.default_rng(11)
+    pts = sorted({(int(a), int(b)) for a, b in rng.integers(0, 512, size=(60000, 2))}, key=lambda p: _morton(*p))
+    hc = np.array(pts, dtype=np.uint32)
+    n = len(pts)
+    vc = ol.rand_elts(rng, n, field)
+    hand = 0
+    for _ in range(8):
+        r = ol.rand_elts(rng, 1, field)[0]
+        ha, va = hc.copy(), vc.copy()
+        na = o.lfo_hquad_bind_h(field, n, P(ha), P(va), elt(r), hand)
+        dh, dv = G.to_dev(hc), G.to_dev(vc)
+        dho = torch.zeros(n * 8, dtype=torch.uint8, device="cuda")
+        dvo = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+        nb = G.gpu().hquad_bind_h(field, n, dh.data_ptr(), dv.data_ptr(), (int(r[0]), int(r[1])), hand,
+                                  dho.data_ptr(), dvo.data_ptr())
+        assert nb == na
+        assert (G.from_dev(dho, np.uint32, (n, 2))[:nb] == ha[:na]).all()
+        assert (G.from_dev(dvo, np.uint64, (n, 2))[:nb] == va[:na]).all()
+        hc, vc, n = ha[:na].copy(), va[:na].copy(), na
+        hand = 1 - hand
+
+
+def test_qw_scatter_gf(G):
+    import torch
+    o = ol.oracle()
+    rng = np.random.default_rng(12)
+    nw = 4096
+    n = 50000
+    hc = rng.integers(0, nw, size=(n, 2)).astype(np.uint32)
+    vc = ol.rand_elts(rng, n)
+    W = ol.rand_elts(rng, nw)
+    for hand in (0, 1):
+        want = np.zeros((nw, 2), dtype=np.uint64)
+        o.lfo_qw_scatter(GF, n, P(hc), P(vc), hand, P(W), nw, P(want))
+        dh, dv, dw = G.to_dev(hc), G.to_dev(vc), G.to_dev(W)
+        dq = torch.ones(nw * 16, dtype=torch.uint8, device="cuda")
+        G.gpu().qw_scatter(GF, n, dh.data_ptr(), dv.data_ptr(), hand, dw.data_ptr(), nw, dq.data_ptr())
+        assert (G.from_dev(dq, np.uint64, (nw, 2)) == want).all()
+
+
+# ---------------------------------------------------------------- K12 row combos
+@pytest.mark.parametrize("field", [GF, FP])
+def test_rows_axpy_and_gather(G, field):
+    import torch
+    o = ol.oracle()
+    rng = np.random.default_rng(13)
+    nrows, n, ld = 17, 910, 1000
+    T = ol.rand_elts(rng, nrows * ld, field).reshape(nrows, ld, 2)
+    u = ol.rand_elts(rng, nrows, field)
+    y = ol.rand_elts(rng, n, field)
+    want = y.copy()
+    for i in range(nrows):
+        o.lfo_axpy(field, n, P(want), elt(u[i]), P(T[i]))
+    dT, dy = G.to_dev(T), G.to_dev(y)
+    G.gpu().rows_axpy(field, nrows, n, dy.data_ptr(), u, dT.data_ptr(), ld)
+    assert (G.from_dev(dy, np.uint64, (n, 2)) == want).all()
+    idx = [int(x) for x in rng.choice(ld - 50, size=36, replace=False)]
+    dreq = torch.zeros(nrows * 36 * 16, dtype=torch.uint8, device="cuda")
+    G.gpu().gather_columns(nrows, ld, 50, dT.data_ptr(), idx, dreq.data_ptr())
+    got = G.from_dev(dreq, np.uint64, (nrows, 36, 2))
+    assert (got == T[:, [50 + i for i in idx], :]).all()
+
+
+def test_host_buffer_wrappers(G):
+    o = ol.oracle()
+    rng = np.random.default_rng(14)
+    a = np.zeros((512, 2), dtype=np.uint64)
+    o.lfo_fp_bogorng_fill(3, 512, P(a))
+    want = a.copy()
+    o.lfo_fp_fftb(P(want), 512, o.lfo_fp_omega32(), 1 << 32)
+    G.gpu().fp128_fft_host(a)
+    assert (a == want).all()
+    b = ol.rand_elts(rng, 256)
+    wb = b.copy()
+    o.lfo_lch14_fft(C.byref(ol.gf_ctx(4)), 8, 256, P(wb))
+    G.gpu().gf2128_lch14_fft_host(b, 8, coset=256)
+    assert (b == wb).all()
+    nrow, n, m = 6, 21, 128
+    T = ol.rand_elts(rng, nrow * m).reshape(nrow, m, 2)
+    wT = T.copy()
+    for r in range(nrow):
+        o.lfo_lch14_rs_interpolate(C.byref(ol.gf_ctx(4)), n, m, P(wT[r]))
+    G.gpu().gf2128_rs_encode_rows_host(T, nrow, n, m, m)
+    assert (T == wT).all()
+    nonces = rng.integers(0, 256, size=(m - 41, 32), dtype=np.uint8)
+    root = np.zeros(32, dtype=np.uint8)
+    o.lfo_column_commit(GF, nrow, m, 41, m - 41, P(wT), P(nonces), P(root), None)
+    assert G.gpu().column_commit_host(GF, T, nrow, m, 41, m - 41, nonces) == bytes(root)
