@@ -304,3 +304,22 @@ def test_host_buffer_wrappers(G):
     root = np.zeros(32, dtype=np.uint8)
     o.lfo_column_commit(GF, nrow, m, 41, m - 41, P(wT), P(nonces), P(root), None)
     assert G.gpu().column_commit_host(GF, T, nrow, m, 41, m - 41, nonces) == bytes(root)
+
+
+# ---------------------------------------------------------------- reference fixtures through the GPU
+def test_gpu_reference_merkle_fixtures(G):
+    """docs/specs/testvectors.md:7-22 and rust/runtime/merkle/tests/merkle_test_vector.bin
+    (C++-generated) reproduced by the HIP Merkle path: root and compressed proof bytes."""
+    import test_oracle_golden as tg
+    leaves = np.frombuffer(bytes.fromhex("".join(tg.SPEC_LEAVES)), dtype=np.uint8).reshape(5, 32)
+    dev = np.zeros((10, 32), dtype=np.uint8)
+    dev[5:] = leaves
+    d = G.to_dev(dev)
+    assert G.gpu().merkle_build_tree(5, d.data_ptr()).hex() == tg.SPEC_ROOT
+    assert [x.hex() for x in G.gpu().merkle_open(5, d.data_ptr(), [1, 3])] == [tg.SPEC_LEAVES[4], tg.SPEC_LEAVES[2], tg.SPEC_LEAVES[0]]
+    n, lv, idx, root, proof = tg.read_merkle_fixture()
+    dev = np.zeros((2 * n, 32), dtype=np.uint8)
+    dev[n:] = lv
+    d = G.to_dev(dev)
+    assert G.gpu().merkle_build_tree(n, d.data_ptr()) == root
+    assert G.gpu().merkle_open(n, d.data_ptr(), idx) == proof
