@@ -132,6 +132,44 @@ int lfgpu_rows_axpy(lfgpu_ctx* ctx, int field, size_t nrows, size_t n, void* d_y
 int lfgpu_gather_columns(lfgpu_ctx* ctx, size_t nrow, size_t ld, size_t col0, const void* d_T,
                          const size_t* h_idx, size_t nreq, void* d_req);
 
+/* ---- Ligero commit / prove on a device-resident tableau -----------------------
+ * The device boundary the survey recommends: inside LigeroProver::commit the witness is
+ * uploaded once, the tableau [nrow][block_enc] stays in HBM, and only the root (and later
+ * y_ldt / y_dot / y_quad / req) come back.  The Fiat-Shamir transcript and the
+ * RandomEngine stay with the caller: randomness is drawn through `rng` in exactly the
+ * reference's order (lib/ligero/ligero_prover.h:171-270, lib/merkle/merkle_commitment.h:54). */
+typedef struct {
+  /* LigeroParam (lib/ligero/ligero_param.h:117-307) */
+  size_t nw, nq, rateinv, nreq;
+  size_t block_enc, block, dblock, block_ext, r, w, nwrow, nqtriples, nwqrow, nrow, mc_pathlen;
+  size_t ildt, idot, iquad, iw, iq;
+} lfgpu_ligero_param;
+/* LigeroParam(nw, nq, rateinv, nreq, block_enc) ctor; LFGPU_ERR_ARG where the reference
+ * would check-fail ("block_enc too large").  field selects kSubFieldBytes (GF2_128<k>: 2^k/8). */
+int lfgpu_ligero_param_init(lfgpu_ligero_param* p, int field, int subfield_log_bits, size_t nw, size_t nq,
+                            size_t rateinv, size_t nreq, size_t block_enc);
+/* RandomEngine::bytes (lib/random/random.h:32-35) */
+typedef void (*lfgpu_rng_fn)(void* user, uint8_t* buf, size_t n);
+typedef struct lfgpu_ligero_prover lfgpu_ligero_prover;
+/* LigeroProver::commit (lib/ligero/ligero_prover.h:58-79) minus the transcript write:
+ * layout (blinding / witness / quadratic rows), RS-encode every row, Merkle-commit the
+ * columns [dblock, block_enc).  h_W: nw host elements; h_lqc: nq x {x,y,z}. */
+int lfgpu_ligero_commit(lfgpu_ctx* ctx, int field, int subfield_log_bits, const lfgpu_ligero_param* p,
+                        const void* h_W, size_t subfield_boundary, const size_t* h_lqc, lfgpu_rng_fn rng,
+                        void* rng_user, uint8_t root_out[32], lfgpu_ligero_prover** out);
+/* low_degree_proof (:281-291): y[block] = T[ildt] + sum_i u_ldt[i] T[iw+i] */
+int lfgpu_ligero_low_degree_proof(lfgpu_ligero_prover* pr, const void* h_u_ldt, void* h_y);
+/* dot_proof (:293-309): y[dblock] = T[idot] + sum_i RS(block->dblock)([0^r | A_i]) (.) T[iw+i] */
+int lfgpu_ligero_dot_proof(lfgpu_ligero_prover* pr, const void* h_A, void* h_y);
+/* quadratic_proof (:311-344); LFGPU_ERR_ASSERT if the W part of y is non-zero */
+int lfgpu_ligero_quadratic_proof(lfgpu_ligero_prover* pr, const void* h_u_quad, void* h_y0, void* h_y2);
+/* compute_req (:346-351) + MerkleCommitment::open (merkle_commitment.h:66-73) */
+int lfgpu_ligero_open(lfgpu_ligero_prover* pr, const size_t* idx, void* h_req, uint8_t* h_nonces,
+                      uint8_t* h_path, size_t path_cap, size_t* npath);
+/* device pointer of the resident tableau (nrow x block_enc elements) */
+int lfgpu_ligero_tableau(lfgpu_ligero_prover* pr, void** d_T);
+int lfgpu_ligero_free(lfgpu_ligero_prover* pr);
+
 /* ---- host-buffer conveniences (what the header-only adapters call) ---------- */
 int lfgpu_fp128_fft_host(lfgpu_ctx* ctx, int dir, size_t n, const uint64_t omega[2], uint64_t omega_order,
                          void* h_A);

@@ -28,7 +28,19 @@ ABI_SYMBOLS = [
     "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
     "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_fp128_fft_host", "lfgpu_gf2128_lch14_fft_host",
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
+    "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
+    "lfgpu_ligero_quadratic_proof", "lfgpu_ligero_open", "lfgpu_ligero_tableau", "lfgpu_ligero_free",
 ]
+
+
+class LigeroParam(C.Structure):
+    """lfgpu_ligero_param == LigeroParam (reference lib/ligero/ligero_param.h:117-307)"""
+    _fields_ = [(n, C.c_size_t) for n in (
+        "nw", "nq", "rateinv", "nreq", "block_enc", "block", "dblock", "block_ext", "r", "w", "nwrow", "nqtriples",
+        "nwqrow", "nrow", "mc_pathlen", "ildt", "idot", "iquad", "iw", "iq")]
+
+
+RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)  # RandomEngine::bytes
 
 
 class LfGpuError(RuntimeError):
@@ -69,6 +81,14 @@ def load_library():
         "lfgpu_gf2128_lch14_fft_host": [vp, ci, ci, C.c_uint, u64, vp],
         "lfgpu_gf2128_rs_encode_rows_host": [vp, ci, sz, sz, sz, vp, sz],
         "lfgpu_column_commit_host": [vp, ci, sz, sz, sz, sz, vp, vp, vp, vp],
+        "lfgpu_ligero_param_init": [C.POINTER(LigeroParam), ci, ci, sz, sz, sz, sz, sz],
+        "lfgpu_ligero_commit": [vp, ci, ci, C.POINTER(LigeroParam), vp, sz, vp, RNG_FN, vp, vp, C.POINTER(vp)],
+        "lfgpu_ligero_low_degree_proof": [vp, vp, vp],
+        "lfgpu_ligero_dot_proof": [vp, vp, vp],
+        "lfgpu_ligero_quadratic_proof": [vp, vp, vp, vp],
+        "lfgpu_ligero_open": [vp, vp, vp, vp, vp, sz, C.POINTER(sz)],
+        "lfgpu_ligero_tableau": [vp, C.POINTER(vp)],
+        "lfgpu_ligero_free": [vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -223,3 +243,89 @@ class LfGpu:
                                                  C.c_void_p(nonces.ctypes.data),
                                                  C.c_void_p(layers.ctypes.data) if layers is not None else None, root))
         return bytes(root)
+
+
+def ligero_param(field, nw, nq, rateinv, nreq, block_enc, subfield_log_bits=4):
+    """LigeroParam(nw, nq, rateinv, nreq, block_enc) (reference lib/ligero/ligero_param.h:172-178)"""
+    p = LigeroParam()
+    rc = load_library().lfgpu_ligero_param_init(C.byref(p), field, subfield_log_bits, nw, nq, rateinv, nreq, block_enc)
+    if rc != 0:
+        raise LfGpuError("LigeroParam layout failed (block_enc too large / too small)")
+    return p
+
+
+class LigeroProver:
+    """Mirror of LigeroProver<Field, InterpolatorFactory> (reference lib/ligero/ligero_prover.h:34-359)
+    over the C ABI: the tableau lives in HBM; the caller owns the transcript and the RandomEngine.
+    `rng_bytes(n) -> bytes` plays RandomEngine::bytes."""
+
+    def __init__(self, gpu, field, param, subfield_log_bits=4):
+        self.gpu, self.field, self.p, self.k = gpu, field, param, subfield_log_bits
+        self.h = None
+
+    def commit(self, W, subfield_boundary, lqc, rng_bytes):
+        """returns the 32-byte commitment root (LigeroProver::commit, :58-79, without ts.write)"""
+        import numpy as np
+        gpu = self.gpu
+
+        def cb(_user, buf, n):
+            data = rng_bytes(n)
+            C.memmove(buf, data, n)
+
+        self._cb = RNG_FN(cb)
+        lq = np.ascontiguousarray(np.asarray(lqc, dtype=np.uint64).reshape(-1))
+        W = np.ascontiguousarray(W)
+        root = (C.c_uint8 * 32)()
+        h = C.c_void_p()
+        gpu._ck(gpu.L.lfgpu_ligero_commit(gpu.h, self.field, self.k, C.byref(self.p), C.c_void_p(W.ctypes.data),
+                                           subfield_boundary, C.c_void_p(lq.ctypes.data) if lq.size else None,
+                                           self._cb, None, root, C.byref(h)))
+        self.h = h
+        return bytes(root)
+
+    def low_degree_proof(self, u_ldt):
+        import numpy as np
+        y = np.zeros((self.p.block, 2), dtype=np.uint64)
+        u = np.ascontiguousarray(u_ldt)
+        self.gpu._ck(self.gpu.L.lfgpu_ligero_low_degree_proof(self.h, C.c_void_p(u.ctypes.data), C.c_void_p(y.ctypes.data)))
+        return y
+
+    def dot_proof(self, A):
+        import numpy as np
+        y = np.zeros((self.p.dblock, 2), dtype=np.uint64)
+        A = np.ascontiguousarray(A)
+        self.gpu._ck(self.gpu.L.lfgpu_ligero_dot_proof(self.h, C.c_void_p(A.ctypes.data), C.c_void_p(y.ctypes.data)))
+        return y
+
+    def quadratic_proof(self, u_quad):
+        import numpy as np
+        y0 = np.zeros((self.p.r, 2), dtype=np.uint64)
+        y2 = np.zeros((self.p.dblock - self.p.block, 2), dtype=np.uint64)
+        u = np.ascontiguousarray(u_quad)
+        self.gpu._ck(self.gpu.L.lfgpu_ligero_quadratic_proof(self.h, C.c_void_p(u.ctypes.data) if u.size else None,
+                                                             C.c_void_p(y0.ctypes.data), C.c_void_p(y2.ctypes.data)))
+        return y0, y2
+
+    def open(self, idx):
+        """compute_req + MerkleCommitment::open -> (req[nrow][nreq], nonces[nreq], path digests)"""
+        import numpy as np
+        p = self.p
+        idx_a = (C.c_size_t * p.nreq)(*idx)
+        req = np.zeros((p.nrow, p.nreq, 2), dtype=np.uint64)
+        nonces = np.zeros((p.nreq, 32), dtype=np.uint8)
+        cap = p.nreq * p.mc_pathlen + 1
+        path = np.zeros((cap, 32), dtype=np.uint8)
+        npath = C.c_size_t()
+        self.gpu._ck(self.gpu.L.lfgpu_ligero_open(self.h, idx_a, C.c_void_p(req.ctypes.data), C.c_void_p(nonces.ctypes.data),
+                                                  C.c_void_p(path.ctypes.data), cap, C.byref(npath)))
+        return req, nonces, [bytes(path[i]) for i in range(npath.value)]
+
+    def tableau_ptr(self):
+        d = C.c_void_p()
+        self.gpu._ck(self.gpu.L.lfgpu_ligero_tableau(self.h, C.byref(d)))
+        return d.value
+
+    def close(self):
+        if self.h:
+            self.gpu.L.lfgpu_ligero_free(self.h)
+            self.h = None

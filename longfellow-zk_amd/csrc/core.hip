@@ -28,6 +28,7 @@ static int grow(lfgpu_ctx* c, void** buf, size_t* cap, size_t bytes, void** out)
 }
 int lf_scratch(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch, &c->scratch_bytes, bytes, out); }
 int lf_scratch2(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch2, &c->scratch2_bytes, bytes, out); }
+int lf_scratch3(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch3, &c->scratch3_bytes, bytes, out); }
 
 bool lf_table_lookup(lfgpu_ctx* c, const std::string& key, void** out) {
   auto it = c->tables.find(key);
@@ -144,6 +145,7 @@ int lfgpu_shutdown(lfgpu_ctx* c) {
   for (auto& kv : c->tables) hipFree(kv.second);
   if (c->scratch) hipFree(c->scratch);
   if (c->scratch2) hipFree(c->scratch2);
+  if (c->scratch3) hipFree(c->scratch3);
   if (c->mailbox_h) hipHostFree(c->mailbox_h);
   if (c->mailbox_d) hipFree(c->mailbox_d);
   delete c;

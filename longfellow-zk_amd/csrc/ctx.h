@@ -30,6 +30,8 @@ struct lfgpu_ctx {
   size_t scratch_bytes = 0;
   void* scratch2 = nullptr;
   size_t scratch2_bytes = 0;
+  void* scratch3 = nullptr;  // Ligero-level temporaries (never used by the kernels' own launchers)
+  size_t scratch3_bytes = 0;
   // cached device tables keyed by a string
   std::map<std::string, void*> tables;
   // cached host-side POD plans (e.g. RS op-list descriptors) keyed by a string
@@ -57,6 +59,7 @@ int lf_fail(lfgpu_ctx* c, int code, const char* fmt, ...);
 
 int lf_scratch(lfgpu_ctx* c, size_t bytes, void** out);
 int lf_scratch2(lfgpu_ctx* c, size_t bytes, void** out);
+int lf_scratch3(lfgpu_ctx* c, size_t bytes, void** out);
 // upload (and cache under `key`) a host table; returns device pointer
 int lf_table(lfgpu_ctx* c, const std::string& key, const void* host, size_t bytes, void** out);
 bool lf_table_lookup(lfgpu_ctx* c, const std::string& key, void** out);

@@ -1,0 +1,355 @@
+// ligero.hip -- LigeroProver::commit / prove on a device-resident tableau.
+//
+// Reference: LigeroParam::layout (lib/ligero/ligero_param.h:185-295),
+// LigeroProver::commit / layout_* / low_degree_proof / dot_proof / quadratic_proof /
+// compute_req (lib/ligero/ligero_prover.h:58-79,171-351), MerkleCommitment
+// (lib/merkle/merkle_commitment.h:50-73).
+//
+// Host side: all RandomEngine draws happen on the host in the reference's order (they do
+// not depend on computed data), the un-encoded rows are assembled in one host buffer and
+// uploaded once; the GPU then RS-encodes every row (K3/K4) and commits the columns
+// (K5/K6).  The tableau stays in HBM for the prove-side row combinations (K12).
+#include "ctx.h"
+
+struct lfgpu_ligero_prover {
+  lfgpu_ctx* c;
+  int field, k;
+  lfgpu_ligero_param p;
+  elt_t* d_T;             // [nrow][block_enc]
+  uint8_t* d_layers;      // [2*block_ext][32]
+  std::vector<uint8_t> nonces;  // block_ext * 32 (host copy for open)
+};
+
+static size_t ceildiv(size_t a, size_t b) { return (a + b - 1) / b; }
+static size_t merkle_tree_len(size_t n) {  // merkle_tree.h:62-70
+  size_t r = 1;
+  size_t pos = n - 1;
+  for (pos += n; pos > 1; pos >>= 1) ++r;
+  return r;
+}
+
+extern "C" int lfgpu_ligero_param_init(lfgpu_ligero_param* p, int field, int k, size_t nw, size_t nq, size_t rateinv,
+                                       size_t nreq, size_t block_enc) {
+  if (!p) return LFGPU_ERR_ARG;
+  memset(p, 0, sizeof(*p));
+  p->nw = nw;
+  p->nq = nq;
+  p->rateinv = rateinv;
+  p->nreq = nreq;
+  p->r = nreq;
+  const size_t max_lg_size = 28, max_size = (size_t)1 << max_lg_size;
+  p->block_enc = block_enc;
+  size_t subfield_bits = field == LFGPU_FIELD_GF2_128 ? ((size_t)1 << k) : 128;
+  if (subfield_bits <= max_lg_size && block_enc >= ((size_t)1 << subfield_bits)) return LFGPU_ERR_ARG;
+  if (block_enc > max_size || rateinv > max_size || (block_enc + 1) < (2 + rateinv)) return LFGPU_ERR_ARG;
+  p->block = (block_enc + 1) / (2 + rateinv);
+  if (p->block < p->r) return LFGPU_ERR_ARG;
+  p->w = p->block - p->r;
+  if (p->w < p->r) return LFGPU_ERR_ARG;
+  p->dblock = 2 * p->block - 1;
+  if (block_enc < p->dblock) return LFGPU_ERR_ARG;
+  p->block_ext = block_enc - p->dblock;
+  p->nwrow = ceildiv(nw, p->w);
+  p->nqtriples = ceildiv(nq, p->w);
+  p->nwqrow = p->nwrow + 3 * p->nqtriples;
+  p->nrow = p->nwqrow + 3;
+  if (p->nrow >= max_size / block_enc) return LFGPU_ERR_ARG;
+  if (p->block_ext == 0) return LFGPU_ERR_ARG;
+  p->mc_pathlen = merkle_tree_len(p->block_ext);
+  if (!(block_enc > p->block)) return LFGPU_ERR_ARG;  // sanity(): block_enc > block
+  p->ildt = 0;
+  p->idot = 1;
+  p->iquad = 2;
+  p->iw = 3;
+  p->iq = p->iw + p->nwrow;
+  return LFGPU_OK;
+}
+
+// ---- field sampling on the host (RandomEngine::elt / subfield_elt, lib/random/random.h:38-48)
+struct Sampler {
+  int field, k;
+  const GfHostCtx* g;
+  lfgpu_rng_fn rng;
+  void* user;
+  elt_t elt() {
+    if (field == LFGPU_FIELD_GF2_128) {  // GF2_128::sample gf2_128.h:182-190: 16 bytes LE
+      uint8_t b[16];
+      rng(user, b, 16);
+      elt_t e;
+      memcpy(&e.lo, b, 8);
+      memcpy(&e.hi, b + 8, 8);
+      return e;
+    }
+    // FpGeneric::sample fp_generic.h:360-371: 16 bytes, reject >= p, to Montgomery
+    for (;;) {
+      uint8_t b[16];
+      rng(user, b, 16);
+      elt_t e;
+      memcpy(&e.lo, b, 8);
+      memcpy(&e.hi, b + 8, 8);
+      if (e.hi < FP_P_HI || (e.hi == FP_P_HI && e.lo < FP_P_LO)) {
+        // to_montgomery = mul by R^2 (fp_generic.h:278-282)
+        static elt_t rsq{0, 0};
+        static bool init = false;
+        if (!init) {
+          elt_t r{1, 0};
+          for (int i = 0; i < 256; ++i) r = fp_add(r, r);
+          rsq = r;
+          init = true;
+        }
+        return fp_mul(e, rsq);
+      }
+    }
+  }
+  elt_t subfield_elt() {
+    if (field != LFGPU_FIELD_GF2_128) return elt();  // FpGeneric::sample_subfield = sample
+    // GF2_128::sample_subfield gf2_128.h:192-214: kSubFieldBytes LE -> of_scalar
+    uint8_t b[8] = {0};
+    size_t nb = g->sub_bits / 8;
+    rng(user, b, nb);
+    u64 u = 0;
+    for (size_t i = nb; i-- > 0;) u = (u << 8) | b[i];
+    elt_t t{0, 0};
+    for (unsigned bit = 0; bit < g->sub_bits; ++bit, u >>= 1)
+      if (u & 1) t = gf_add(t, g->beta[bit]);
+    return t;
+  }
+};
+
+static inline elt_t h_add(int field, elt_t a, elt_t b) { return field == LFGPU_FIELD_GF2_128 ? gf_add(a, b) : fp_add(a, b); }
+static inline elt_t h_sub(int field, elt_t a, elt_t b) { return field == LFGPU_FIELD_GF2_128 ? gf_add(a, b) : fp_sub(a, b); }
+static inline elt_t h_mul(int field, elt_t a, elt_t b) { return field == LFGPU_FIELD_GF2_128 ? gf_mul(a, b) : fp_mul(a, b); }
+
+static int rs_rows(lfgpu_ctx* c, int field, int k, size_t nrow, size_t n, size_t m, elt_t* d, size_t ld) {
+  if (nrow == 0) return LFGPU_OK;
+  if (field == LFGPU_FIELD_GF2_128) return lfgpu_gf2128_rs_encode_rows(c, k, nrow, n, m, d, ld);
+  // Fp128: the 2^32-order root of lib/algebra/fp_p128.h:48-56
+  static const char* kOmega = "164956748514267535023998284330560247862";
+  unsigned __int128 v = 0;
+  for (const char* s = kOmega; *s; ++s) v = v * 10 + (unsigned)(*s - '0');
+  elt_t raw{(u64)v, (u64)(v >> 64)};
+  elt_t rsq{1, 0};
+  for (int i = 0; i < 256; ++i) rsq = fp_add(rsq, rsq);
+  elt_t w = fp_mul(raw, rsq);
+  uint64_t om[2] = {w.lo, w.hi};
+  return lfgpu_fp128_rs_encode_rows(c, nrow, n, m, om, (uint64_t)1 << 32, d, ld);
+}
+
+extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_ligero_param* pp, const void* h_W,
+                                   size_t subfield_boundary, const size_t* h_lqc, lfgpu_rng_fn rng, void* user,
+                                   uint8_t root_out[32], lfgpu_ligero_prover** out) {
+  if (!c || !pp || !rng || !root_out || !out || (pp->nw && !h_W) || (pp->nq && !h_lqc))
+    return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit: null argument");
+  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128) return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit: field");
+  const GfHostCtx* g = nullptr;
+  if (field == LFGPU_FIELD_GF2_128) {
+    g = lf_gf_ctx(c, k);
+    if (!g) return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit: subfield_log_bits must be 4 or 5");
+  }
+  const lfgpu_ligero_param& p = *pp;
+  const elt_t* W = (const elt_t*)h_W;
+  const size_t ld = p.block_enc;
+  LF_HIP(c, hipSetDevice(c->device));
+  Sampler S{field, k, g, rng, user};
+  const elt_t zero{0, 0};
+
+  // host image of the un-encoded rows: only the first dblock columns are ever non-trivial
+  const size_t hw = p.dblock;
+  std::vector<elt_t> H(p.nrow * hw, zero);
+  auto at = [&](size_t i, size_t j) -> elt_t& { return H[i * hw + j]; };
+  // layout_blinding_rows (ligero_prover.h:171-205)
+  for (size_t j = 0; j < p.block; ++j) at(p.ildt, j) = S.elt();
+  for (size_t j = 0; j < p.dblock; ++j) at(p.idot, j) = S.elt();
+  {
+    elt_t sum = zero;
+    for (size_t j = 0; j < p.w; ++j) sum = h_add(field, sum, at(p.idot, p.r + j));
+    at(p.idot, p.r) = h_sub(field, at(p.idot, p.r), sum);
+  }
+  for (size_t j = 0; j < p.dblock; ++j) at(p.iquad, j) = S.elt();
+  for (size_t j = 0; j < p.w; ++j) at(p.iquad, p.r + j) = zero;
+  // layout_witness_rows (:207-231)
+  for (size_t i = 0; i < p.nwrow; ++i) {
+    bool subfield_only = ((i + 1) * p.w <= subfield_boundary);
+    for (size_t j = 0; j < p.r; ++j) at(i + p.iw, j) = subfield_only ? S.subfield_elt() : S.elt();
+    size_t max_col = std::min(p.w, p.nw - i * p.w);
+    for (size_t j = 0; j < max_col; ++j) at(i + p.iw, p.r + j) = W[i * p.w + j];
+  }
+  // layout_quadratic_rows (:233-270)
+  const size_t iqx = p.iq, iqy = iqx + p.nqtriples, iqz = iqy + p.nqtriples;
+  for (size_t i = 0; i < p.nqtriples; ++i) {
+    for (size_t j = 0; j < p.r; ++j) at(iqx + i, j) = S.elt();
+    for (size_t j = 0; j < p.r; ++j) at(iqy + i, j) = S.elt();
+    for (size_t j = 0; j < p.r; ++j) at(iqz + i, j) = S.elt();
+    for (size_t j = 0; j < p.w && j + i * p.w < p.nq; ++j) {
+      const size_t* l = &h_lqc[3 * (j + i * p.w)];
+      if (l[0] >= p.nw || l[1] >= p.nw || l[2] >= p.nw) return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit: lqc index >= nw");
+      elt_t prod = h_mul(field, W[l[0]], W[l[1]]);
+      if (!(prod.lo == W[l[2]].lo && prod.hi == W[l[2]].hi))
+        return lf_fail(c, LFGPU_ERR_ASSERT, "ligero_commit: invalid quadratic constraints (ligero_prover.h:259-260)");
+      at(iqx + i, j + p.r) = W[l[0]];
+      at(iqy + i, j + p.r) = W[l[1]];
+      at(iqz + i, j + p.r) = W[l[2]];
+    }
+  }
+  // MerkleCommitment::commit draws one 32-byte nonce per leaf, after the layout (merkle_commitment.h:52-54)
+  lfgpu_ligero_prover* pr = new lfgpu_ligero_prover();
+  pr->c = c;
+  pr->field = field;
+  pr->k = k;
+  pr->p = p;
+  pr->d_T = nullptr;
+  pr->d_layers = nullptr;
+  pr->nonces.resize(p.block_ext * 32);
+  for (size_t j = 0; j < p.block_ext; ++j) rng(user, &pr->nonces[32 * j], 32);
+
+  auto fail = [&](int rc) {
+    lfgpu_ligero_free(pr);
+    return rc;
+  };
+  if (hipMalloc((void**)&pr->d_T, p.nrow * ld * 16) != hipSuccess) return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit: tableau alloc"));
+  if (hipMalloc((void**)&pr->d_layers, 2 * p.block_ext * 32) != hipSuccess) return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit: layers alloc"));
+  void* d_non = nullptr;
+  int rc = lf_scratch3(c, p.block_ext * 32, &d_non);
+  if (rc) return fail(rc);
+  if (hipMemcpy2DAsync(pr->d_T, ld * 16, H.data(), hw * 16, hw * 16, p.nrow, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemcpyAsync(d_non, pr->nonces.data(), p.block_ext * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit: upload failed"));
+  // rows 0 (ILDT) and all witness/quadratic rows: block -> block_enc; rows 1,2: dblock -> block_enc
+  if ((rc = rs_rows(c, field, k, 1, p.block, p.block_enc, pr->d_T + p.ildt * ld, ld))) return fail(rc);
+  if ((rc = rs_rows(c, field, k, 2, p.dblock, p.block_enc, pr->d_T + p.idot * ld, ld))) return fail(rc);
+  if ((rc = rs_rows(c, field, k, p.nwqrow, p.block, p.block_enc, pr->d_T + p.iw * ld, ld))) return fail(rc);
+  if ((rc = lfgpu_column_commit(c, field, p.nrow, ld, p.dblock, p.block_ext, pr->d_T, d_non, pr->d_layers, root_out)))
+    return fail(rc);
+  *out = pr;
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_ligero_free(lfgpu_ligero_prover* pr) {
+  if (!pr) return LFGPU_ERR_ARG;
+  if (pr->d_T) (void)hipFree(pr->d_T);
+  if (pr->d_layers) (void)hipFree(pr->d_layers);
+  delete pr;
+  return LFGPU_OK;
+}
+extern "C" int lfgpu_ligero_tableau(lfgpu_ligero_prover* pr, void** d_T) {
+  if (!pr || !d_T) return LFGPU_ERR_ARG;
+  *d_T = pr->d_T;
+  return LFGPU_OK;
+}
+
+// y[j] = T0[j] + sum_i A[i][j] * T[i][j]        (dot_proof accumulation, Blas::vaxpy blas.h:71-78)
+template <int F>
+__global__ void rows_vaxpy_kernel(u32 nrows, size_t n, const elt_t* __restrict__ T0, const elt_t* __restrict__ A,
+                                  size_t lda, const elt_t* __restrict__ T, size_t ld, elt_t* __restrict__ y) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  elt_t acc = ld16(&T0[j]);
+  for (u32 i = 0; i < nrows; ++i)
+    acc = Fld<F>::add(acc, Fld<F>::mul(ld16(&T[(size_t)i * ld + j]), ld16(&A[(size_t)i * lda + j])));
+  st16(&y[j], acc);
+}
+// y[j] = Tq[j] + sum_i u[i] * (z_i[j] - x_i[j]*y_i[j])   (quadratic_proof :311-333)
+template <int F>
+__global__ void quad_combo_kernel(u32 nt, size_t n, const elt_t* __restrict__ Tq, const elt_t* __restrict__ u,
+                                  const elt_t* __restrict__ X, const elt_t* __restrict__ Y, const elt_t* __restrict__ Z,
+                                  size_t ld, elt_t* __restrict__ y) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  elt_t acc = ld16(&Tq[j]);
+  for (u32 i = 0; i < nt; ++i) {
+    elt_t t = Fld<F>::sub(ld16(&Z[(size_t)i * ld + j]), Fld<F>::mul(ld16(&X[(size_t)i * ld + j]), ld16(&Y[(size_t)i * ld + j])));
+    acc = Fld<F>::add(acc, Fld<F>::mul(ld16(&u[i]), t));
+  }
+  st16(&y[j], acc);
+}
+// Aext[i] = [0^r | A[i*w .. (i+1)*w) | 0...]   (layout_Aext ligero_param.h:423-430)
+__global__ void layout_aext_kernel(u32 r, u32 w, size_t lda, const elt_t* __restrict__ A, elt_t* __restrict__ Aext) {
+  u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 i = blockIdx.y;
+  if (j >= r + w) return;
+  st16(&Aext[(size_t)i * lda + j], j < r ? elt_zero() : ld16(&A[(size_t)i * w + (j - r)]));
+}
+
+#define LIG_DISPATCH(field, KERNEL, grid, block, ...)                                  \
+  do {                                                                                 \
+    if ((field) == LFGPU_FIELD_GF2_128)                                                \
+      hipLaunchKernelGGL(KERNEL<FIELD_GF2_128>, grid, block, 0, c->stream, __VA_ARGS__); \
+    else                                                                               \
+      hipLaunchKernelGGL(KERNEL<FIELD_FP128>, grid, block, 0, c->stream, __VA_ARGS__);   \
+  } while (0)
+
+extern "C" int lfgpu_ligero_low_degree_proof(lfgpu_ligero_prover* pr, const void* h_u, void* h_y) {
+  if (!pr || !h_u || !h_y) return LFGPU_ERR_ARG;
+  lfgpu_ctx* c = pr->c;
+  const lfgpu_ligero_param& p = pr->p;
+  LF_HIP(c, hipSetDevice(c->device));
+  void* dy = nullptr;
+  LF_TRY(lf_scratch3(c, p.block * 16, &dy));
+  LF_HIP(c, hipMemcpyAsync(dy, pr->d_T + p.ildt * p.block_enc, p.block * 16, hipMemcpyDeviceToDevice, c->stream));
+  LF_TRY(lfgpu_rows_axpy(c, pr->field, p.nwqrow, p.block, dy, (const uint64_t*)h_u, pr->d_T + p.iw * p.block_enc, p.block_enc));
+  return lfgpu_memcpy_d2h(c, h_y, dy, p.block * 16);
+}
+
+extern "C" int lfgpu_ligero_dot_proof(lfgpu_ligero_prover* pr, const void* h_A, void* h_y) {
+  if (!pr || !h_A || !h_y) return LFGPU_ERR_ARG;
+  lfgpu_ctx* c = pr->c;
+  const lfgpu_ligero_param& p = pr->p;
+  LF_HIP(c, hipSetDevice(c->device));
+  const size_t lda = p.dblock;
+  void* sc = nullptr;
+  LF_TRY(lf_scratch3(c, (p.nwqrow * p.w + p.nwqrow * lda + p.dblock) * 16 + 64, &sc));
+  elt_t* dA = (elt_t*)sc;
+  elt_t* dAext = dA + p.nwqrow * p.w;
+  elt_t* dy = dAext + p.nwqrow * lda;
+  LF_HIP(c, hipMemcpyAsync(dA, h_A, p.nwqrow * p.w * 16, hipMemcpyHostToDevice, c->stream));
+  LF_HIP(c, hipMemsetAsync(dAext, 0, p.nwqrow * lda * 16, c->stream));
+  hipLaunchKernelGGL(layout_aext_kernel, dim3((u32)((p.block + 255) / 256), (u32)p.nwqrow), dim3(256), 0, c->stream,
+                     (u32)p.r, (u32)p.w, lda, (const elt_t*)dA, dAext);
+  LF_TRY(rs_rows(c, pr->field, pr->k, p.nwqrow, p.block, p.dblock, dAext, lda));
+  LIG_DISPATCH(pr->field, rows_vaxpy_kernel, dim3((u32)((p.dblock + 255) / 256)), dim3(256), (u32)p.nwqrow, p.dblock,
+               (const elt_t*)(pr->d_T + p.idot * p.block_enc), (const elt_t*)dAext, lda,
+               (const elt_t*)(pr->d_T + p.iw * p.block_enc), p.block_enc, dy);
+  LF_HIP(c, hipGetLastError());
+  return lfgpu_memcpy_d2h(c, h_y, dy, p.dblock * 16);
+}
+
+extern "C" int lfgpu_ligero_quadratic_proof(lfgpu_ligero_prover* pr, const void* h_u_quad, void* h_y0, void* h_y2) {
+  if (!pr || !h_y0 || !h_y2 || (pr->p.nqtriples && !h_u_quad)) return LFGPU_ERR_ARG;
+  lfgpu_ctx* c = pr->c;
+  const lfgpu_ligero_param& p = pr->p;
+  LF_HIP(c, hipSetDevice(c->device));
+  void* sc = nullptr;
+  LF_TRY(lf_scratch3(c, (p.nqtriples + p.dblock) * 16 + 64, &sc));
+  elt_t* du = (elt_t*)sc;
+  elt_t* dy = du + p.nqtriples + 1;
+  if (p.nqtriples) LF_HIP(c, hipMemcpyAsync(du, h_u_quad, p.nqtriples * 16, hipMemcpyHostToDevice, c->stream));
+  const size_t ld = p.block_enc;
+  const elt_t* X = pr->d_T + p.iq * ld;
+  const elt_t* Y = X + p.nqtriples * ld;
+  const elt_t* Z = Y + p.nqtriples * ld;
+  LIG_DISPATCH(pr->field, quad_combo_kernel, dim3((u32)((p.dblock + 255) / 256)), dim3(256), (u32)p.nqtriples, p.dblock,
+               (const elt_t*)(pr->d_T + p.iquad * ld), (const elt_t*)du, X, Y, Z, ld, dy);
+  LF_HIP(c, hipGetLastError());
+  std::vector<elt_t> y(p.dblock);
+  LF_TRY(lfgpu_memcpy_d2h(c, y.data(), dy, p.dblock * 16));
+  for (size_t j = 0; j < p.w; ++j)  // sanity check of the reference (:335-337)
+    if (y[p.r + j].lo | y[p.r + j].hi) return lf_fail(c, LFGPU_ERR_ASSERT, "quadratic_proof: W part is nonzero");
+  memcpy(h_y0, y.data(), p.r * 16);
+  memcpy(h_y2, y.data() + p.block, (p.dblock - p.block) * 16);
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_ligero_open(lfgpu_ligero_prover* pr, const size_t* idx, void* h_req, uint8_t* h_nonces,
+                                 uint8_t* h_path, size_t path_cap, size_t* npath) {
+  if (!pr || !idx || !h_req || !h_nonces || !npath) return LFGPU_ERR_ARG;
+  lfgpu_ctx* c = pr->c;
+  const lfgpu_ligero_param& p = pr->p;
+  for (size_t i = 0; i < p.nreq; ++i)
+    if (idx[i] >= p.block_ext) return lf_fail(c, LFGPU_ERR_ARG, "ligero_open: index out of range");
+  void* dreq = nullptr;
+  LF_TRY(lf_scratch3(c, p.nrow * p.nreq * 16, &dreq));
+  LF_TRY(lfgpu_gather_columns(c, p.nrow, p.block_enc, p.dblock, pr->d_T, idx, p.nreq, dreq));
+  LF_TRY(lfgpu_memcpy_d2h(c, h_req, dreq, p.nrow * p.nreq * 16));
+  for (size_t i = 0; i < p.nreq; ++i) memcpy(h_nonces + 32 * i, &pr->nonces[32 * idx[i]], 32);
+  return lfgpu_merkle_open(c, p.block_ext, pr->d_layers, idx, p.nreq, h_path, path_cap, npath);
+}

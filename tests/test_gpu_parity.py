@@ -323,3 +323,98 @@ def test_gpu_reference_merkle_fixtures(G):
     d = G.to_dev(dev)
     assert G.gpu().merkle_build_tree(n, d.data_ptr()) == root
     assert G.gpu().merkle_open(n, d.data_ptr(), idx) == proof
+
+
+# ---------------------------------------------------------------- Ligero commit / prove pieces
+def test_ligero_commit_reference_fixture(G):
+    """LigeroProver::commit through the GPU path reproduces the C++ commitment root of
+    rust/runtime/ligero/tests/ligero_test_vector.bin: pins RNG draw order, row layout,
+    LCH14 RS encode (K3), column hashing (K5) and the Merkle tree (K6) end to end."""
+    import ligero_fixture as lf
+    v = lf.load()
+    pkg = G.pkg
+    p = pkg.ligero_param(pkg.FIELD_GF2_128, v["nw"], v["nq"], 4, v["nreq"], 4096)
+    assert (p.block, p.dblock, p.nrow, p.r, p.w, p.block_ext) == (682, 1363, 8, 36, 646, 2733)
+    rng = lf.LcgRng(100)
+    pr = pkg.LigeroProver(G.gpu(), pkg.FIELD_GF2_128, p)
+    root = pr.commit(v["W"], v["subfield_boundary"], v["lqc"], rng.bytes)
+    assert root == v["root"]
+    pr.close()
+
+
+@pytest.mark.parametrize("field", [GF, FP])
+def test_ligero_prove_pieces_vs_oracle(G, field):
+    """low_degree_proof / dot_proof / quadratic_proof / compute_req+open against the oracle's
+    Blas restatement on the tableau the GPU committed (challenges are random test inputs)."""
+    pkg = G.pkg
+    o = ol.oracle()
+    rng = np.random.default_rng(77 + field)
+    nw, nq, nreq, be = 700, 40, 12, 512
+    p = pkg.ligero_param(field, nw, nq, 4, nreq, be)
+    W = ol.rand_elts(rng, nw, field)
+    lqc = []
+    zs = rng.choice(np.arange(nw // 2, nw), size=nq, replace=False)
+    for i in range(nq):  # W[z] = W[x] * W[y], x, y in the first half, z distinct in the second half
+        x, y, z = int(rng.integers(0, nw // 2)), int(rng.integers(0, nw // 2)), int(zs[i])
+        W[z] = arr(o.lfo_mul(field, elt(W[x]), elt(W[y])))
+        lqc.append((x, y, z))
+    seed_rng = np.random.default_rng(5)
+    pr = pkg.LigeroProver(G.gpu(), field, p)
+    root = pr.commit(W, 0, lqc, lambda n: bytes(seed_rng.integers(0, 256, size=n, dtype=np.uint8)))
+    T = G.from_dev(_wrap(G, pr.tableau_ptr(), p.nrow * p.block_enc * 16), np.uint64, (p.nrow, p.block_enc, 2)).copy()
+    # every row is a codeword: re-encode the first n columns with the oracle
+    for i in range(p.nrow):
+        n = p.dblock if i in (p.idot, p.iquad) else p.block
+        row = T[i].copy()
+        row[n:] = 0
+        if field == GF:
+            o.lfo_lch14_rs_interpolate(C.byref(ol.gf_ctx(4)), n, p.block_enc, P(row))
+        else:
+            o.lfo_fp_rs_interpolate(n, p.block_enc, P(row))
+        assert (row == T[i]).all(), i
+    # low degree
+    u = ol.rand_elts(rng, p.nwqrow, field)
+    want = T[p.ildt, :p.block].copy()
+    for i in range(p.nwqrow):
+        o.lfo_axpy(field, p.block, P(want), elt(u[i]), P(np.ascontiguousarray(T[p.iw + i, :p.block])))
+    assert (pr.low_degree_proof(u) == want).all()
+    # dot
+    A = ol.rand_elts(rng, p.nwqrow * p.w, field)
+    want = T[p.idot, :p.dblock].copy()
+    for i in range(p.nwqrow):
+        ext = np.zeros((p.dblock, 2), dtype=np.uint64)
+        ext[p.r:p.r + p.w] = A[i * p.w:(i + 1) * p.w]
+        if field == GF:
+            o.lfo_lch14_rs_interpolate(C.byref(ol.gf_ctx(4)), p.block, p.dblock, P(ext))
+        else:
+            o.lfo_fp_rs_interpolate(p.block, p.dblock, P(ext))
+        o.lfo_vaxpy(field, p.dblock, P(want), P(ext), P(np.ascontiguousarray(T[p.iw + i, :p.dblock])))
+    assert (pr.dot_proof(A) == want).all()
+    # quadratic
+    uq = ol.rand_elts(rng, p.nqtriples, field)
+    y = T[p.iquad, :p.dblock].copy()
+    iqx, iqy, iqz = p.iq, p.iq + p.nqtriples, p.iq + 2 * p.nqtriples
+    for i in range(p.nqtriples):
+        for j in range(p.dblock):
+            t = o.lfo_sub(field, elt(T[iqz + i, j]), o.lfo_mul(field, elt(T[iqx + i, j]), elt(T[iqy + i, j])))
+            y[j] = arr(o.lfo_add(field, elt(y[j]), o.lfo_mul(field, elt(uq[i]), t)))
+    y0, y2 = pr.quadratic_proof(uq)
+    assert (y[p.r:p.r + p.w] == 0).all()
+    assert (y0 == y[:p.r]).all() and (y2 == y[p.block:p.dblock]).all()
+    # open
+    idx = [int(t) for t in rng.choice(p.block_ext, size=p.nreq, replace=False)]
+    req, nonces, path = pr.open(idx)
+    assert (req == T[:, [p.dblock + i for i in idx], :]).all()
+    pr.close()
+
+
+def _wrap(G, ptr, nbytes):
+    """copy `nbytes` of device memory at raw pointer `ptr` into a torch byte tensor"""
+    import torch
+    t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    import ctypes
+    G.gpu()._ck(G.gpu().L.lfgpu_memcpy_d2h(G.gpu().h, 0, 0, 0))  # sync the lfgpu stream
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(t.data_ptr(), ptr, nbytes, 3) == 0  # hipMemcpyDeviceToDevice
+    return t
