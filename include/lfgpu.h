@@ -123,6 +123,11 @@ int lfgpu_dense_bind(lfgpu_ctx* ctx, int field, size_t n0, const uint64_t r[2], 
 int lfgpu_hquad_bind_h(lfgpu_ctx* ctx, int field, size_t n, const void* d_hc, const void* d_vc,
                        const uint64_t r[2], int hand, void* d_hc_out, void* d_vc_out, size_t* n_out);
 
+/* ---- element-wise field ops (Field::addf / subf / mulf, lib/gf2k/gf2_128.h:227-237,
+ * lib/algebra/fp_generic.h:203-214): out[i] = a[i] op b[i], op 0 add, 1 sub, 2 mul.  Used by the
+ * parity tests to pin the device arithmetic directly. */
+int lfgpu_field_binop(lfgpu_ctx* ctx, int field, int op, size_t n, const void* d_a, const void* d_b, void* d_out);
+
 /* ---- K12: Ligero row combinations -----------------------------------------
  * y[j] += sum_i u[i] * T[i][j], j < n  (low_degree_proof, lib/ligero/ligero_prover.h:281-291;
  * Blas::axpy lib/algebra/blas.h:62-68).  h_u: nrows host elements. */

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "lfgpu_free", "lfgpu_memcpy_h2d", "lfgpu_memcpy_d2h", "lfgpu_fp128_fft", "lfgpu_gf2128_lch14_fft",
     "lfgpu_gf2128_rs_encode_rows", "lfgpu_fp128_rs_encode_rows", "lfgpu_column_commit", "lfgpu_merkle_build_tree",
     "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
-    "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_fp128_fft_host", "lfgpu_gf2128_lch14_fft_host",
+    "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_field_binop", "lfgpu_fp128_fft_host", "lfgpu_gf2128_lch14_fft_host",
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
     "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
     "lfgpu_ligero_quadratic_proof", "lfgpu_ligero_open", "lfgpu_ligero_tableau", "lfgpu_ligero_free",
@@ -76,6 +76,7 @@ def load_library():
         "lfgpu_dense_bind": [vp, ci, sz, pu64, vp, vp],
         "lfgpu_hquad_bind_h": [vp, ci, sz, vp, vp, pu64, ci, vp, vp, C.POINTER(sz)],
         "lfgpu_rows_axpy": [vp, ci, sz, sz, vp, vp, vp, sz],
+        "lfgpu_field_binop": [vp, ci, ci, sz, vp, vp, vp],
         "lfgpu_gather_columns": [vp, sz, sz, sz, vp, vp, sz, vp],
         "lfgpu_fp128_fft_host": [vp, ci, sz, pu64, u64, vp],
         "lfgpu_gf2128_lch14_fft_host": [vp, ci, ci, C.c_uint, u64, vp],
@@ -212,6 +213,10 @@ class LfGpu:
         self._ck(self.L.lfgpu_hquad_bind_h(self.h, field, n, C.c_void_p(d_hc), C.c_void_p(d_vc), _u64x2(r), hand,
                                            C.c_void_p(d_hc_out), C.c_void_p(d_vc_out), C.byref(n_out)))
         return n_out.value
+
+    def field_binop(self, field, op, n, d_a, d_b, d_out):
+        """element-wise Field::addf/subf/mulf (op 0/1/2)"""
+        self._ck(self.L.lfgpu_field_binop(self.h, field, op, n, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out)))
 
     # --- K12 row combinations (reference lib/ligero/ligero_prover.h:281-291,346-351)
     def rows_axpy(self, field, nrows, n, d_y, u_host, d_T, ld):

@@ -46,7 +46,7 @@ LF_HD void st16(elt_t* p, elt_t e) {
 #define FP_P_LO 0x0000000000000001ull
 #define FP_P_HI 0xFFFFF00000000000ull
 
-LF_HD elt_t fp_add(elt_t a, elt_t b) {
+LF_HD elt_t fp_add_c(elt_t a, elt_t b) {
   u64 lo = a.lo + b.lo;
   u64 c = lo < a.lo;
   u64 hi = a.hi + b.hi;
@@ -61,7 +61,7 @@ LF_HD elt_t fp_add(elt_t a, elt_t b) {
   return ge ? elt_t{slo, shi} : elt_t{lo, hi};
 }
 
-LF_HD elt_t fp_sub(elt_t a, elt_t b) {
+LF_HD elt_t fp_sub_c(elt_t a, elt_t b) {
   u64 lo = a.lo - b.lo;
   u64 bw = a.lo < b.lo;
   u64 hi = a.hi - b.hi - bw;
@@ -88,7 +88,7 @@ LF_HD void mul64(u64 a, u64 b, u64& lo, u64& hi) {
 // Montgomery product a*b/2^128 mod p.  -p^-1 mod 2^64 = 2^64 - 1 (p = 1 mod 2^64),
 // and m*p = m*2^128 - m*2^108 + m needs shifts only (the reference's
 // Fp128Reduce::reduction_step, fp_p128.h:68-75).
-LF_HD elt_t fp_mul(elt_t a, elt_t b) {
+LF_HD elt_t fp_mul_c(elt_t a, elt_t b) {
   u64 t0, t1, t2, t3, t4 = 0;
   u64 l, h, c;
   // schoolbook
@@ -149,6 +149,215 @@ LF_HD elt_t fp_mul(elt_t a, elt_t b) {
   bool ge = (t4 != 0) || (hi > FP_P_HI) || (hi == FP_P_HI && lo >= FP_P_LO);
   return ge ? elt_t{slo, shi} : elt_t{lo, hi};
 }
+
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 versions: explicit 32-bit limb carry chains (v_add_co/v_addc_co through VCC) and
+// v_mad_u64_u32 with its carry-out.  hipcc's own lowering of the portable code above recomputes
+// every carry with 64-bit compares (183 VALU instructions per product); these are ~100.
+// Each asm statement keeps VCC live only inside itself.  gfx950 needs 2 wait states between a VALU
+// that writes VCC and a VALU that reads it (hipcc emits `s_nop 1` in compiled code but never inside an
+// asm statement), so every carry link carries its own `s_nop 1`; other waves issue in those slots.
+#define FP_W(e, w0, w1, w2, w3) \
+  u32 w0 = (u32)(e).lo, w1 = (u32)((e).lo >> 32), w2 = (u32)(e).hi, w3 = (u32)((e).hi >> 32)
+#define FP_PACK(w0, w1, w2, w3) elt_t{((u64)(w1) << 32) | (w0), ((u64)(w3) << 32) | (w2)}
+
+__device__ __forceinline__ elt_t fp_add(elt_t a, elt_t b) {
+  FP_W(a, a0, a1, a2, a3);
+  FP_W(b, b0, b1, b2, b3);
+  u32 s0, s1, s2, s3, c, d0, d1, d2, d3;
+  asm("v_add_co_u32 %0, vcc, %9, %13\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %1, vcc, %10, %14, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %2, vcc, %11, %15, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %3, vcc, %12, %16, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %4, vcc, 0, 0, vcc\n\t"
+      // (c:s) - p, p = {1, 0, 0, 0xfffff000}; final borrow set <=> s < p
+      "v_subrev_co_u32 %5, vcc, 1, %0\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %6, vcc, 0, %1, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %7, vcc, 0, %2, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %8, vcc, %3, %17, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %4, vcc, 0, %4, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32 %0, %5, %0, vcc\n\t"
+      "v_cndmask_b32 %1, %6, %1, vcc\n\t"
+      "v_cndmask_b32 %2, %7, %2, vcc\n\t"
+      "v_cndmask_b32 %3, %8, %3, vcc"
+      : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(c), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(0xfffff000u)
+      : "vcc");
+  return FP_PACK(s0, s1, s2, s3);
+}
+
+__device__ __forceinline__ elt_t fp_sub(elt_t a, elt_t b) {
+  FP_W(a, a0, a1, a2, a3);
+  FP_W(b, b0, b1, b2, b3);
+  u32 d0, d1, d2, d3, e0, e3;
+  asm("v_sub_co_u32 %0, vcc, %6, %10\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %1, vcc, %7, %11, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %2, vcc, %8, %12, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %3, vcc, %9, %13, vcc\n\t"
+      // borrow => add p back
+      "s_nop 1\n\t"
+      "v_cndmask_b32 %4, 0, 1, vcc\n\t"
+      "v_cndmask_b32 %5, 0, %14, vcc\n\t"
+      "v_add_co_u32 %0, vcc, %0, %4\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %3, vcc, %5, %3, vcc"
+      : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(e0), "=&v"(e3)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(0xfffff000u)
+      : "vcc");
+  return FP_PACK(d0, d1, d2, d3);
+}
+
+// acc(64) += x*y, carry-out accumulated into ov
+#define FP_MADC(acc, ov, x, y) \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(ov) : "v"(x), "v"(y) : "vcc")
+#define FP_MAD(acc, x, y) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc")
+#define FP_COL(tk, acc, ov)                 \
+  tk = (u32)(acc);                          \
+  acc = ((acc) >> 32) | ((u64)(ov) << 32);  \
+  ov = 0
+
+__device__ __forceinline__ elt_t fp_mul(elt_t a, elt_t b) {
+  FP_W(a, a0, a1, a2, a3);
+  FP_W(b, b0, b1, b2, b3);
+  u32 t0, t1, t2, t3, t4, t5, t6, t7, t8, ov = 0;
+  u64 acc = 0;
+  // product scanning, 16 x v_mad_u64_u32
+  FP_MAD(acc, a0, b0);
+  FP_COL(t0, acc, ov);
+  FP_MAD(acc, a0, b1);
+  FP_MADC(acc, ov, a1, b0);
+  FP_COL(t1, acc, ov);
+  FP_MADC(acc, ov, a0, b2);
+  FP_MADC(acc, ov, a1, b1);
+  FP_MADC(acc, ov, a2, b0);
+  FP_COL(t2, acc, ov);
+  FP_MADC(acc, ov, a0, b3);
+  FP_MADC(acc, ov, a1, b2);
+  FP_MADC(acc, ov, a2, b1);
+  FP_MADC(acc, ov, a3, b0);
+  FP_COL(t3, acc, ov);
+  FP_MADC(acc, ov, a1, b3);
+  FP_MADC(acc, ov, a2, b2);
+  FP_MADC(acc, ov, a3, b1);
+  FP_COL(t4, acc, ov);
+  FP_MADC(acc, ov, a2, b3);
+  FP_MADC(acc, ov, a3, b2);
+  FP_COL(t5, acc, ov);
+  FP_MAD(acc, a3, b3);
+  t6 = (u32)acc;
+  t7 = (u32)(acc >> 32);
+  // REDC, two 64-bit steps: m = -(t[k+1]:t[k]);  t += m*2^(32k) * (2^128 - 2^108 + 1)
+  u32 m0, m1, s3, s4, s5;
+  asm("v_sub_co_u32 %0, vcc, 0, %9\n\t"          // m = 0 - (t1:t0); borrow-out = (t != 0) = carry into limb 2
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %1, vcc, 0, %10, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %4, vcc, %0, %4, vcc\n\t"   // + m * 2^128
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %5, vcc, %1, %5, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %6, vcc, 0, %6, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %7, vcc, 0, %7, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %8, vcc, 0, 0, vcc"
+      : "=&v"(m0), "=&v"(m1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7), "=&v"(t8)
+      : "v"(t0), "v"(t1)
+      : "vcc");
+  s3 = m0 << 12;
+  s4 = __builtin_amdgcn_alignbit(m1, m0, 20);
+  s5 = m1 >> 20;
+  asm("v_sub_co_u32 %0, vcc, %0, %6\n\t"           // - m * 2^108
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %1, vcc, %1, %7, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %2, vcc, %2, %8, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %4, vcc, 0, %4, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %5, vcc, 0, %5, vcc"
+      : "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7), "+v"(t8)
+      : "v"(s3), "v"(s4), "v"(s5)
+      : "vcc");
+  asm("v_sub_co_u32 %0, vcc, 0, %7\n\t"           // m = 0 - (t3:t2)
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %1, vcc, 0, %8, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %4, vcc, %0, %4, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %5, vcc, %1, %5, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %6, vcc, 0, %6, vcc"
+      : "=&v"(m0), "=&v"(m1), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7), "+v"(t8)
+      : "v"(t2), "v"(t3)
+      : "vcc");
+  s3 = m0 << 12;
+  s4 = __builtin_amdgcn_alignbit(m1, m0, 20);
+  s5 = m1 >> 20;
+  u32 d0, d1, d2, d3;
+  asm("v_sub_co_u32 %0, vcc, %0, %8\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %1, vcc, %1, %9, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %2, vcc, %2, %10, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      // (t8:t7..t4) - p ; final borrow <=> value < p
+      "v_subrev_co_u32 %4, vcc, 1, %11\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %5, vcc, 0, %0, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %6, vcc, 0, %1, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %7, vcc, %2, %12, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %3, vcc, 0, %3, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32 %4, %4, %11, vcc\n\t"
+      "v_cndmask_b32 %5, %5, %0, vcc\n\t"
+      "v_cndmask_b32 %6, %6, %1, vcc\n\t"
+      "v_cndmask_b32 %7, %7, %2, vcc"
+      : "+v"(t5), "+v"(t6), "+v"(t7), "+v"(t8), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+      : "v"(s3), "v"(s4), "v"(s5), "v"(t4), "v"(0xfffff000u)
+      : "vcc");
+  return FP_PACK(d0, d1, d2, d3);
+}
+// host functions parsed during the device pass resolve to these overloads
+__host__ inline elt_t fp_add(elt_t a, elt_t b) { return fp_add_c(a, b); }
+__host__ inline elt_t fp_sub(elt_t a, elt_t b) { return fp_sub_c(a, b); }
+__host__ inline elt_t fp_mul(elt_t a, elt_t b) { return fp_mul_c(a, b); }
+#else
+LF_HD elt_t fp_add(elt_t a, elt_t b) { return fp_add_c(a, b); }
+LF_HD elt_t fp_sub(elt_t a, elt_t b) { return fp_sub_c(a, b); }
+LF_HD elt_t fp_mul(elt_t a, elt_t b) { return fp_mul_c(a, b); }
+#endif
 
 LF_HD elt_t fp_from_mont(elt_t a) { return fp_mul(a, elt_t{1ull, 0ull}); }
 

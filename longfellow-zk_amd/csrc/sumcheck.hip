@@ -206,6 +206,16 @@ __global__ void gather_columns_kernel(u32 nrow, size_t ld, size_t col0, const el
   st16(&req[t], ld16(&T[(size_t)i * ld + col0 + idx[j]]));
 }
 
+// out[i] = a[i] (op) b[i]: op 0 add, 1 sub, 2 mul   (Field::addf/subf/mulf element-wise)
+template <int F>
+__global__ __launch_bounds__(SC_THREADS) void field_binop_kernel(int op, size_t n, const elt_t* __restrict__ a,
+                                                                 const elt_t* __restrict__ b, elt_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
+  if (i >= n) return;
+  elt_t x = ld16(&a[i]), y = ld16(&b[i]);
+  st16(&out[i], op == 0 ? Fld<F>::add(x, y) : op == 1 ? Fld<F>::sub(x, y) : Fld<F>::mul(x, y));
+}
+
 // ------------------------------------------------------------------ C ABI
 #define DISPATCH_FIELD(field, KERNEL, grid, block, ...)                                              \
   do {                                                                                               \
@@ -330,5 +340,17 @@ extern "C" int lfgpu_gather_columns(lfgpu_ctx* c, size_t nrow, size_t ld, size_t
                      (const elt_t*)d_T, (const u64*)di, (u32)nreq, (elt_t*)d_req);
   LF_HIP(c, hipGetLastError());
   LF_HIP(c, hipStreamSynchronize(c->stream));
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_field_binop(lfgpu_ctx* c, int field, int op, size_t n, const void* d_a, const void* d_b,
+                                 void* d_out) {
+  if (!c || (n && (!d_a || !d_b || !d_out)) || op < 0 || op > 2) return lf_fail(c, LFGPU_ERR_ARG, "field_binop: bad argument");
+  if (n == 0) return LFGPU_OK;
+  LF_HIP(c, hipSetDevice(c->device));
+  u32 nb = (u32)((n + SC_THREADS - 1) / SC_THREADS);
+  DISPATCH_FIELD(field, field_binop_kernel, dim3(nb), dim3(SC_THREADS), op, n, (const elt_t*)d_a, (const elt_t*)d_b,
+                 (elt_t*)d_out);
+  LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
 }

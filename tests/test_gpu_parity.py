@@ -17,6 +17,34 @@ def G():
     return gpu_util
 
 
+# ---------------------------------------------------------------- a1 / a2 field arithmetic
+@pytest.mark.parametrize("field", [GF, FP])
+def test_field_binops(G, field):
+    """device add/sub/mul (hand-written carry chains / Kronecker clmul) incl. edge values"""
+    import torch
+    o = ol.oracle()
+    rng = np.random.default_rng(3 + field)
+    n = 20000
+    x, y = ol.rand_elts(rng, n, field), ol.rand_elts(rng, n, field)
+    pm1 = [0, 0xFFFFF00000000000]
+    edge = [[0, 0], [1, 0], pm1, [0xFFFFFFFFFFFFFFFF, 0xFFFFEFFFFFFFFFFF], [0xFFFFFFFFFFFFFFFF, 0], [0, 1],
+            [0, 0xFFFFF00000000000 - 1], [0xFFFFFFFF, 0], [0x100000000, 0], [0, 0xFFFFEFFF00000000]]
+    if field == GF:
+        edge += [[0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF], [0, 0x8000000000000000]]
+    k = 0
+    for a in edge:
+        for b in edge:
+            x[k], y[k] = a, b
+            k += 1
+    dx, dy = G.to_dev(x), G.to_dev(y)
+    dout = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+    for op, fn in ((0, o.lfo_add), (1, o.lfo_sub), (2, o.lfo_mul)):
+        G.gpu().field_binop(field, op, n, dx.data_ptr(), dy.data_ptr(), dout.data_ptr())
+        got = G.from_dev(dout, np.uint64, (n, 2))
+        for i in list(range(k)) + list(range(k, n, 37)):
+            assert (got[i] == arr(fn(field, elt(x[i]), elt(y[i])))).all(), (op, i)
+
+
 # ---------------------------------------------------------------- K1 Fp128 FFT
 @pytest.mark.parametrize("n,rows", [(2, 1), (4, 3), (64, 5), (1024, 2), (8192, 3), (1 << 14, 2), (1 << 16, 1), (1 << 17, 2)])
 @pytest.mark.parametrize("forward", [False, True])
