@@ -126,6 +126,13 @@ def main():
         dt = float(tt.item())
 
     launches_per_step = 1 if logn <= 13 else 2  # fp_fft_tile passes (fft.hip)
+    # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
+    # with the same command and committed under profiles/ -- counters cannot be read in-process
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_fp_fft_tile.json")
+    if os.path.exists(pmc) and rows == 1024 and logn == 20:
+        with open(pmc) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
     kern_ms = dev_ms / (args.steps * launches_per_step)
     algo_bytes_per_launch = 2.0 * nelem * 16 / launches_per_step
     achieved = algo_bytes_per_launch / (kern_ms * 1e-3) / 1e9
@@ -146,7 +153,7 @@ def main():
         "config": {"workload": "batched FFT 2^%d points x %d rows per GPU, Fp128 fftb, in place in HBM" % (logn, rows),
                    "field": "Fp128 p=2^128-2^108+1", "rows_per_gpu": rows, "n": n, "parallelism": "rows sharded x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "fp_fft_tile", "launches_per_step": launches_per_step, "avg_launch_ms": kern_ms,
                      "note": "integer-ALU-bound (no 64-bit multiplier on CDNA4): see DESIGN.md"},
     }
