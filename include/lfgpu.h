@@ -123,6 +123,27 @@ int lfgpu_dense_bind(lfgpu_ctx* ctx, int field, size_t n0, const uint64_t r[2], 
 int lfgpu_hquad_bind_h(lfgpu_ctx* ctx, int field, size_t n, const void* d_hc, const void* d_vc,
                        const uint64_t r[2], int hand, void* d_hc_out, void* d_vc_out, size_t* n_out);
 
+/* ---- K10 / K11: sumcheck layer (Quad) resident on the device -----------------------
+ * lfgpu_quad_upload: one layer's corners in EXPANDED form, in the order the reference's
+ * Quad iterator yields them (canonical: Morton(h0,h1) then g, lib/sumcheck/equad.h:79-106;
+ * delta decode of lib/sumcheck/quad.h:100-130 done by the caller), vi indexing the shared
+ * constant table kvec (nk elements; a zero constant marks an assert-zero term, quad.h:213-220).
+ * nv = number of output gates of the layer.  Upload once per circuit; reuse per proof. */
+typedef struct lfgpu_quad lfgpu_quad;
+int lfgpu_quad_upload(lfgpu_ctx* ctx, int field, size_t nterms, const uint32_t* g, const uint32_t* h0,
+                      const uint32_t* h1, const uint32_t* vi, size_t nk, const void* h_kvec, size_t nv,
+                      lfgpu_quad** out);
+int lfgpu_quad_free(lfgpu_quad* q);
+/* ProverLayers::eval_quad with nc = 1 (lib/sumcheck/prover_layers.h:278-305):
+ * V[g] = sum kvec[vi] * W[h1] * W[h0]; *ok = 0 if an assert-zero term is non-zero
+ * (the reference returns false / eval_circuit returns nullptr). */
+int lfgpu_eval_quad(lfgpu_quad* q, size_t nw, const void* d_W, void* d_V, int* ok);
+/* Quad::bind_g (lib/sumcheck/quad.h:152-185): HQUAD[(h0,h1)] = sum_g prep_v(v, beta) *
+ * (EQ(G0,g) + alpha EQ(G1,g)); outputs the compact HQuad (d_hc_out: pairs of u32, d_vc_out:
+ * elements; capacity nterms) and its size. */
+int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                      const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out);
+
 /* ---- element-wise field ops (Field::addf / subf / mulf, lib/gf2k/gf2_128.h:227-237,
  * lib/algebra/fp_generic.h:203-214): out[i] = a[i] op b[i], op 0 add, 1 sub, 2 mul.  Used by the
  * parity tests to pin the device arithmetic directly. */

@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
     "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
     "lfgpu_ligero_quadratic_proof", "lfgpu_ligero_open", "lfgpu_ligero_tableau", "lfgpu_ligero_free",
+    "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g",
 ]
 
 
@@ -90,6 +91,10 @@ def load_library():
         "lfgpu_ligero_open": [vp, vp, vp, vp, vp, sz, C.POINTER(sz)],
         "lfgpu_ligero_tableau": [vp, C.POINTER(vp)],
         "lfgpu_ligero_free": [vp],
+        "lfgpu_quad_upload": [vp, ci, sz, vp, vp, vp, vp, sz, vp, sz, C.POINTER(vp)],
+        "lfgpu_quad_free": [vp],
+        "lfgpu_eval_quad": [vp, sz, vp, vp, C.POINTER(ci)],
+        "lfgpu_quad_bind_g": [vp, sz, vp, vp, pu64, pu64, vp, vp, C.POINTER(sz)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -333,4 +338,38 @@ class LigeroProver:
     def close(self):
         if self.h:
             self.gpu.L.lfgpu_ligero_free(self.h)
+            self.h = None
+
+
+class Quad:
+    """One sumcheck layer resident on the device (mirror of Quad<Field>, reference
+    lib/sumcheck/quad.h:55-226): eval (ProverLayers::eval_quad) and bind_g."""
+
+    def __init__(self, gpu, field, g, h0, h1, vi, kvec, nv):
+        import numpy as np
+        self.gpu, self.field, self.n, self.nv = gpu, field, len(g), nv
+        arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in (g, h0, h1, vi)]
+        kvec = np.ascontiguousarray(kvec)
+        h = C.c_void_p()
+        gpu._ck(gpu.L.lfgpu_quad_upload(gpu.h, field, self.n, *[C.c_void_p(a.ctypes.data) for a in arrs], len(kvec),
+                                        C.c_void_p(kvec.ctypes.data), nv, C.byref(h)))
+        self.h = h
+
+    def eval(self, nw, d_W, d_V):
+        ok = C.c_int()
+        self.gpu._ck(self.gpu.L.lfgpu_eval_quad(self.h, nw, C.c_void_p(d_W), C.c_void_p(d_V), C.byref(ok)))
+        return bool(ok.value)
+
+    def bind_g(self, logv, G0, G1, alpha, beta, d_hc_out, d_vc_out):
+        import numpy as np
+        G0, G1 = np.ascontiguousarray(G0), np.ascontiguousarray(G1)
+        n_out = C.c_size_t()
+        self.gpu._ck(self.gpu.L.lfgpu_quad_bind_g(self.h, logv, C.c_void_p(G0.ctypes.data), C.c_void_p(G1.ctypes.data),
+                                                  _u64x2(alpha), _u64x2(beta), C.c_void_p(d_hc_out), C.c_void_p(d_vc_out),
+                                                  C.byref(n_out)))
+        return n_out.value
+
+    def close(self):
+        if self.h:
+            self.gpu.L.lfgpu_quad_free(self.h)
             self.h = None

@@ -1,0 +1,263 @@
+// quad.hip -- K10 (Quad::bind_g) and K11 (ProverLayers::eval_quad) on an uploaded layer.
+//
+// Reference: Quad::bind_g + prep_v (lib/sumcheck/quad.h:152-185,213-220), Eqs::raw_eq2 /
+// fill_recursive (lib/arrays/eqs.h:46-80), ProverLayers::eval_quad
+// (lib/sumcheck/prover_layers.h:278-305), corner order of EQuad::canonicalize
+// (lib/sumcheck/equad.h:79-106).
+//
+// A layer is uploaded ONCE per circuit in expanded form (the delta decode of quad.h:100-130
+// is a host prefix sum done by the caller's adapter) and kept in HBM in two orders:
+//   * canonical order (Morton(h0,h1), then g): equal hand pairs are adjacent, which is what
+//     makes bind_g a run-length reduction (K10);
+//   * grouped by output gate g (CSR): eval_quad becomes a per-gate gather/sum without atomics,
+//     so Fp128 needs no 128-bit atomic and GF2_128 results do not depend on arrival order (K11).
+#include <algorithm>
+#include <numeric>
+
+#include "ctx.h"
+
+#define QD_THREADS 256
+
+struct __attribute__((aligned(16))) corner4 {
+  u32 g, h0, h1, vi;
+};
+
+struct lfgpu_quad {
+  lfgpu_ctx* c;
+  int field;
+  size_t n, nk, nv;
+  corner4* d_morton;  // canonical order
+  corner4* d_bygate;  // sorted by g (stable)
+  u32* d_goff;        // nv + 1 offsets into d_bygate
+  elt_t* d_kvec;      // nk constants
+};
+
+// ---- K11: V[g] = sum_{terms of g} kvec[vi] * W[h1] * W[h0]; assert-zero terms must vanish
+template <int F>
+__global__ __launch_bounds__(QD_THREADS) void eval_quad_kernel(u32 nv, const u32* __restrict__ goff,
+                                                               const corner4* __restrict__ terms,
+                                                               const elt_t* __restrict__ kvec, const elt_t* __restrict__ W,
+                                                               elt_t* __restrict__ V, int* __restrict__ fail) {
+  u32 g = blockIdx.x * QD_THREADS + threadIdx.x;
+  if (g >= nv) return;
+  elt_t acc = elt_zero();
+  bool bad = false;
+  for (u32 t = goff[g]; t < goff[g + 1]; ++t) {
+    corner4 cr = *reinterpret_cast<const corner4*>(&terms[t]);
+    elt_t v = ld16(&kvec[cr.vi]);
+    elt_t p = Fld<F>::mul(ld16(&W[cr.h1]), ld16(&W[cr.h0]));
+    if ((v.lo | v.hi) == 0) {
+      bad |= (p.lo | p.hi) != 0;
+    } else {
+      acc = Fld<F>::add(acc, Fld<F>::mul(v, p));
+    }
+  }
+  st16(&V[g], acc);
+  if (bad) atomicOr(fail, 1);
+}
+
+// ---- K10 step 1: eq[i] = EQ(G0,i) + alpha*EQ(G1,i), EQ(G,i) = prod_l (bit_l(i) ? G[l] : 1 - G[l])
+template <int F>
+__global__ __launch_bounds__(QD_THREADS) void raw_eq2_kernel(u32 logn, u32 n, const elt_t* __restrict__ G /*G0|G1|1-G0|1-G1*/,
+                                                             elt_t alpha, elt_t one, elt_t* __restrict__ eq) {
+  u32 i = blockIdx.x * QD_THREADS + threadIdx.x;
+  if (i >= n) return;
+  elt_t e0 = one, e1 = alpha;
+  for (u32 l = 0; l < logn; ++l) {
+    u32 bit = (i >> l) & 1;
+    e0 = Fld<F>::mul(e0, ld16(&G[(bit ? 0 : 2 * logn) + l]));
+    e1 = Fld<F>::mul(e1, ld16(&G[(bit ? logn : 3 * logn) + l]));
+  }
+  st16(&eq[i], Fld<F>::add(e0, e1));
+}
+
+// ---- K10 step 2: run heads (first term of each distinct hand pair)
+__device__ __forceinline__ bool is_head(const corner4* t, size_t i) {
+  if (i == 0) return true;
+  return t[i].h0 != t[i - 1].h0 || t[i].h1 != t[i - 1].h1;
+}
+__global__ __launch_bounds__(QD_THREADS) void bindg_count_kernel(size_t n, const corner4* __restrict__ t,
+                                                                 u32* __restrict__ block_counts) {
+  __shared__ u32 cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x;
+  bool head = i < n && is_head(t, i);
+  u64 mask = __ballot(head);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&cnt, (u32)__popcll(mask));
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = cnt;
+}
+__global__ __launch_bounds__(1024) void bindg_scan_kernel(u32 nblocks, u32* __restrict__ block_counts, u32* __restrict__ total) {
+  __shared__ u32 sh[1024];
+  __shared__ u32 carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (u32 base = 0; base < nblocks; base += 1024) {
+    u32 i = base + threadIdx.x;
+    u32 v = i < nblocks ? block_counts[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (u32 off = 1; off < 1024; off <<= 1) {
+      u32 x = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += x;
+      __syncthreads();
+    }
+    u32 incl = sh[threadIdx.x];
+    if (i < nblocks) block_counts[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+// each run head sums its run: v' = (v == 0 ? beta : v) * eq[g]   (prep_v)
+template <int F>
+__global__ __launch_bounds__(QD_THREADS) void bindg_emit_kernel(size_t n, const corner4* __restrict__ t,
+                                                                const elt_t* __restrict__ kvec, const elt_t* __restrict__ eq,
+                                                                elt_t beta, const u32* __restrict__ block_off,
+                                                                uint2* __restrict__ hc_out, elt_t* __restrict__ vc_out) {
+  __shared__ u32 wave_off[QD_THREADS / 64];
+  size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x;
+  bool head = i < n && is_head(t, i);
+  u64 mask = __ballot(head);
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_off[wave] = (u32)__popcll(mask);
+  __syncthreads();
+  u32 off = block_off[blockIdx.x];
+  for (u32 w = 0; w < wave; ++w) off += wave_off[w];
+  off += (u32)__popcll(mask & ((1ull << lane) - 1));
+  if (!head) return;
+  corner4 c0 = t[i];
+  elt_t acc = elt_zero();
+  for (size_t j = i; j < n; ++j) {
+    corner4 cj = t[j];
+    if (cj.h0 != c0.h0 || cj.h1 != c0.h1) break;
+    elt_t v = ld16(&kvec[cj.vi]);
+    if ((v.lo | v.hi) == 0) v = beta;
+    acc = Fld<F>::add(acc, Fld<F>::mul(v, ld16(&eq[cj.g])));
+  }
+  hc_out[off] = make_uint2(c0.h0, c0.h1);
+  st16(&vc_out[off], acc);
+}
+
+#define QD_DISPATCH(field, KERNEL, grid, block, ...)                                    \
+  do {                                                                                  \
+    if ((field) == LFGPU_FIELD_GF2_128)                                                 \
+      hipLaunchKernelGGL(KERNEL<FIELD_GF2_128>, grid, block, 0, c->stream, __VA_ARGS__); \
+    else                                                                                \
+      hipLaunchKernelGGL(KERNEL<FIELD_FP128>, grid, block, 0, c->stream, __VA_ARGS__);   \
+  } while (0)
+
+extern "C" int lfgpu_quad_free(lfgpu_quad* q) {
+  if (!q) return LFGPU_ERR_ARG;
+  if (q->d_morton) (void)hipFree(q->d_morton);
+  if (q->d_bygate) (void)hipFree(q->d_bygate);
+  if (q->d_goff) (void)hipFree(q->d_goff);
+  if (q->d_kvec) (void)hipFree(q->d_kvec);
+  delete q;
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32_t* g, const uint32_t* h0,
+                                 const uint32_t* h1, const uint32_t* vi, size_t nk, const void* h_kvec, size_t nv,
+                                 lfgpu_quad** out) {
+  if (!c || !out || n == 0 || !g || !h0 || !h1 || !vi || !h_kvec || nk == 0 || nv == 0)
+    return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: bad argument (Quad n > 0, quad.h:86)");
+  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: field");
+  if (n > 0xfffffff0u || nv > 0xfffffff0u) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: too large");
+  LF_HIP(c, hipSetDevice(c->device));
+  std::vector<corner4> mort(n), byg(n);
+  std::vector<u32> goff(nv + 1, 0);
+  for (size_t i = 0; i < n; ++i) {
+    if (g[i] >= nv || vi[i] >= nk) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: corner %zu out of range", i);
+    mort[i] = corner4{g[i], h0[i], h1[i], vi[i]};
+    goff[g[i] + 1]++;
+  }
+  for (size_t v = 0; v < nv; ++v) goff[v + 1] += goff[v];
+  {
+    std::vector<u32> pos(goff.begin(), goff.end() - 1);
+    for (size_t i = 0; i < n; ++i) byg[pos[g[i]]++] = mort[i];  // counting sort: stable
+  }
+  lfgpu_quad* q = new lfgpu_quad();
+  q->c = c;
+  q->field = field;
+  q->n = n;
+  q->nk = nk;
+  q->nv = nv;
+  q->d_morton = q->d_bygate = nullptr;
+  q->d_goff = nullptr;
+  q->d_kvec = nullptr;
+  bool ok = hipMalloc((void**)&q->d_morton, n * 16) == hipSuccess && hipMalloc((void**)&q->d_bygate, n * 16) == hipSuccess &&
+            hipMalloc((void**)&q->d_goff, (nv + 1) * 4) == hipSuccess && hipMalloc((void**)&q->d_kvec, nk * 16) == hipSuccess;
+  ok = ok && hipMemcpy(q->d_morton, mort.data(), n * 16, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(q->d_bygate, byg.data(), n * 16, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(q->d_goff, goff.data(), (nv + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(q->d_kvec, h_kvec, nk * 16, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    lfgpu_quad_free(q);
+    return lf_fail(c, LFGPU_ERR_NOMEM, "quad_upload: device allocation / copy failed");
+  }
+  *out = q;
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_eval_quad(lfgpu_quad* q, size_t nw, const void* d_W, void* d_V, int* ok_out) {
+  if (!q || !d_W || !d_V || !ok_out) return LFGPU_ERR_ARG;
+  lfgpu_ctx* c = q->c;
+  (void)nw;
+  LF_HIP(c, hipSetDevice(c->device));
+  int* d_fail = (int*)((uint8_t*)c->mailbox_d + 128);
+  LF_HIP(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
+  u32 nb = (u32)((q->nv + QD_THREADS - 1) / QD_THREADS);
+  QD_DISPATCH(q->field, eval_quad_kernel, dim3(nb), dim3(QD_THREADS), (u32)q->nv, (const u32*)q->d_goff,
+              (const corner4*)q->d_bygate, (const elt_t*)q->d_kvec, (const elt_t*)d_W, (elt_t*)d_V, d_fail);
+  LF_HIP(c, hipGetLastError());
+  LF_HIP(c, hipMemcpyAsync(c->mailbox_h, d_fail, 4, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  *ok_out = *(const int*)c->mailbox_h ? 0 : 1;
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                                 const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out) {
+  if (!q || !alpha || !beta || !d_hc_out || !d_vc_out || !n_out || (logv && (!h_G0 || !h_G1))) return LFGPU_ERR_ARG;
+  lfgpu_ctx* c = q->c;
+  if (logv > 40 || ((size_t)1 << logv) < q->nv) return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_g: 2^logv < nv");
+  LF_HIP(c, hipSetDevice(c->device));
+  const int field = q->field;
+  const elt_t one = field == LFGPU_FIELD_GF2_128 ? elt_t{1, 0} : h_fp_of_scalar(1);
+  // table [G0 | G1 | 1-G0 | 1-G1]
+  std::vector<elt_t> Gt(4 * logv + 1);
+  const elt_t* G0 = (const elt_t*)h_G0;
+  const elt_t* G1 = (const elt_t*)h_G1;
+  for (size_t l = 0; l < logv; ++l) {
+    Gt[l] = G0[l];
+    Gt[logv + l] = G1[l];
+    Gt[2 * logv + l] = field == LFGPU_FIELD_GF2_128 ? gf_add(one, G0[l]) : fp_sub(one, G0[l]);
+    Gt[3 * logv + l] = field == LFGPU_FIELD_GF2_128 ? gf_add(one, G1[l]) : fp_sub(one, G1[l]);
+  }
+  const size_t n = q->n;
+  const u32 nb = (u32)((n + QD_THREADS - 1) / QD_THREADS);
+  void* sc = nullptr;
+  LF_TRY(lf_scratch3(c, q->nv * 16 + Gt.size() * 16 + (size_t)nb * 4 + 256, &sc));
+  elt_t* d_eq = (elt_t*)sc;
+  elt_t* d_G = d_eq + q->nv;
+  u32* counts = (u32*)(d_G + Gt.size());
+  u32* total = (u32*)((uint8_t*)c->mailbox_d + 192);
+  LF_HIP(c, hipMemcpyAsync(d_G, Gt.data(), Gt.size() * 16, hipMemcpyHostToDevice, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));  // Gt is a stack-lifetime host buffer
+  elt_t al{alpha[0], alpha[1]}, be{beta[0], beta[1]};
+  QD_DISPATCH(field, raw_eq2_kernel, dim3((u32)((q->nv + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logv,
+              (u32)q->nv, (const elt_t*)d_G, al, one, d_eq);
+  hipLaunchKernelGGL(bindg_count_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton, counts);
+  hipLaunchKernelGGL(bindg_scan_kernel, dim3(1), dim3(1024), 0, c->stream, nb, counts, total);
+  QD_DISPATCH(field, bindg_emit_kernel, dim3(nb), dim3(QD_THREADS), n, (const corner4*)q->d_morton,
+              (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)counts, (uint2*)d_hc_out, (elt_t*)d_vc_out);
+  LF_HIP(c, hipGetLastError());
+  LF_HIP(c, hipMemcpyAsync(c->mailbox_h, total, 4, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  *n_out = *(const u32*)c->mailbox_h;
+  return LFGPU_OK;
+}

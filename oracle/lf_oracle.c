@@ -121,8 +121,6 @@ lfo_elt lfo_gf_mul(lfo_elt a, lfo_elt b) {
   return gf_mul_portable(a, b);
 }
 
-static inline int gf_is_zero(lfo_elt a) { return (a.l[0] | a.l[1]) == 0; }
-static inline int gf_eq(lfo_elt a, lfo_elt b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1]; }
 
 /* a^(2^128-2) -- any correct inverse equals GF2_128::invertf (lib/gf2k/gf2_128.h:272-309) */
 lfo_elt lfo_gf_inv(lfo_elt a) {
@@ -721,6 +719,70 @@ void lfo_qw_scatter(int f, size_t n, const uint32_t* hc, const lfo_elt* vc, int 
     uint32_t p0 = hc[2 * i + hand], p1 = hc[2 * i + 1 - hand];
     QW[p0] = lfo_add(f, QW[p0], lfo_mul(f, vc[i], Wother[p1]));
   }
+}
+
+/* Eqs::raw_eq2 / fill_recursive (lib/arrays/eqs.h:46-80) */
+static void eq2_fill(int f, lfo_elt* eq, size_t l, size_t n, const lfo_elt* G0, const lfo_elt* G1, lfo_elt w0, lfo_elt w1) {
+  if (l > 0) {
+    size_t nl = l - 1, s = (size_t)1 << nl;
+    lfo_elt w0hi = lfo_mul(f, w0, G0[nl]), w1hi = lfo_mul(f, w1, G1[nl]);
+    lfo_elt w0lo = lfo_sub(f, w0, w0hi), w1lo = lfo_sub(f, w1, w1hi);
+    if (n <= s) {
+      eq2_fill(f, eq, nl, n, G0, G1, w0lo, w1lo);
+    } else {
+      eq2_fill(f, eq, nl, s, G0, G1, w0lo, w1lo);
+      eq2_fill(f, eq + s, nl, n - s, G0, G1, w0hi, w1hi);
+    }
+  } else {
+    eq[0] = lfo_add(f, w0, w1);
+  }
+}
+void lfo_raw_eq2(int f, size_t logn, size_t n, const lfo_elt* G0, const lfo_elt* G1, lfo_elt alpha, lfo_elt* eq) {
+  lfo_elt one = f == LFO_FIELD_GF2_128 ? (lfo_elt){{1, 0}} : lfo_fp_of_scalar(1);
+  eq2_fill(f, eq, logn, n, G0, G1, one, alpha);
+}
+
+static int elt_is_zero(lfo_elt a) { return (a.l[0] | a.l[1]) == 0; }
+
+/* ProverLayers::eval_quad (lib/sumcheck/prover_layers.h:278-305), n0 = 1; r = h[0], l = h[1] */
+int lfo_eval_quad(int f, size_t nterms, const uint32_t* g, const uint32_t* h0, const uint32_t* h1, const uint32_t* vi,
+                  const lfo_elt* kvec, size_t nv, const lfo_elt* W, lfo_elt* V) {
+  memset(V, 0, nv * sizeof(lfo_elt));
+  for (size_t i = 0; i < nterms; ++i) {
+    lfo_elt v = kvec[vi[i]];
+    if (elt_is_zero(v)) {
+      lfo_elt y = lfo_mul(f, W[h1[i]], W[h0[i]]);
+      if (!elt_is_zero(y)) return 0;
+    } else {
+      lfo_elt x = lfo_mul(f, lfo_mul(f, v, W[h1[i]]), W[h0[i]]);
+      V[g[i]] = lfo_add(f, V[g[i]], x);
+    }
+  }
+  return 1;
+}
+
+/* Quad::bind_g (lib/sumcheck/quad.h:152-185) with prep_v (:213-220) */
+size_t lfo_quad_bind_g(int f, size_t nterms, const uint32_t* g, const uint32_t* h0, const uint32_t* h1,
+                       const uint32_t* vi, const lfo_elt* kvec, size_t logv, const lfo_elt* G0, const lfo_elt* G1,
+                       lfo_elt alpha, lfo_elt beta, uint32_t* hc_out, lfo_elt* vc_out) {
+  size_t nv = (size_t)1 << logv;
+  lfo_elt* dot = (lfo_elt*)malloc(nv * sizeof(lfo_elt));
+  lfo_raw_eq2(f, logv, nv, G0, G1, alpha, dot);
+  size_t wr = 0;
+  for (size_t i = 0; i < nterms; ++i) {
+    lfo_elt v = kvec[vi[i]];
+    lfo_elt pv = lfo_mul(f, elt_is_zero(v) ? beta : v, dot[g[i]]);
+    if (wr > 0 && hc_out[2 * (wr - 1)] == h0[i] && hc_out[2 * (wr - 1) + 1] == h1[i]) {
+      vc_out[wr - 1] = lfo_add(f, vc_out[wr - 1], pv);
+    } else {
+      hc_out[2 * wr] = h0[i];
+      hc_out[2 * wr + 1] = h1[i];
+      vc_out[wr] = pv;
+      ++wr;
+    }
+  }
+  free(dot);
+  return wr;
 }
 
 /* Blas::axpy / vaxpy (lib/algebra/blas.h:62-78) */

@@ -115,6 +115,18 @@ size_t lfo_hquad_bind_h(int field, size_t n, uint32_t* hc, lfo_elt* vc, lfo_elt 
 void lfo_qw_scatter(int field, size_t n, const uint32_t* hc, const lfo_elt* vc, int hand,
                     const lfo_elt* Wother, size_t nqw, lfo_elt* QW);
 
+/* ------------------------------------------------------------------ quad (expanded corners) */
+/* eq[i] = EQ(G0,i) + alpha*EQ(G1,i), i < n  (Eqs::raw_eq2) */
+void lfo_raw_eq2(int field, size_t logn, size_t n, const lfo_elt* G0, const lfo_elt* G1, lfo_elt alpha, lfo_elt* eq);
+/* ProverLayers::eval_quad with nc = 1: V[g] += kvec[vi]*W[h1]*W[h0]; assert-zero terms (kvec[vi]==0)
+ * require W[h1]*W[h0] == 0.  Returns 1 if ok, 0 if an assertion failed. */
+int lfo_eval_quad(int field, size_t nterms, const uint32_t* g, const uint32_t* h0, const uint32_t* h1,
+                  const uint32_t* vi, const lfo_elt* kvec, size_t nv, const lfo_elt* W, lfo_elt* V);
+/* Quad::bind_g: hc_out[2*j..], vc_out[j]; returns the HQuad size */
+size_t lfo_quad_bind_g(int field, size_t nterms, const uint32_t* g, const uint32_t* h0, const uint32_t* h1,
+                       const uint32_t* vi, const lfo_elt* kvec, size_t logv, const lfo_elt* G0, const lfo_elt* G1,
+                       lfo_elt alpha, lfo_elt beta, uint32_t* hc_out, lfo_elt* vc_out);
+
 /* ------------------------------------------------------------------ Ligero row combos (Blas) */
 /* y[j] += a * x[j] */
 void lfo_axpy(int field, size_t n, lfo_elt* y, lfo_elt a, const lfo_elt* x);

@@ -38,6 +38,7 @@
 #include "merkle/merkle_tree.h"
 #include "random/random.h"
 #include "sumcheck/hquad.h"
+#include "sumcheck/quad.h"
 // ProverLayers::evaluations is private; the shim needs to call it directly.
 #define private public
 #include "sumcheck/prover_layers.h"
@@ -298,4 +299,75 @@ static size_t hquad_bind_t(const Field& F, size_t n, uint32_t* hc, void* vc, con
 }
 extern "C" size_t ref_hquad_bind_h(int field, size_t n, uint32_t* hc, void* vc, const void* r, int hand) {
   return field == 4 ? hquad_bind_t(gf4(), n, hc, vc, r, hand) : hquad_bind_t(fp(), n, hc, vc, r, hand);
+}
+
+// ---------------------------------------------------------------- quad: eval_quad / bind_g / raw_eq2
+template <class Field>
+static std::unique_ptr<Quad<Field>> make_quad(size_t n, const uint32_t* g, const uint32_t* h0, const uint32_t* h1,
+                                              const uint32_t* vi, size_t nk, const void* kvec) {
+  using Elt = typename Field::Elt;
+  using Q = Quad<Field>;
+  using qc = typename Q::quad_corner_t;
+  auto kv = std::make_shared<std::vector<Elt>>(nk);
+  memcpy(kv->data(), kvec, 16 * nk);
+  auto dt = std::make_shared<typename Q::delta_table_t>(n);
+  auto q = std::make_unique<Q>(n, kv, dt);
+  uint32_t pg = 0, p0 = 0, p1 = 0;
+  for (size_t i = 0; i < n; ++i) {
+    (*dt)[i].dg = qc(uint32_t(g[i] - pg));
+    (*dt)[i].dh[0] = qc(uint32_t(h0[i] - p0));
+    (*dt)[i].dh[1] = qc(uint32_t(h1[i] - p1));
+    (*dt)[i].vi = vi[i];
+    q->assign(i, static_cast<uint32_t>(i));
+    pg = g[i];
+    p0 = h0[i];
+    p1 = h1[i];
+  }
+  return q;
+}
+template <class Field>
+static int eval_quad_t(const Field& F, size_t n, const uint32_t* g, const uint32_t* h0, const uint32_t* h1,
+                       const uint32_t* vi, size_t nk, const void* kvec, size_t nv, size_t nw, const void* W, void* V) {
+  auto q = make_quad<Field>(n, g, h0, h1, vi, nk, kvec);
+  Dense<Field> dW(1, nw), dV(1, nv);
+  memcpy(&dW.v_[0], W, 16 * nw);
+  ProverLayers<Field> pl(F);
+  bool ok = pl.eval_quad(q.get(), &dV, &dW, F);
+  memcpy(V, &dV.v_[0], 16 * nv);
+  return ok ? 1 : 0;
+}
+extern "C" int ref_eval_quad(int field, size_t n, const uint32_t* g, const uint32_t* h0, const uint32_t* h1,
+                             const uint32_t* vi, size_t nk, const void* kvec, size_t nv, size_t nw, const void* W, void* V) {
+  return field == 4 ? eval_quad_t(gf4(), n, g, h0, h1, vi, nk, kvec, nv, nw, W, V)
+                    : eval_quad_t(fp(), n, g, h0, h1, vi, nk, kvec, nv, nw, W, V);
+}
+template <class Field>
+static size_t bind_g_t(const Field& F, size_t n, const uint32_t* g, const uint32_t* h0, const uint32_t* h1,
+                       const uint32_t* vi, size_t nk, const void* kvec, size_t logv, const void* G0, const void* G1,
+                       const void* alpha, const void* beta, uint32_t* hc, void* vc) {
+  using Elt = typename Field::Elt;
+  auto q = make_quad<Field>(n, g, h0, h1, vi, nk, kvec);
+  auto hq = q->bind_g(logv, reinterpret_cast<const Elt*>(G0), reinterpret_cast<const Elt*>(G1), ld<Elt>(alpha),
+                      ld<Elt>(beta), F);
+  for (size_t i = 0; i < hq->n_; ++i) {
+    hc[2 * i] = static_cast<uint32_t>(size_t(hq->hc_[i].h[0]));
+    hc[2 * i + 1] = static_cast<uint32_t>(size_t(hq->hc_[i].h[1]));
+    st(reinterpret_cast<uint8_t*>(vc) + 16 * i, hq->vc_[i].v);
+  }
+  return hq->n_;
+}
+extern "C" size_t ref_quad_bind_g(int field, size_t n, const uint32_t* g, const uint32_t* h0, const uint32_t* h1,
+                                  const uint32_t* vi, size_t nk, const void* kvec, size_t logv, const void* G0,
+                                  const void* G1, const void* alpha, const void* beta, uint32_t* hc, void* vc) {
+  return field == 4 ? bind_g_t(gf4(), n, g, h0, h1, vi, nk, kvec, logv, G0, G1, alpha, beta, hc, vc)
+                    : bind_g_t(fp(), n, g, h0, h1, vi, nk, kvec, logv, G0, G1, alpha, beta, hc, vc);
+}
+template <class Field>
+static void raw_eq2_t(const Field& F, size_t logn, size_t n, const void* G0, const void* G1, const void* alpha, void* out) {
+  using Elt = typename Field::Elt;
+  auto v = Eqs<Field>::raw_eq2(logn, n, reinterpret_cast<const Elt*>(G0), reinterpret_cast<const Elt*>(G1), ld<Elt>(alpha), F);
+  memcpy(out, v.data(), 16 * n);
+}
+extern "C" void ref_raw_eq2(int field, size_t logn, size_t n, const void* G0, const void* G1, const void* alpha, void* out) {
+  if (field == 4) raw_eq2_t(gf4(), logn, n, G0, G1, alpha, out); else raw_eq2_t(fp(), logn, n, G0, G1, alpha, out);
 }

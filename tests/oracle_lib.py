@@ -83,6 +83,9 @@ def oracle():
         "lfo_dense_bind": (sz, [ci, sz, Elt, vp, vp]),
         "lfo_hquad_bind_h": (sz, [ci, sz, vp, vp, Elt, ci]),
         "lfo_qw_scatter": (None, [ci, sz, vp, vp, ci, vp, sz, vp]),
+        "lfo_raw_eq2": (None, [ci, sz, sz, vp, vp, Elt, vp]),
+        "lfo_eval_quad": (ci, [ci, sz, vp, vp, vp, vp, vp, sz, vp, vp]),
+        "lfo_quad_bind_g": (sz, [ci, sz, vp, vp, vp, vp, vp, sz, vp, vp, Elt, Elt, vp, vp]),
         "lfo_axpy": (None, [ci, sz, vp, Elt, vp]), "lfo_vaxpy": (None, [ci, sz, vp, vp, vp]),
         "lfo_fp_bogorng_fill": (None, [u64, sz, vp]), "lfo_gf_fill": (None, [u64, sz, vp]),
     }
@@ -141,6 +144,9 @@ def ref():
         "ref_sumcheck_evaluations": (None, [ci, sz, vp, vp, vp, vp, vp]),
         "ref_dense_bind": (sz, [ci, sz, vp, vp]),
         "ref_hquad_bind_h": (sz, [ci, sz, vp, vp, vp, ci]),
+        "ref_eval_quad": (ci, [ci, sz, vp, vp, vp, vp, sz, vp, sz, sz, vp, vp]),
+        "ref_quad_bind_g": (sz, [ci, sz, vp, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp]),
+        "ref_raw_eq2": (None, [ci, sz, sz, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

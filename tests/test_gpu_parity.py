@@ -446,3 +446,38 @@ def _wrap(G, ptr, nbytes):
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     assert hip.hipMemcpy(t.data_ptr(), ptr, nbytes, 3) == 0  # hipMemcpyDeviceToDevice
     return t
+
+
+# ---------------------------------------------------------------- K10 / K11 quad
+@pytest.mark.parametrize("field", [GF, FP])
+@pytest.mark.parametrize("logv,logw,nterms,n_assert", [(0, 1, 1, 0), (3, 4, 40, 5), (8, 10, 5000, 300), (12, 13, 60000, 2000)])
+def test_eval_quad_and_bind_g(G, field, logv, logw, nterms, n_assert):
+    import torch
+    import quad_util as qu
+    o = ol.oracle()
+    rng = np.random.default_rng(logv * 100 + logw + field)
+    nterms = min(nterms, (1 << logv) * (1 << logw) // 2 + 1)
+    L = qu.make_layer(rng, field, logv, logw, nterms, n_assert=min(n_assert, nterms // 2))
+    q = G.pkg.Quad(G.gpu(), field, L["g"], L["h0"], L["h1"], L["vi"], L["kvec"], L["nv"])
+    want = np.zeros((L["nv"], 2), dtype=np.uint64)
+    assert o.lfo_eval_quad(field, L["n"], P(L["g"]), P(L["h0"]), P(L["h1"]), P(L["vi"]), P(L["kvec"]), L["nv"], P(L["W"]), P(want)) == 1
+    dW = G.to_dev(L["W"])
+    dV = torch.ones(L["nv"] * 16, dtype=torch.uint8, device="cuda")
+    assert q.eval(L["nw"], dW.data_ptr(), dV.data_ptr()) is True
+    assert (G.from_dev(dV, np.uint64, (L["nv"], 2)) == want).all()
+    if n_assert:  # a violated assert-zero term is reported, as eval_quad returns false
+        W2 = ol.rand_elts(rng, L["nw"], field)
+        W2[W2[:, 0] == 0, 0] = 1
+        assert q.eval(L["nw"], G.to_dev(W2).data_ptr(), dV.data_ptr()) is False
+    G0, G1 = ol.rand_elts(rng, max(1, logv), field), ol.rand_elts(rng, max(1, logv), field)
+    alpha, beta = ol.rand_elts(rng, 1, field)[0], ol.rand_elts(rng, 1, field)[0]
+    ha, va = np.zeros((L["n"], 2), dtype=np.uint32), np.zeros((L["n"], 2), dtype=np.uint64)
+    na = o.lfo_quad_bind_g(field, L["n"], P(L["g"]), P(L["h0"]), P(L["h1"]), P(L["vi"]), P(L["kvec"]), logv, P(G0), P(G1),
+                           elt(alpha), elt(beta), P(ha), P(va))
+    dh = torch.zeros(L["n"] * 8, dtype=torch.uint8, device="cuda")
+    dv = torch.zeros(L["n"] * 16, dtype=torch.uint8, device="cuda")
+    nb = q.bind_g(logv, G0, G1, (int(alpha[0]), int(alpha[1])), (int(beta[0]), int(beta[1])), dh.data_ptr(), dv.data_ptr())
+    assert nb == na
+    assert (G.from_dev(dh, np.uint32, (L["n"], 2))[:nb] == ha[:na]).all()
+    assert (G.from_dev(dv, np.uint64, (L["n"], 2))[:nb] == va[:na]).all()
+    q.close()

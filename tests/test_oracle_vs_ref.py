@@ -227,3 +227,43 @@ def _morton(a, b):
     for i in range(16):
         m |= ((a >> i) & 1) << (2 * i) | ((b >> i) & 1) << (2 * i + 1)
     return m
+
+
+@pytest.mark.parametrize("field", [GF, FP])
+@pytest.mark.parametrize("logv,logw,nterms,n_assert", [(0, 1, 1, 0), (3, 4, 40, 5), (8, 10, 5000, 300), (10, 9, 9000, 0)])
+def test_eval_quad_bind_g_raw_eq2(field, logv, logw, nterms, n_assert):
+    import quad_util as qu
+    o, r = ol.oracle(), ol.ref()
+    rng = np.random.default_rng(logv * 100 + logw + field)
+    nterms = min(nterms, (1 << logv) * (1 << logw) // 2 + 1)
+    L = qu.make_layer(rng, field, logv, logw, nterms, n_assert=min(n_assert, nterms // 2))
+    # eval_quad (assertions satisfied)
+    Va = np.zeros((L["nv"], 2), dtype=np.uint64)
+    Vb = np.zeros((L["nv"], 2), dtype=np.uint64)
+    oka = o.lfo_eval_quad(field, L["n"], P(L["g"]), P(L["h0"]), P(L["h1"]), P(L["vi"]), P(L["kvec"]), L["nv"], P(L["W"]), P(Va))
+    okb = r.ref_eval_quad(field, L["n"], P(L["g"]), P(L["h0"]), P(L["h1"]), P(L["vi"]), len(L["kvec"]), P(L["kvec"]),
+                          L["nv"], L["nw"], P(L["W"]), P(Vb))
+    assert oka == okb == 1 and (Va == Vb).all()
+    if n_assert:  # violated assertion: both must report failure
+        W2 = ol.rand_elts(rng, L["nw"], field)
+        W2[W2[:, 0] == 0, 0] = 1
+        oka = o.lfo_eval_quad(field, L["n"], P(L["g"]), P(L["h0"]), P(L["h1"]), P(L["vi"]), P(L["kvec"]), L["nv"], P(W2), P(Va))
+        okb = r.ref_eval_quad(field, L["n"], P(L["g"]), P(L["h0"]), P(L["h1"]), P(L["vi"]), len(L["kvec"]), P(L["kvec"]),
+                              L["nv"], L["nw"], P(W2), P(Vb))
+        assert oka == okb == 0
+    # raw_eq2 + bind_g
+    G0, G1 = ol.rand_elts(rng, max(1, logv), field), ol.rand_elts(rng, max(1, logv), field)
+    alpha, beta = ol.rand_elts(rng, 1, field)[0], ol.rand_elts(rng, 1, field)[0]
+    for n in (L["nv"], max(1, L["nv"] - 3)):
+        ea = np.zeros((n, 2), dtype=np.uint64)
+        eb = np.zeros((n, 2), dtype=np.uint64)
+        o.lfo_raw_eq2(field, logv, n, P(G0), P(G1), elt(alpha), P(ea))
+        r.ref_raw_eq2(field, logv, n, P(G0), P(G1), P(alpha), P(eb))
+        assert (ea == eb).all()
+    ha, va = np.zeros((L["n"], 2), dtype=np.uint32), np.zeros((L["n"], 2), dtype=np.uint64)
+    hb, vb = np.zeros((L["n"], 2), dtype=np.uint32), np.zeros((L["n"], 2), dtype=np.uint64)
+    na = o.lfo_quad_bind_g(field, L["n"], P(L["g"]), P(L["h0"]), P(L["h1"]), P(L["vi"]), P(L["kvec"]), logv, P(G0), P(G1),
+                           elt(alpha), elt(beta), P(ha), P(va))
+    nb = r.ref_quad_bind_g(field, L["n"], P(L["g"]), P(L["h0"]), P(L["h1"]), P(L["vi"]), len(L["kvec"]), P(L["kvec"]), logv,
+                           P(G0), P(G1), P(alpha), P(beta), P(hb), P(vb))
+    assert na == nb and (ha[:na] == hb[:nb]).all() and (va[:na] == vb[:nb]).all()
