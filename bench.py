@@ -51,6 +51,54 @@ def cpu_baseline(logn, budget_s=12.0):
             "sample": "%d rows of 2^%d Fp128 points through FFT<Fp128>::fftb, 1 thread, %.1f s" % (rows, logn, dt)}
 
 
+def ligero_commit_shape(gpu, torch, np, stream, with_cpu):
+    """BASELINE configs[2]: Ligero RS encode + Merkle column commit on the flatsha256 32-block tableau
+    shape (GF2_128<4>: 150 rows, block 910, dblock 1819, block_enc 8192, block_ext 6373 -- SURVEY 6b),
+    synthetic witness rows resident in HBM.  GPU: K3 (3 launches) + K5 + K6."""
+    import oracle_lib as ol
+    nrow, block, dblock, be = 150, 910, 1819, 8192
+    ext = be - dblock
+    rng = np.random.default_rng(32)
+    T = ol.rand_elts(rng, nrow * be).reshape(nrow, be, 2)
+    nonces = rng.integers(0, 256, size=(ext, 32), dtype=np.uint8)
+    dT0 = torch.from_numpy(T.view(np.int64).reshape(-1)).cuda()
+    dT = dT0.clone()
+    dN = torch.from_numpy(nonces).cuda()
+    dL = torch.zeros(2 * ext * 32, dtype=torch.uint8, device="cuda")
+
+    def run():
+        p = dT.data_ptr()
+        gpu.gf2128_rs_encode_rows(p, 1, block, be, ld=be)
+        gpu.gf2128_rs_encode_rows(p + be * 16, 2, dblock, be, ld=be)
+        gpu.gf2128_rs_encode_rows(p + 3 * be * 16, nrow - 3, block, be, ld=be)
+        return gpu.column_commit(4, nrow, be, dblock, ext, p, dN.data_ptr(), dL.data_ptr())
+
+    root = run()
+    reps = 20
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dT.copy_(dT0)
+        run()
+    torch.cuda.synchronize()
+    gpu_ms = (time.perf_counter() - t0) / reps * 1e3
+    res = {"shape": "150 rows x 8192 (block 910, dblock 1819, 6373 leaves), GF2_128<4>", "gpu_ms": gpu_ms,
+           "includes": "device copy of the 19.7 MB tableau + 3 RS launches + leaf hash + tree + 32-byte root readback"}
+    if with_cpu:
+        r = ol.ref()
+        if r is not None:
+            Tc = T.copy()
+            t0 = time.perf_counter()
+            r.ref_lch14_rs_encode_rows(4, 1, block, be, ol.P(Tc), be)
+            r.ref_lch14_rs_encode_rows(4, 2, dblock, be, ol.P(Tc[1:]), be)
+            r.ref_lch14_rs_encode_rows(4, nrow - 3, block, be, ol.P(Tc[3:]), be)
+            rootc = np.zeros(32, dtype=np.uint8)
+            r.ref_column_commit(4, nrow, be, dblock, ext, ol.P(Tc), ol.P(nonces), ol.P(rootc))
+            res["cpu_reference_ms"] = (time.perf_counter() - t0) * 1e3
+            res["root_matches_reference"] = bool(rootc.tobytes() == root)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +222,8 @@ def main():
         ms = e0.elapsed_time(e1) / s2
         out["gf2128_lch14_fft"] = {"field_elems_per_s": nelem / (ms * 1e-3), "ms_per_step": ms,
                                    "algo_GBps": 2.0 * nelem * 16 / (ms * 1e-3) / 1e9}
+    if rank == 0 and not args.no_secondary:
+        out["ligero_commit_flatsha32"] = ligero_commit_shape(gpu, torch, np, stream, not args.no_cpu_baseline)
     if dist is not None:
         dist.barrier()
     if rank == 0:

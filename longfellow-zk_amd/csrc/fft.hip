@@ -13,8 +13,10 @@
 
 #include "ctx.h"
 
-#define TILE_ELTS 8192u
-#define FFT_THREADS 1024
+#define TILE_ELTS 8192u  // largest tile (128 KiB)
+// Tile geometry: 2^13 elements / 1024 threads (one workgroup per CU) or 2^12 elements / 512 threads
+// (two workgroups per CU, so one workgroup's HBM phase overlaps the other's butterfly phase).
+static int g_tile_log = 12;  // measured: 46.9 ms vs 54.8 ms per 2^20 x 1024 Fp128 batch (profiles/r01)
 
 struct TilePlan {
   const elt_t* src;
@@ -28,9 +30,19 @@ struct TilePlan {
 
 __device__ __forceinline__ u32 bitrev(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
+// LDS slot of point k, column c.  Rows are C*16 bytes; bit-reversed / strided row indices would put
+// the 8 lanes of one ds_write_b128 pass on the same banks, so the top four bits of k are XORed into
+// the low slot bits (a bijection inside every aligned 16-slot = 256-byte bank row).
+__device__ __forceinline__ u32 lds_slot(u32 k, u32 c, u32 logT, u32 logC) {
+  u32 slot = (k << logC) + c;
+  if (logT >= 8 && logC >= 3) slot ^= (k >> (logT - 4)) & 15u;
+  return slot;
+}
+
 // ------------------------------------------------------------------ K1: Fp128
 // W[i << wshift] = w_T^i (i < T/2).  Optional inter-pass twiddle w_n^{j*(col)}
 // = tw_lo[e & 1023] * tw_hi[e >> 10].
+template <int FFT_THREADS>
 __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt_t* __restrict__ W, u32 wshift,
                                                            const elt_t* __restrict__ tw_lo,
                                                            const elt_t* __restrict__ tw_hi) {
@@ -45,7 +57,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
     if (p.kfast_src) { k = e & (T - 1); c = e >> p.logT; } else { c = e & (C - 1); k = e >> p.logC; }
     elt_t v = elt_zero();
     if (cbase + c < p.nbatch) v = ld16(src + (long long)k * p.sk + (long long)c * p.sc);
-    st16(&s[(bitrev(k, p.logT) << p.logC) + c], v);
+    st16(&s[lds_slot(bitrev(k, p.logT), c, p.logT, p.logC)], v);
   }
   __syncthreads();
   for (u32 st = 0; st < p.logT; ++st) {
@@ -54,11 +66,12 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
       u32 c = e & (C - 1), b = e >> p.logC;
       u32 j = b & (m - 1);
       u32 i0 = ((b >> st) << (st + 1)) + j, i1 = i0 + m;
-      elt_t a0 = ld16(&s[(i0 << p.logC) + c]);
-      elt_t a1 = ld16(&s[(i1 << p.logC) + c]);
+      const u32 s0 = lds_slot(i0, c, p.logT, p.logC), s1 = lds_slot(i1, c, p.logT, p.logC);
+      elt_t a0 = ld16(&s[s0]);
+      elt_t a1 = ld16(&s[s1]);
       if (j) a1 = fp_mul(a1, ld16(&W[(size_t)(j << (p.logT - 1 - st)) << wshift]));
-      st16(&s[(i0 << p.logC) + c], fp_add(a0, a1));
-      st16(&s[(i1 << p.logC) + c], fp_sub(a0, a1));
+      st16(&s[s0], fp_add(a0, a1));
+      st16(&s[s1], fp_sub(a0, a1));
     }
     __syncthreads();
   }
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
     u32 j, c;
     if (p.kfast_dst) { j = e & (T - 1); c = e >> p.logT; } else { c = e & (C - 1); j = e >> p.logC; }
     if (cbase + c >= p.nbatch) continue;
-    elt_t v = ld16(&s[(j << p.logC) + c]);
+    elt_t v = ld16(&s[lds_slot(j, c, p.logT, p.logC)]);
     if (tw_lo) {
       u32 ex = j * (cbase + c);
       if (ex) {
@@ -90,6 +103,7 @@ struct LchTables {
   u32 off[16];
 };
 
+template <int FFT_THREADS>
 __global__ __launch_bounds__(FFT_THREADS) void lch_fft_tile(TilePlan p, int inverse, LchTables t) {
   extern __shared__ elt_t s[];
   const u32 T = 1u << p.logT, C = 1u << p.logC, tid = threadIdx.x;
@@ -144,11 +158,32 @@ __global__ __launch_bounds__(FFT_THREADS) void lch_fft_tile(TilePlan p, int inve
 static int set_lds_limit(lfgpu_ctx* c) {
   static bool done = false;
   if (!done) {
-    LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
-    LF_HIP(c, hipFuncSetAttribute((const void*)lch_fft_tile, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
+    if (const char* e = getenv("LFGPU_TILE_LOG")) {  // tuning knob: 12 or 13
+      int v = atoi(e);
+      if (v == 12 || v == 13) g_tile_log = v;
+    }
+    LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
+    LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
+    LF_HIP(c, hipFuncSetAttribute((const void*)lch_fft_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
+    LF_HIP(c, hipFuncSetAttribute((const void*)lch_fft_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
     done = true;
   }
   return LFGPU_OK;
+}
+
+template <class... Args>
+static void launch_fp(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
+  if (g_tile_log == 13)
+    hipLaunchKernelGGL(fp_fft_tile<1024>, grid, dim3(1024), lds, c->stream, args...);
+  else
+    hipLaunchKernelGGL(fp_fft_tile<512>, grid, dim3(512), lds, c->stream, args...);
+}
+template <class... Args>
+static void launch_lch(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
+  if (g_tile_log == 13)
+    hipLaunchKernelGGL(lch_fft_tile<1024>, grid, dim3(1024), lds, c->stream, args...);
+  else
+    hipLaunchKernelGGL(lch_fft_tile<512>, grid, dim3(512), lds, c->stream, args...);
 }
 
 static u32 floor_pow2_log(size_t x) {
@@ -177,7 +212,7 @@ static std::string keyf(const char* fmt, ...) {
 // single-pass plan: T = n points, batch = rows
 static TilePlan plan_single(void* A, size_t rows, u32 logn, size_t ld) {
   TilePlan p{};
-  u32 logC = 13 - logn;
+  u32 logC = (u32)g_tile_log - logn;
   u32 need = lf_log2(rows);
   if (logC > need) logC = need;
   p.src = (const elt_t*)A;
@@ -210,7 +245,7 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
   elt_t w{omega[0], omega[1]};
   if (dir == 1) w = h_fp_inv(w);  // fftf = fftb with omega^-1 (fft.h:198-201)
   elt_t wn = fp_reroot(w, omega_order, n);
-  const u32 logn2 = logn <= 13 ? logn : 10, logn1 = logn - logn2;
+  const u32 logn2 = logn <= (u32)g_tile_log ? logn : 10, logn1 = logn - logn2;
   const u32 logTw = logn1 > logn2 ? logn1 : logn2;  // root table covers the larger tile
 
   // root table W[i] = w_Tw^i, i < Tw/2
@@ -229,8 +264,7 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     TilePlan p = plan_single(d_A, rows, logn, ld);
     u32 ntiles = (u32)((rows + (1u << p.logC) - 1) >> p.logC);
     size_t lds = ((size_t)16 << p.logT) << p.logC;
-    hipLaunchKernelGGL(fp_fft_tile, dim3(ntiles, 1), dim3(FFT_THREADS), lds, c->stream, p, (const elt_t*)dW,
-                       logTw - logn, (const elt_t*)nullptr, (const elt_t*)nullptr);
+    launch_fp(c, dim3(ntiles, 1), lds, p, (const elt_t*)dW, logTw - logn, (const elt_t*)nullptr, (const elt_t*)nullptr);
     LF_HIP(c, hipGetLastError());
     return LFGPU_OK;
   }
@@ -258,7 +292,7 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
   {  // pass A: n1-point transforms over k1 (stride n2), C consecutive k2 per tile
     TilePlan p{};
     p.logT = logn1;
-    p.logC = 13 - logn1;
+    p.logC = (u32)g_tile_log - logn1;
     if (p.logC > logn2) p.logC = logn2;
     p.src = (const elt_t*)d_A;
     p.dst = (elt_t*)scratch;
@@ -270,14 +304,14 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     p.nbatch = (u32)n2;
     p.kfast_src = p.kfast_dst = 0;
     size_t lds = ((size_t)16 << p.logT) << p.logC;
-    hipLaunchKernelGGL(fp_fft_tile, dim3((u32)(n2 >> p.logC), (u32)rows), dim3(FFT_THREADS), lds, c->stream, p,
-                       (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi);
+    launch_fp(c, dim3((u32)(n2 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo,
+              (const elt_t*)dhi);
     LF_HIP(c, hipGetLastError());
   }
   {  // pass B: n2-point transforms on contiguous rows j1; output X[j1 + n1*j2]
     TilePlan p{};
     p.logT = logn2;
-    p.logC = 13 - logn2;
+    p.logC = (u32)g_tile_log - logn2;
     if (p.logC > logn1) p.logC = logn1;
     p.src = (const elt_t*)scratch;
     p.dst = (elt_t*)d_A;
@@ -293,8 +327,8 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     p.kfast_src = 1;
     p.kfast_dst = 0;
     size_t lds = ((size_t)16 << p.logT) << p.logC;
-    hipLaunchKernelGGL(fp_fft_tile, dim3((u32)(n1 >> p.logC), (u32)rows), dim3(FFT_THREADS), lds, c->stream, p,
-                       (const elt_t*)dW, logTw - logn2, (const elt_t*)nullptr, (const elt_t*)nullptr);
+    launch_fp(c, dim3((u32)(n1 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn2, (const elt_t*)nullptr,
+              (const elt_t*)nullptr);
     LF_HIP(c, hipGetLastError());
   }
   return LFGPU_OK;
@@ -354,13 +388,13 @@ extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx* c, int k, int dir, size_t rows,
   LF_HIP(c, hipSetDevice(c->device));
   LF_TRY(set_lds_limit(c));
   const int inverse = dir ? 1 : 0;
-  if (l <= 13) {
+  if (l <= (unsigned)g_tile_log) {
     TilePlan p = plan_single(d_B, rows, l, ld);
     LchTables t{};
     LF_TRY(lch_tables(c, g, 0, l, coset, true, 1, &t));
     u32 ntiles = (u32)((rows + (1u << p.logC) - 1) >> p.logC);
     size_t lds = ((size_t)16 << p.logT) << p.logC;
-    hipLaunchKernelGGL(lch_fft_tile, dim3(ntiles, 1), dim3(FFT_THREADS), lds, c->stream, p, inverse, t);
+    launch_lch(c, dim3(ntiles, 1), lds, p, inverse, t);
     LF_HIP(c, hipGetLastError());
     return LFGPU_OK;
   }
@@ -370,7 +404,7 @@ extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx* c, int k, int dir, size_t rows,
   LchTables ta{}, tb{};
   // pass A: stages i >= lo over k1 (stride n2); twiddle index u = k1 >> (ii+1): no block term
   pa.logT = logn1;
-  pa.logC = 13 - logn1;
+  pa.logC = (u32)g_tile_log - logn1;
   if (pa.logC > lo) pa.logC = lo;
   pa.src = (const elt_t*)d_B;
   pa.dst = (elt_t*)d_B;
@@ -383,7 +417,7 @@ extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx* c, int k, int dir, size_t rows,
   LF_TRY(lch_tables(c, g, lo, logn1, coset, true, 1, &ta));
   // pass B: stages i < lo on contiguous blocks k1; C consecutive blocks per tile
   pb.logT = lo;
-  pb.logC = 13 - lo;
+  pb.logC = (u32)g_tile_log - lo;
   if (pb.logC > logn1) pb.logC = logn1;
   pb.src = (const elt_t*)d_B;
   pb.dst = (elt_t*)d_B;
@@ -397,11 +431,11 @@ extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx* c, int k, int dir, size_t rows,
   size_t lds_a = ((size_t)16 << pa.logT) << pa.logC, lds_b = ((size_t)16 << pb.logT) << pb.logC;
   dim3 ga((u32)(n2 >> pa.logC), (u32)rows), gb((u32)(n1 >> pb.logC), (u32)rows);
   if (!inverse) {  // FFT: stages l-1 .. 0
-    hipLaunchKernelGGL(lch_fft_tile, ga, dim3(FFT_THREADS), lds_a, c->stream, pa, 0, ta);
-    hipLaunchKernelGGL(lch_fft_tile, gb, dim3(FFT_THREADS), lds_b, c->stream, pb, 0, tb);
+    launch_lch(c, ga, lds_a, pa, 0, ta);
+    launch_lch(c, gb, lds_b, pb, 0, tb);
   } else {  // IFFT: stages 0 .. l-1
-    hipLaunchKernelGGL(lch_fft_tile, gb, dim3(FFT_THREADS), lds_b, c->stream, pb, 1, tb);
-    hipLaunchKernelGGL(lch_fft_tile, ga, dim3(FFT_THREADS), lds_a, c->stream, pa, 1, ta);
+    launch_lch(c, gb, lds_b, pb, 1, tb);
+    launch_lch(c, ga, lds_a, pa, 1, ta);
   }
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
