@@ -13,6 +13,8 @@
 
 #include "ctx.h"
 
+int lf_lch14_fft_bitsliced(lfgpu_ctx* c, int k, int inverse, size_t rows, unsigned l, u64 coset, void* d_B, size_t ld);
+
 #define TILE_ELTS 8192u  // largest tile (128 KiB)
 // Tile geometry: 2^13 elements / 1024 threads (one workgroup per CU) or 2^12 elements / 512 threads
 // (two workgroups per CU, so one workgroup's HBM phase overlaps the other's butterfly phase).
@@ -388,6 +390,14 @@ extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx* c, int k, int dir, size_t rows,
   LF_HIP(c, hipSetDevice(c->device));
   LF_TRY(set_lds_limit(c));
   const int inverse = dir ? 1 : 0;
+  {  // batches of >= 32 rows take the bit-sliced tower path (lch_bs.hip); LFGPU_LCH_BS=0 disables it
+    static int bs = -1;
+    if (bs < 0) {
+      const char* e = getenv("LFGPU_LCH_BS");
+      bs = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (bs && rows >= 32 && l >= 7) return lf_lch14_fft_bitsliced(c, k, inverse, rows, l, coset, d_B, ld);
+  }
   if (l <= (unsigned)g_tile_log) {
     TilePlan p = plan_single(d_B, rows, l, ld);
     LchTables t{};

@@ -1,0 +1,316 @@
+// lch_bs.hip -- K2, bit-sliced: batched LCH14 additive FFT over GF(2^128) for >= 32 rows.
+//
+// Reference semantics: LCH14<GF2_128<k>>::FFT / IFFT (lib/gf2k/lch14.h:106-144), bit-exact.
+// Why a second implementation: the per-lane kernel (fft.hip) pays ~510 VALU ops per twiddle
+// product because CDNA4 has no carry-less multiply.  Here 32 batch rows share one 32-bit word per
+// coordinate bit of the tower basis (bitslice.h), all rows of a column pair share the twiddle, and a
+// twiddle product is ~m/2 conditional plane XORs: ~45 (k=4) / ~85 (k=5) ops per butterfly.
+//
+// Pipeline (all device-resident, "internal" = bit-sliced tower units of m words):
+//   bs_cin   : rows (reference Elt layout) -> transpose 32x32 bits -> poly->tower basis -> units
+//   bs_bfly  : one launch per group of <= 4 index bits; tile = 32 (row-group, coordinate) combos x
+//              16 columns in LDS, lanes run over combos so a wave shares its twiddle (scalar branches)
+//   bs_cout  : units -> tower->poly basis -> transpose -> rows
+// Internal buffer: unit index ((rg*D + q)*n + c), m words each; 128-byte (k=5) / 64-byte (k=4)
+// contiguous chunks in every pass.
+#include <string>
+
+#include "bitslice.h"
+#include "ctx.h"
+
+#define BS_COLS 128     // columns per conversion tile
+#define BS_R_LOG 5      // combos per butterfly tile (32)
+#define BS_NB_MAX 4     // index bits per butterfly pass
+#define BS_PS(units) ((units) + 1)  // LDS plane stride (words): +1 keeps the 8x4-byte scatter of a 128-byte chunk on distinct banks
+
+// ------------------------------------------------------------------ conversion in
+template <int K>
+__global__ __launch_bounds__(512) void bs_cin_kernel(const elt_t* __restrict__ src, size_t ld, u32 rows, u32 n,
+                                                     u32* __restrict__ dst) {
+  constexpr int M = Tower<K>::M, D = Tower<K>::D;
+  extern __shared__ u32 lds[];  // 128 x 128 words
+  const u32 t = threadIdx.x, rg = blockIdx.y, c0 = blockIdx.x * BS_COLS;
+  {  // phase 1: coalesced row reads (16 B per lane, 2 KiB contiguous per row)
+    const u32 lc = t & 127, rq = t >> 7;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const u32 r = rq * 8 + i, row = rg * 32 + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < rows) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c0 + lc);
+      *reinterpret_cast<uint4*>(&lds[(r * 128 + lc) * 4]) = v;
+    }
+  }
+  __syncthreads();
+  {  // phase 2: per (column, dword) 32x32 bit transpose
+    const u32 lc = t >> 2, w = t & 3;
+    u32 x[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = lds[(r * 128 + lc) * 4 + w];
+    __syncthreads();
+    bs_transpose32(x);
+#pragma unroll
+    for (int b = 0; b < 32; ++b) lds[(w * 32 + b) * 128 + lc] = x[b];
+  }
+  __syncthreads();
+  {  // phase 3: polynomial basis -> tower basis, one coordinate per thread (wave-uniform q)
+    const u32 lc = t & 127, q0 = t >> 7;
+#define BS_IN(i) lds[(i) * 128 + lc]
+#define BS_OUT(o) out[o]
+    for (u32 q = q0; q < (u32)D; q += 4) {
+      u32 out[M];
+      if (K == 5) {
+        switch (q) {
+          case 0: TOWER_K5_P2T_Q0(BS_IN, BS_OUT); break;
+          case 1: TOWER_K5_P2T_Q1(BS_IN, BS_OUT); break;
+          case 2: TOWER_K5_P2T_Q2(BS_IN, BS_OUT); break;
+          default: TOWER_K5_P2T_Q3(BS_IN, BS_OUT); break;
+        }
+      } else {
+        switch (q) {
+          case 0: TOWER_K4_P2T_Q0(BS_IN, BS_OUT); break;
+          case 1: TOWER_K4_P2T_Q1(BS_IN, BS_OUT); break;
+          case 2: TOWER_K4_P2T_Q2(BS_IN, BS_OUT); break;
+          case 3: TOWER_K4_P2T_Q3(BS_IN, BS_OUT); break;
+          case 4: TOWER_K4_P2T_Q4(BS_IN, BS_OUT); break;
+          case 5: TOWER_K4_P2T_Q5(BS_IN, BS_OUT); break;
+          case 6: TOWER_K4_P2T_Q6(BS_IN, BS_OUT); break;
+          default: TOWER_K4_P2T_Q7(BS_IN, BS_OUT); break;
+        }
+      }
+      uint4* u = reinterpret_cast<uint4*>(dst + ((size_t)(rg * D + q) * n + c0 + lc) * M);
+#pragma unroll
+      for (int j = 0; j < M / 4; ++j) u[j] = make_uint4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
+    }
+#undef BS_IN
+#undef BS_OUT
+  }
+}
+
+// ------------------------------------------------------------------ conversion out
+template <int K>
+__global__ __launch_bounds__(512) void bs_cout_kernel(const u32* __restrict__ src, size_t ld, u32 rows, u32 n,
+                                                      elt_t* __restrict__ dst) {
+  constexpr int M = Tower<K>::M, D = Tower<K>::D;
+  extern __shared__ u32 lds[];
+  const u32 t = threadIdx.x, rg = blockIdx.y, c0 = blockIdx.x * BS_COLS;
+  {  // units -> tower planes [p][lc]
+    const u32 lc = t & 127, q0 = t >> 7;
+    for (u32 q = q0; q < (u32)D; q += 4) {
+      const uint4* u = reinterpret_cast<const uint4*>(src + ((size_t)(rg * D + q) * n + c0 + lc) * M);
+#pragma unroll
+      for (int j = 0; j < M / 4; ++j) {
+        uint4 v = u[j];
+        lds[(q * M + 4 * j + 0) * 128 + lc] = v.x;
+        lds[(q * M + 4 * j + 1) * 128 + lc] = v.y;
+        lds[(q * M + 4 * j + 2) * 128 + lc] = v.z;
+        lds[(q * M + 4 * j + 3) * 128 + lc] = v.w;
+      }
+    }
+  }
+  __syncthreads();
+  {  // tower -> poly for one dword of the element, then 32x32 transpose back to rows
+    const u32 lc = t & 127, w = t >> 7;
+    u32 x[32];
+#define BS_IN(i) lds[(i) * 128 + lc]
+#define BS_OUT(o) x[o]
+    if (K == 5) {
+      switch (w) {
+        case 0: TOWER_K5_T2P_W0(BS_IN, BS_OUT); break;
+        case 1: TOWER_K5_T2P_W1(BS_IN, BS_OUT); break;
+        case 2: TOWER_K5_T2P_W2(BS_IN, BS_OUT); break;
+        default: TOWER_K5_T2P_W3(BS_IN, BS_OUT); break;
+      }
+    } else {
+      switch (w) {
+        case 0: TOWER_K4_T2P_W0(BS_IN, BS_OUT); break;
+        case 1: TOWER_K4_T2P_W1(BS_IN, BS_OUT); break;
+        case 2: TOWER_K4_T2P_W2(BS_IN, BS_OUT); break;
+        default: TOWER_K4_T2P_W3(BS_IN, BS_OUT); break;
+      }
+    }
+#undef BS_IN
+#undef BS_OUT
+    __syncthreads();
+    bs_transpose32(x);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) lds[(r * 128 + lc) * 4 + w] = x[r];
+  }
+  __syncthreads();
+  {
+    const u32 lc = t & 127, rq = t >> 7;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const u32 r = rq * 8 + i, row = rg * 32 + r;
+      if (row < rows) *reinterpret_cast<uint4*>(dst + (size_t)row * ld + c0 + lc) = *reinterpret_cast<const uint4*>(&lds[(r * 128 + lc) * 4]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ butterflies
+struct BflyArgs {
+  u32* data;
+  const u32* tw;      // stage tables, coset folded in: tw[off[b] + u_glob]
+  u32 off[BS_NB_MAX];
+  u32 n;              // columns per combo (2^l)
+  u32 lo_bit, nb;     // this pass covers index bits [lo_bit, lo_bit + nb)
+  int inverse;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void bs_bfly_kernel(BflyArgs a) {
+  constexpr int M = Tower<K>::M;
+  constexpr u32 MU = Tower<K>::MU_LOW;
+  constexpr u32 R = 1u << BS_R_LOG;
+  extern __shared__ u32 lds[];
+  const u32 tid = threadIdx.x;
+  const u32 ncol = 1u << a.nb, units = R << a.nb, PS = BS_PS(units);
+  const u32 tc = blockIdx.x, cb0 = blockIdx.y << BS_R_LOG;
+  const u32 tc_lo = tc & ((1u << a.lo_bit) - 1), tc_hi = tc >> a.lo_bit;
+  const u32 cbase = (tc_hi << (a.lo_bit + a.nb)) | tc_lo;
+  constexpr u32 PIECES = M / 4;  // 16-byte pieces per unit
+  // load: unit s = j*R + cl  <->  global ((cb0+cl)*n + cbase + (j << lo_bit)) * M words
+  for (u32 e = tid; e < units * PIECES; e += 256) {
+    const u32 s = e / PIECES, p4 = e % PIECES;
+    const u32 j = s >> BS_R_LOG, cl = s & (R - 1);
+    const uint4 v = *reinterpret_cast<const uint4*>(a.data + ((size_t)(cb0 + cl) * a.n + cbase + ((size_t)j << a.lo_bit)) * M + 4 * p4);
+    lds[(4 * p4 + 0) * PS + s] = v.x;
+    lds[(4 * p4 + 1) * PS + s] = v.y;
+    lds[(4 * p4 + 2) * PS + s] = v.z;
+    lds[(4 * p4 + 3) * PS + s] = v.w;
+  }
+  __syncthreads();
+  const u32 ntask = R << (a.nb - 1);
+  for (u32 step = 0; step < a.nb; ++step) {
+    const u32 b = a.inverse ? step : (a.nb - 1 - step);
+    if (tid < ntask) {
+      const u32 cl = tid & (R - 1), pv = tid >> BS_R_LOG;
+      const u32 v = pv & ((1u << b) - 1), u = pv >> b;
+      const u32 j0 = (u << (b + 1)) | v, j1 = j0 + (1u << b);
+      const u32 s0 = (j0 << BS_R_LOG) + cl, s1 = (j1 << BS_R_LOG) + cl;
+      // global twiddle index: (column >> (i+1)), i = lo_bit + b
+      const u32 ug = (tc_hi << (a.nb - 1 - b)) | u;
+      u32 tw = a.tw[a.off[b] + ug];
+      u32 b0[M], b1[M];
+#pragma unroll
+      for (int p = 0; p < M; ++p) {
+        b0[p] = lds[p * PS + s0];
+        b1[p] = lds[p * PS + s1];
+      }
+      const bool uniform = (R << b) >= 64;  // every lane of the wave shares u
+      if (!a.inverse) {  // b0 ^= tw*b1; b1 ^= b0   (lch14.h:219-223)
+        if (uniform) bs_mac_uniform<M, MU>(__builtin_amdgcn_readfirstlane(tw), b1, b0);
+        else bs_mac_lane<M, MU>(tw, b1, b0);
+#pragma unroll
+        for (int p = 0; p < M; ++p) b1[p] ^= b0[p];
+      } else {  // b1 ^= b0; b0 ^= tw*b1   (lch14.h:225-229)
+#pragma unroll
+        for (int p = 0; p < M; ++p) b1[p] ^= b0[p];
+        if (uniform) bs_mac_uniform<M, MU>(__builtin_amdgcn_readfirstlane(tw), b1, b0);
+        else bs_mac_lane<M, MU>(tw, b1, b0);
+      }
+#pragma unroll
+      for (int p = 0; p < M; ++p) {
+        lds[p * PS + s0] = b0[p];
+        lds[p * PS + s1] = b1[p];
+      }
+    }
+    __syncthreads();
+  }
+  for (u32 e = tid; e < units * PIECES; e += 256) {
+    const u32 s = e / PIECES, p4 = e % PIECES;
+    const u32 j = s >> BS_R_LOG, cl = s & (R - 1);
+    uint4 v;
+    v.x = lds[(4 * p4 + 0) * PS + s];
+    v.y = lds[(4 * p4 + 1) * PS + s];
+    v.z = lds[(4 * p4 + 2) * PS + s];
+    v.w = lds[(4 * p4 + 3) * PS + s];
+    *reinterpret_cast<uint4*>(a.data + ((size_t)(cb0 + cl) * a.n + cbase + ((size_t)j << a.lo_bit)) * M + 4 * p4) = v;
+  }
+}
+
+// ------------------------------------------------------------------ host
+template <int K>
+static int bs_tables(lfgpu_ctx* c, const GfHostCtx* g, unsigned l, u64 coset, const u32** d_tw, std::vector<u32>* offs) {
+  // tw_i[u] = tower bits of twiddle(i, coset ^ (u << (i+1))), i = 0..l-1; linear in the bits of the argument
+  char kb[96];
+  snprintf(kb, sizeof(kb), "bstw:%d:%u:%llx", K, l, (u64)coset);
+  std::string key(kb);
+  offs->assign(l, 0);
+  u32 off = 0;
+  for (unsigned i = 0; i < l; ++i) {
+    (*offs)[i] = off;
+    off += 1u << (l - 1 - i);
+  }
+  void* d = nullptr;
+  if (!lf_table_lookup(c, key, &d)) {
+    std::vector<u32> tbl(off ? off : 1);
+    for (unsigned i = 0; i < l; ++i) {
+      elt_t t0 = h_lch14_twiddle(g, i, coset);
+      u32* t = &tbl[(*offs)[i]];
+      t[0] = tower_twiddle_bits<K>(t0.lo, t0.hi);
+      for (unsigned kk = 0; (i + 1) + kk < l; ++kk) {
+        elt_t sh = g->w_hat[i][(i + 1) + kk];
+        u32 sb = tower_twiddle_bits<K>(sh.lo, sh.hi);
+        for (u32 u = 0; u < (1u << kk); ++u) t[u + (1u << kk)] = t[u] ^ sb;
+      }
+    }
+    LF_TRY(lf_table(c, key, tbl.data(), tbl.size() * 4, &d));
+  }
+  *d_tw = (const u32*)d;
+  return LFGPU_OK;
+}
+
+template <int K>
+static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows, unsigned l, u64 coset, void* d_B, size_t ld) {
+  constexpr int M = Tower<K>::M, D = Tower<K>::D;
+  constexpr u32 R = 1u << BS_R_LOG;
+  const u32 n = 1u << l;
+  const u32 nrg = (u32)((rows + 31) / 32);
+  const u32 combos = ((nrg * D + R - 1) / R) * R;  // padded to whole butterfly tiles
+  void* internal = nullptr;
+  LF_TRY(lf_scratch(c, (size_t)combos * n * M * 4, &internal));
+  const u32* d_tw = nullptr;
+  std::vector<u32> offs;
+  LF_TRY(bs_tables<K>(c, g, l, coset, &d_tw, &offs));
+  static bool attr = false;
+  if (!attr) {
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_cin_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_cin_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_cout_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_cout_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr = true;
+  }
+  if (combos > nrg * D)  // padded combos: define the bits (values are never read back)
+    LF_HIP(c, hipMemsetAsync((u32*)internal + (size_t)nrg * D * n * M, 0, (size_t)(combos - nrg * D) * n * M * 4, c->stream));
+  hipLaunchKernelGGL(bs_cin_kernel<K>, dim3(n / BS_COLS, nrg), dim3(512), 65536, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
+                     (u32*)internal);
+  // bit groups of <= BS_NB_MAX index bits; FFT walks stages l-1..0, IFFT 0..l-1
+  std::vector<std::pair<u32, u32>> groups;  // (lo_bit, nb), ascending
+  for (u32 lo = 0; lo < l; lo += BS_NB_MAX) groups.push_back({lo, std::min<u32>(BS_NB_MAX, l - lo)});
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    const auto& gr = inverse ? groups[gi] : groups[groups.size() - 1 - gi];
+    BflyArgs a{};
+    a.data = (u32*)internal;
+    a.tw = d_tw;
+    for (u32 b = 0; b < gr.second; ++b) a.off[b] = offs[gr.first + b];
+    a.n = n;
+    a.lo_bit = gr.first;
+    a.nb = gr.second;
+    a.inverse = inverse;
+    const u32 units = R << gr.second;
+    hipLaunchKernelGGL(bs_bfly_kernel<K>, dim3(n >> gr.second, combos / R), dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
+  }
+  hipLaunchKernelGGL(bs_cout_kernel<K>, dim3(n / BS_COLS, nrg), dim3(512), 65536, c->stream, (const u32*)internal, ld, (u32)rows, n,
+                     (elt_t*)d_B);
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
+// entry used by lfgpu_gf2128_lch14_fft (fft.hip) when the batch is large enough
+int lf_lch14_fft_bitsliced(lfgpu_ctx* c, int k, int inverse, size_t rows, unsigned l, u64 coset, void* d_B, size_t ld) {
+  const GfHostCtx* g = lf_gf_ctx(c, k);
+  if (!g) return LFGPU_ERR_ARG;
+  return k == 4 ? lch_bs_run<4>(c, g, inverse, rows, l, coset, d_B, ld) : lch_bs_run<5>(c, g, inverse, rows, l, coset, d_B, ld);
+}

@@ -21,3 +21,69 @@ void hf_sha_blocks(const unsigned char* p, unsigned nblk, u32* h) {
   for (int i = 0; i < 8; ++i) h[i] = s.h[i];
 }
 }
+
+// ---- bit-sliced tower arithmetic (csrc/bitslice.h), host compilation
+#include "../longfellow-zk_amd/csrc/bitslice.h"
+
+template <int K>
+static void bs_roundtrip_mul(const u64* t_poly, const u64* in, u64* out, int mode) {
+  constexpr int M = Tower<K>::M, D = Tower<K>::D;
+  constexpr u32 MU = Tower<K>::MU_LOW;
+  // rows -> poly planes
+  u32 P[128], T[128], R[128], Q[128];
+  for (int w = 0; w < 4; ++w) {
+    u32 x[32];
+    for (int r = 0; r < 32; ++r) x[r] = (u32)(in[2 * r + (w >> 1)] >> (32 * (w & 1)));
+    bs_transpose32(x);
+    for (int b = 0; b < 32; ++b) P[32 * w + b] = x[b];
+  }
+#define IN_(i) P[i]
+  if (K == 4) {
+#define O0(o) T[0 * 16 + o]
+#define O1(o) T[1 * 16 + o]
+#define O2(o) T[2 * 16 + o]
+#define O3(o) T[3 * 16 + o]
+#define O4(o) T[4 * 16 + o]
+#define O5(o) T[5 * 16 + o]
+#define O6(o) T[6 * 16 + o]
+#define O7(o) T[7 * 16 + o]
+    TOWER_K4_P2T_Q0(IN_, O0); TOWER_K4_P2T_Q1(IN_, O1); TOWER_K4_P2T_Q2(IN_, O2); TOWER_K4_P2T_Q3(IN_, O3);
+    TOWER_K4_P2T_Q4(IN_, O4); TOWER_K4_P2T_Q5(IN_, O5); TOWER_K4_P2T_Q6(IN_, O6); TOWER_K4_P2T_Q7(IN_, O7);
+  } else {
+#define U0(o) T[0 * 32 + o]
+#define U1(o) T[1 * 32 + o]
+#define U2(o) T[2 * 32 + o]
+#define U3(o) T[3 * 32 + o]
+    TOWER_K5_P2T_Q0(IN_, U0); TOWER_K5_P2T_Q1(IN_, U1); TOWER_K5_P2T_Q2(IN_, U2); TOWER_K5_P2T_Q3(IN_, U3);
+  }
+  u32 t = tower_twiddle_bits<K>(t_poly[0], t_poly[1]);
+  for (int q = 0; q < D; ++q) {
+    u32 b[M], dst[M];
+    for (int j = 0; j < M; ++j) { b[j] = T[q * M + j]; dst[j] = 0; }
+    if (mode == 0) bs_mac_uniform<M, MU>(t, b, dst); else bs_mac_lane<M, MU>(t, b, dst);
+    for (int j = 0; j < M; ++j) R[q * M + j] = dst[j];
+  }
+#define RIN(i) R[i]
+#define Q0(o) Q[0 + o]
+#define Q1(o) Q[32 + o]
+#define Q2(o) Q[64 + o]
+#define Q3(o) Q[96 + o]
+  if (K == 4) { TOWER_K4_T2P_W0(RIN, Q0); TOWER_K4_T2P_W1(RIN, Q1); TOWER_K4_T2P_W2(RIN, Q2); TOWER_K4_T2P_W3(RIN, Q3); }
+  else { TOWER_K5_T2P_W0(RIN, Q0); TOWER_K5_T2P_W1(RIN, Q1); TOWER_K5_T2P_W2(RIN, Q2); TOWER_K5_T2P_W3(RIN, Q3); }
+  for (int r = 0; r < 64; ++r) out[r] = 0;
+  for (int w = 0; w < 4; ++w) {
+    u32 x[32];
+    for (int b = 0; b < 32; ++b) x[b] = Q[32 * w + b];
+    bs_transpose32(x);
+    for (int r = 0; r < 32; ++r) out[2 * r + (w >> 1)] |= (u64)x[r] << (32 * (w & 1));
+  }
+}
+extern "C" void hf_bs_mul(int k, const u64* t_poly, const u64* in, u64* out, int mode) {
+  if (k == 4) bs_roundtrip_mul<4>(t_poly, in, out, mode); else bs_roundtrip_mul<5>(t_poly, in, out, mode);
+}
+extern "C" void hf_transpose32(u32* x) {
+  u32 y[32];
+  for (int i = 0; i < 32; ++i) y[i] = x[i];
+  bs_transpose32(y);
+  for (int i = 0; i < 32; ++i) x[i] = y[i];
+}

@@ -77,3 +77,35 @@ def test_sha_compress_matches_hashlib():
         L.hf_sha_blocks(P(buf), nblk, P(h))
         got = b"".join(int(x).to_bytes(4, "big") for x in h)
         assert got == hashlib.sha256(msg).digest()
+
+
+def test_bitslice_transpose():
+    L = _lib()
+    rng = np.random.default_rng(8)
+    x = rng.integers(0, 2**32, size=32, dtype=np.uint32)
+    y = x.copy()
+    L.hf_transpose32(P(y))
+    for r in range(32):
+        for b in range(32):
+            assert (int(y[b]) >> r) & 1 == (int(x[r]) >> b) & 1
+
+
+@pytest.mark.parametrize("k", [4, 5])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_bitsliced_tower_multiply_matches_gf_mul(k, mode):
+    """rows -> bit-sliced tower basis -> multiply by a subfield twiddle -> back == gf_mul per row
+    (pins tools/gen_tower.py's basis/programs and csrc/bitslice.h on the CPU)"""
+    import ctypes as C
+    L, o = _lib(), ol.oracle()
+    c = ol.gf_ctx(k)
+    rng = np.random.default_rng(9 + k)
+    for trial in range(6):
+        x = ol.rand_elts(rng, 32)
+        if trial == 0:
+            t = np.array([1, 0], dtype=np.uint64)
+        else:
+            t = arr(o.lfo_lch14_twiddle(C.byref(c), int(rng.integers(0, 1 << k)), int(rng.integers(0, 2**((1 << k) - 1)))))
+        out = np.zeros((32, 2), dtype=np.uint64)
+        L.hf_bs_mul(k, P(t), P(x), P(out), mode)
+        for r in range(32):
+            assert (out[r] == arr(o.lfo_gf_mul(elt(t), elt(x[r])))).all(), (trial, r)

@@ -114,6 +114,42 @@ def test_lch14_fft(G, k, l, coset, rows, inverse):
     assert (G.from_dev(d, np.uint64, a.shape) == want).all()
 
 
+@pytest.mark.parametrize("k,l,coset,rows", [(4, 7, 0, 32), (4, 7, 128, 40), (4, 8, 0, 64), (4, 10, 3 << 10, 150), (4, 11, 0, 33),
+                                            (4, 13, 1 << 13, 32), (5, 14, 0, 64), (5, 9, 7 << 9, 96)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_lch14_fft_bitsliced_batches(G, k, l, coset, rows, inverse):
+    """>= 32 rows take the bit-sliced tower path (lch_bs.hip), incl. ragged row groups"""
+    o = ol.oracle()
+    c = ol.gf_ctx(k)
+    rng = np.random.default_rng(l * 13 + k + rows)
+    ld = (1 << l) + 5
+    a = ol.rand_elts(rng, rows * ld).reshape(rows, ld, 2)
+    want = a.copy()
+    for r in range(rows):
+        (o.lfo_lch14_ifft if inverse else o.lfo_lch14_fft)(C.byref(c), l, coset, P(want[r]))
+    d = G.to_dev(a)
+    G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, coset=coset, ld=ld, inverse=inverse, subfield_log_bits=k)
+    assert (G.from_dev(d, np.uint64, a.shape) == want).all()
+
+
+def test_lch14_fft_bitsliced_full_size_rows(G):
+    """l = 20 (GF2_128<5>), 32 rows: row 0 and row 31 against the oracle, then IFFT round trip"""
+    o = ol.oracle()
+    c = ol.gf_ctx(5)
+    rng = np.random.default_rng(2020)
+    rows, l = 32, 20
+    a = ol.rand_elts(rng, rows << l).reshape(rows, 1 << l, 2)
+    d = G.to_dev(a)
+    G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, subfield_log_bits=5)
+    got = G.from_dev(d, np.uint64, a.shape).copy()
+    for r in (0, 31):
+        w = a[r].copy()
+        o.lfo_lch14_fft(C.byref(c), l, 0, P(w))
+        assert (got[r] == w).all()
+    G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, inverse=True, subfield_log_bits=5)
+    assert (G.from_dev(d, np.uint64, a.shape) == a).all()
+
+
 def test_lch14_fft_roundtrip_full_size(G):
     """IFFT(FFT(x)) = x at l = 20 (GF2_128<5>), the BASELINE row length"""
     rng = np.random.default_rng(20)
