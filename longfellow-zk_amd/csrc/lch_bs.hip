@@ -19,8 +19,11 @@
 #include "ctx.h"
 
 #define BS_COLS 128     // columns per conversion tile
-#define BS_R_LOG 5      // combos per butterfly tile (32)
-#define BS_NB_MAX 4     // index bits per butterfly pass
+#define BS_NB_MAX 4     // index bits per butterfly pass (array bound)
+// Butterfly tile = 2^r_log (row-group, coordinate) combos x 2^nb columns = 512 units.  r_log 5 / nb 4
+// (one masked per-lane stage per pass) or r_log 6 / nb 3 (every stage wave-uniform, more passes):
+// LFGPU_BS_RLOG selects; see DESIGN.md.
+static u32 g_bs_rlog = 5;
 #define BS_PS(units) ((units) + 1)  // LDS plane stride (words): +1 keeps the 8x4-byte scatter of a 128-byte chunk on distinct banks
 
 // ------------------------------------------------------------------ conversion in
@@ -153,43 +156,69 @@ struct BflyArgs {
   u32 off[BS_NB_MAX];
   u32 n;              // columns per combo (2^l)
   u32 lo_bit, nb;     // this pass covers index bits [lo_bit, lo_bit + nb)
+  u32 r_log;          // log2(lanes per column pair) = log2(combos per tile) + cu
+  u32 cu;             // low column bits kept inside the tile (2^cu consecutive columns: 2^cu * 4m-byte segments)
   int inverse;
 };
 
-template <int K>
-__global__ __launch_bounds__(256) void bs_bfly_kernel(BflyArgs a) {
+template <int K, bool INV>
+__global__ __launch_bounds__(256, 2) void bs_bfly_kernel(BflyArgs a) {
   constexpr int M = Tower<K>::M;
   constexpr u32 MU = Tower<K>::MU_LOW;
-  constexpr u32 R = 1u << BS_R_LOG;
+  const u32 RL = a.r_log, R = 1u << RL;
   extern __shared__ u32 lds[];
   const u32 tid = threadIdx.x;
   const u32 ncol = 1u << a.nb, units = R << a.nb, PS = BS_PS(units);
-  const u32 tc = blockIdx.x, cb0 = blockIdx.y << BS_R_LOG;
-  const u32 tc_lo = tc & ((1u << a.lo_bit) - 1), tc_hi = tc >> a.lo_bit;
-  const u32 cbase = (tc_hi << (a.lo_bit + a.nb)) | tc_lo;
+  const u32 CU = a.cu, cumask = (1u << CU) - 1;
+  const u32 tc = blockIdx.x, cb0 = blockIdx.y << (RL - CU);
+  const u32 tc_lo = tc & ((1u << (a.lo_bit - CU)) - 1), tc_hi = tc >> (a.lo_bit - CU);
+  const u32 cbase = (tc_hi << (a.lo_bit + a.nb)) | (tc_lo << CU);
   constexpr u32 PIECES = M / 4;  // 16-byte pieces per unit
-  // load: unit s = j*R + cl  <->  global ((cb0+cl)*n + cbase + (j << lo_bit)) * M words
-  for (u32 e = tid; e < units * PIECES; e += 256) {
-    const u32 s = e / PIECES, p4 = e % PIECES;
-    const u32 j = s >> BS_R_LOG, cl = s & (R - 1);
-    const uint4 v = *reinterpret_cast<const uint4*>(a.data + ((size_t)(cb0 + cl) * a.n + cbase + ((size_t)j << a.lo_bit)) * M + 4 * p4);
-    lds[(4 * p4 + 0) * PS + s] = v.x;
-    lds[(4 * p4 + 1) * PS + s] = v.y;
-    lds[(4 * p4 + 2) * PS + s] = v.z;
-    lds[(4 * p4 + 3) * PS + s] = v.w;
+  // load: unit s = j*R + cl, cl = (combo offset << cu) | inner column.  All global loads of the thread are
+  // issued before the first LDS write (one exposed HBM latency per tile instead of one per piece).
+  constexpr u32 MAXIT = (512 * PIECES) / 256;
+  const u32 total = units * PIECES;
+  {
+    uint4 v[MAXIT];
+#pragma unroll
+    for (u32 it = 0; it < MAXIT; ++it) {
+      const u32 e = tid + it * 256;
+      const u32 s = e / PIECES, p4 = e % PIECES;
+      const u32 j = s >> RL, cl = s & (R - 1);
+      v[it] = make_uint4(0, 0, 0, 0);
+      if (e < total)
+        v[it] = *reinterpret_cast<const uint4*>(a.data + ((size_t)(cb0 + (cl >> CU)) * a.n + cbase + ((size_t)j << a.lo_bit) + (cl & cumask)) * M + 4 * p4);
+    }
+#pragma unroll
+    for (u32 it = 0; it < MAXIT; ++it) {
+      const u32 e = tid + it * 256;
+      const u32 s = e / PIECES, p4 = e % PIECES;
+      if (e < total) {
+        lds[(4 * p4 + 0) * PS + s] = v[it].x;
+        lds[(4 * p4 + 1) * PS + s] = v[it].y;
+        lds[(4 * p4 + 2) * PS + s] = v[it].z;
+        lds[(4 * p4 + 3) * PS + s] = v[it].w;
+      }
+    }
+  }
+  // this tile's twiddles for every stage of the pass (prefetched: one latency, not one per stage)
+  u32 twv[BS_NB_MAX];
+#pragma unroll
+  for (u32 b = 0; b < BS_NB_MAX; ++b) {
+    twv[b] = 0;
+    if (b < a.nb) twv[b] = a.tw[a.off[b] + ((tc_hi << (a.nb - 1 - b)) | ((tid >> RL) >> b))];
   }
   __syncthreads();
   const u32 ntask = R << (a.nb - 1);
   for (u32 step = 0; step < a.nb; ++step) {
-    const u32 b = a.inverse ? step : (a.nb - 1 - step);
+    const u32 b = INV ? step : (a.nb - 1 - step);
     if (tid < ntask) {
-      const u32 cl = tid & (R - 1), pv = tid >> BS_R_LOG;
+      const u32 cl = tid & (R - 1), pv = tid >> RL;
       const u32 v = pv & ((1u << b) - 1), u = pv >> b;
       const u32 j0 = (u << (b + 1)) | v, j1 = j0 + (1u << b);
-      const u32 s0 = (j0 << BS_R_LOG) + cl, s1 = (j1 << BS_R_LOG) + cl;
+      const u32 s0 = (j0 << RL) + cl, s1 = (j1 << RL) + cl;
       // global twiddle index: (column >> (i+1)), i = lo_bit + b
-      const u32 ug = (tc_hi << (a.nb - 1 - b)) | u;
-      u32 tw = a.tw[a.off[b] + ug];
+      const u32 tw = b == 0 ? twv[0] : b == 1 ? twv[1] : b == 2 ? twv[2] : twv[3];  // (column >> (i+1)) table entry, i = lo_bit + b
       u32 b0[M], b1[M];
 #pragma unroll
       for (int p = 0; p < M; ++p) {
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(256) void bs_bfly_kernel(BflyArgs a) {
         b1[p] = lds[p * PS + s1];
       }
       const bool uniform = (R << b) >= 64;  // every lane of the wave shares u
-      if (!a.inverse) {  // b0 ^= tw*b1; b1 ^= b0   (lch14.h:219-223)
+      if (!INV) {  // b0 ^= tw*b1; b1 ^= b0   (lch14.h:219-223)
         if (uniform) bs_mac_uniform<M, MU>(__builtin_amdgcn_readfirstlane(tw), b1, b0);
         else bs_mac_lane<M, MU>(tw, b1, b0);
 #pragma unroll
@@ -218,13 +247,13 @@ __global__ __launch_bounds__(256) void bs_bfly_kernel(BflyArgs a) {
   }
   for (u32 e = tid; e < units * PIECES; e += 256) {
     const u32 s = e / PIECES, p4 = e % PIECES;
-    const u32 j = s >> BS_R_LOG, cl = s & (R - 1);
+    const u32 j = s >> RL, cl = s & (R - 1);
     uint4 v;
     v.x = lds[(4 * p4 + 0) * PS + s];
     v.y = lds[(4 * p4 + 1) * PS + s];
     v.z = lds[(4 * p4 + 2) * PS + s];
     v.w = lds[(4 * p4 + 3) * PS + s];
-    *reinterpret_cast<uint4*>(a.data + ((size_t)(cb0 + cl) * a.n + cbase + ((size_t)j << a.lo_bit)) * M + 4 * p4) = v;
+    *reinterpret_cast<uint4*>(a.data + ((size_t)(cb0 + (cl >> CU)) * a.n + cbase + ((size_t)j << a.lo_bit) + (cl & cumask)) * M + 4 * p4) = v;
   }
 }
 
@@ -263,7 +292,17 @@ static int bs_tables(lfgpu_ctx* c, const GfHostCtx* g, unsigned l, u64 coset, co
 template <int K>
 static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows, unsigned l, u64 coset, void* d_B, size_t ld) {
   constexpr int M = Tower<K>::M, D = Tower<K>::D;
-  constexpr u32 R = 1u << BS_R_LOG;
+  static bool env = false;
+  if (!env) {
+    if (const char* e = getenv("LFGPU_BS_RLOG")) {
+      int v = atoi(e);
+      if (v >= 5 && v <= 7) g_bs_rlog = (u32)v;
+    }
+    env = true;
+  }
+  const u32 R = 1u << g_bs_rlog, nbmax = 9 - g_bs_rlog;
+  static u32 cu_env = 3;
+  if (const char* e = getenv("LFGPU_BS_CU")) cu_env = (u32)atoi(e) <= 5 ? (u32)atoi(e) : 3;
   const u32 n = 1u << l;
   const u32 nrg = (u32)((rows + 31) / 32);
   const u32 combos = ((nrg * D + R - 1) / R) * R;  // padded to whole butterfly tiles
@@ -278,8 +317,10 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_cin_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_cout_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_cout_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     attr = true;
   }
   if (combos > nrg * D)  // padded combos: define the bits (values are never read back)
@@ -288,7 +329,7 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
                      (u32*)internal);
   // bit groups of <= BS_NB_MAX index bits; FFT walks stages l-1..0, IFFT 0..l-1
   std::vector<std::pair<u32, u32>> groups;  // (lo_bit, nb), ascending
-  for (u32 lo = 0; lo < l; lo += BS_NB_MAX) groups.push_back({lo, std::min<u32>(BS_NB_MAX, l - lo)});
+  for (u32 lo = 0; lo < l; lo += nbmax) groups.push_back({lo, std::min<u32>(nbmax, l - lo)});
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const auto& gr = inverse ? groups[gi] : groups[groups.size() - 1 - gi];
     BflyArgs a{};
@@ -298,9 +339,14 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
     a.n = n;
     a.lo_bit = gr.first;
     a.nb = gr.second;
+    a.r_log = g_bs_rlog;
+    a.cu = std::min(std::min(cu_env, gr.first), g_bs_rlog);  // inner bits must lie below the stage bits
     a.inverse = inverse;
     const u32 units = R << gr.second;
-    hipLaunchKernelGGL(bs_bfly_kernel<K>, dim3(n >> gr.second, combos / R), dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
+    if (inverse)
+      hipLaunchKernelGGL((bs_bfly_kernel<K, true>), dim3(n >> (gr.second + a.cu), combos >> (g_bs_rlog - a.cu)), dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
+    else
+      hipLaunchKernelGGL((bs_bfly_kernel<K, false>), dim3(n >> (gr.second + a.cu), combos >> (g_bs_rlog - a.cu)), dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
   }
   hipLaunchKernelGGL(bs_cout_kernel<K>, dim3(n / BS_COLS, nrg), dim3(512), 65536, c->stream, (const u32*)internal, ld, (u32)rows, n,
                      (elt_t*)d_B);
