@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Runs oracle/_ref/gen_flatsha (the REAL reference's circuit builder, witness generator and
+sumcheck prover) and stores xz-compressed fixtures under tests/golden/:
+  flatsha_nb<N>.lfc1.xz  circuit in the reference's LFC1 wire format (CircuitWriter output)
+  flatsha_nb<N>.w.xz     witness, ninputs x 16-byte GF2_128 elements
+  flatsha_nb<N>.scproof  transmitted sumcheck evaluations of run_prover (transcript "testing")
+  flatsha_nb<N>.json     sizes + the reference's single-thread timings in this container
+Build container only (needs /root/reference)."""
+import json
+import lzma
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "oracle", "_ref", "gen_flatsha")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    blocks = [int(a) for a in sys.argv[1:]] or [1, 32]
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/gen_flatsha"])
+    for nb in blocks:
+        with tempfile.TemporaryDirectory() as td:
+            pre = os.path.join(td, "x")
+            info = json.loads(subprocess.check_output([GEN, str(nb), pre]).decode())
+            for ext, comp in ((".lfc1", True), (".w", True), (".scproof", False)):
+                data = open(pre + ext, "rb").read()
+                dst = os.path.join(OUT, "flatsha_nb%d%s" % (nb, ext + (".xz" if comp else "")))
+                with open(dst, "wb") as f:
+                    f.write(lzma.compress(data, preset=9 | lzma.PRESET_EXTREME) if comp else data)
+                print(dst, os.path.getsize(dst))
+            with open(os.path.join(OUT, "flatsha_nb%d.json" % nb), "w") as f:
+                json.dump(info, f)
+            print(info)
+
+
+if __name__ == "__main__":
+    main()
