@@ -142,6 +142,56 @@ __global__ __launch_bounds__(QD_THREADS) void bindg_emit_kernel(size_t n, const 
   st16(&vc_out[off], acc);
 }
 
+// GF2_128 variant without serial runs: a hand pair shared by very many gates (constant wires: the
+// 32-block flatsha256 layers hold runs of > 10^5 terms) would otherwise be summed by ONE lane.  Every
+// term computes its own product, a wave folds equal-run neighbours with shuffles (runs are contiguous
+// in canonical order), and the last lane of each run fragment issues one pair of 64-bit atomic XORs --
+// exact and order-independent because addition in GF(2^128) is XOR.  d_vc_out must be zeroed first.
+__global__ __launch_bounds__(QD_THREADS) void bindg_emit_gf_kernel(size_t n, const corner4* __restrict__ t,
+                                                                   const elt_t* __restrict__ kvec,
+                                                                   const elt_t* __restrict__ eq, elt_t beta,
+                                                                   const u32* __restrict__ block_off,
+                                                                   uint2* __restrict__ hc_out, u64* __restrict__ vc_out) {
+  __shared__ u32 wave_off[QD_THREADS / 64];
+  const size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x;
+  const bool valid = i < n;
+  const bool head = valid && is_head(t, i);
+  const u64 mask = __ballot(head);
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_off[wave] = (u32)__popcll(mask);
+  __syncthreads();
+  u32 ri = block_off[blockIdx.x];
+  for (u32 w = 0; w < wave; ++w) ri += wave_off[w];
+  ri += (u32)__popcll(mask & ((2ull << lane) - 1));  // inclusive count of heads up to this lane
+  ri -= 1;                                            // run index (a run continuing from an earlier block/wave keeps its index)
+  elt_t pv = elt_zero();
+  corner4 c0{0, 0, 0, 0};
+  if (valid) {
+    c0 = t[i];
+    elt_t v = ld16(&kvec[c0.vi]);
+    if ((v.lo | v.hi) == 0) v = beta;
+    pv = gf_mul(v, ld16(&eq[c0.g]));
+  }
+  if (head) hc_out[ri] = make_uint2(c0.h0, c0.h1);
+  // segmented suffix fold inside the wave: lane keeps the XOR of its run's terms at lanes >= itself
+  const u32 key = valid ? ri : 0xffffffffu;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const u64 olo = __shfl_down(pv.lo, off, 64), ohi = __shfl_down(pv.hi, off, 64);
+    const u32 okey = __shfl_down(key, off, 64);
+    if (lane + off < 64 && okey == key) {
+      pv.lo ^= olo;
+      pv.hi ^= ohi;
+    }
+  }
+  // the first lane of each run fragment in the wave now holds the fragment's sum
+  const u32 pkey = __shfl_up(key, 1, 64);
+  if (valid && (lane == 0 || pkey != key)) {
+    atomicXor(&vc_out[2 * (size_t)ri], pv.lo);
+    atomicXor(&vc_out[2 * (size_t)ri + 1], pv.hi);
+  }
+}
+
 #define QD_DISPATCH(field, KERNEL, grid, block, ...)                                    \
   do {                                                                                  \
     if ((field) == LFGPU_FIELD_GF2_128)                                                 \
@@ -253,8 +303,15 @@ extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, c
               (u32)q->nv, (const elt_t*)d_G, al, one, d_eq);
   hipLaunchKernelGGL(bindg_count_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton, counts);
   hipLaunchKernelGGL(bindg_scan_kernel, dim3(1), dim3(1024), 0, c->stream, nb, counts, total);
-  QD_DISPATCH(field, bindg_emit_kernel, dim3(nb), dim3(QD_THREADS), n, (const corner4*)q->d_morton,
-              (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)counts, (uint2*)d_hc_out, (elt_t*)d_vc_out);
+  if (field == LFGPU_FIELD_GF2_128) {
+    LF_HIP(c, hipMemsetAsync(d_vc_out, 0, n * 16, c->stream));  // upper bound on the HQuad size
+    hipLaunchKernelGGL(bindg_emit_gf_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
+                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)counts, (uint2*)d_hc_out, (u64*)d_vc_out);
+  } else {
+    // Fp128 has no 128-bit atomic add: each run head sums its run (long runs serialise)
+    hipLaunchKernelGGL(bindg_emit_kernel<FIELD_FP128>, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
+                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)counts, (uint2*)d_hc_out, (elt_t*)d_vc_out);
+  }
   LF_HIP(c, hipGetLastError());
   LF_HIP(c, hipMemcpyAsync(c->mailbox_h, total, 4, hipMemcpyDeviceToHost, c->stream));
   LF_HIP(c, hipStreamSynchronize(c->stream));

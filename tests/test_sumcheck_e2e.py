@@ -14,6 +14,8 @@ def test_aes256_fips197_kat():
     key = bytes(range(32))
     pt = bytes.fromhex("00112233445566778899aabbccddeeff")
     assert AES256(key).encrypt_block(pt).hex() == "8ea2b7ca516745bfeafc49904b496089"
+    from fs_transcript import make_aes256
+    assert make_aes256(key).encrypt_block(pt).hex() == "8ea2b7ca516745bfeafc49904b496089"  # libcrypto path when loadable
 
 
 def test_lfc1_reader_matches_reference_sizes():
