@@ -144,6 +144,22 @@ int lfgpu_eval_quad(lfgpu_quad* q, size_t nw, const void* d_W, void* d_V, int* o
 int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
                       const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out);
 
+/* ---- one whole sumcheck layer with the transcript behind a callback -------------------
+ * Replaces the body of ProverLayers::layer for logc = 0 (every ZK use, lib/zk/zk_common.h:72) together
+ * with the bind_g that precedes it (lib/sumcheck/prover_layers.h:140-146,185-271): HQUAD = bind_g(...),
+ * then for round < logw, hand in {0,1}: QW scatter, evaluations() -> the 3 evaluations of the round
+ * polynomial at poly_evaluation_point(0..2), `round` callback (the caller's round_h: subtract pad, store in
+ * the proof, ts.round(poly) -> challenge), bind W[hand] and HQUAD.  The Fiat-Shamir transcript never
+ * leaves the caller.  d_W: the layer's nw input wires (device; consumed).  wc_in: the two claims of the
+ * previous layer; outputs: wc_out = W[R,C], W[L,C]; g_out[hand][round] = the challenges (next layer's
+ * G0/G1); bound_quad = HQUAD->scalar() (ProofAux::bound_quad). */
+typedef void (*lfgpu_sc_round_fn)(void* user, size_t hand, size_t round, const uint64_t evals[3][2],
+                                  uint64_t challenge_out[2]);
+int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                         const uint64_t beta[2], size_t logw, size_t nw, void* d_W, const uint64_t wc_in[2][2],
+                         lfgpu_sc_round_fn round, void* user, uint64_t wc_out[2][2], uint64_t* g_out /*[2][logw][2]*/,
+                         uint64_t bound_quad[2]);
+
 /* ---- element-wise field ops (Field::addf / subf / mulf, lib/gf2k/gf2_128.h:227-237,
  * lib/algebra/fp_generic.h:203-214): out[i] = a[i] op b[i], op 0 add, 1 sub, 2 mul.  Used by the
  * parity tests to pin the device arithmetic directly. */

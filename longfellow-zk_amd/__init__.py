@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
     "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
     "lfgpu_ligero_quadratic_proof", "lfgpu_ligero_open", "lfgpu_ligero_tableau", "lfgpu_ligero_free",
-    "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g",
+    "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g", "lfgpu_sumcheck_layer",
 ]
 
 
@@ -42,6 +42,8 @@ class LigeroParam(C.Structure):
 
 
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)  # RandomEngine::bytes
+# round callback of lfgpu_sumcheck_layer: (user, hand, round, evals[3][2], challenge_out[2])
+SC_ROUND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 
 
 class LfGpuError(RuntimeError):
@@ -95,6 +97,7 @@ def load_library():
         "lfgpu_quad_free": [vp],
         "lfgpu_eval_quad": [vp, sz, vp, vp, C.POINTER(ci)],
         "lfgpu_quad_bind_g": [vp, sz, vp, vp, pu64, pu64, vp, vp, C.POINTER(sz)],
+        "lfgpu_sumcheck_layer": [vp, sz, vp, vp, pu64, pu64, sz, sz, vp, pu64, SC_ROUND_FN, vp, pu64, pu64, pu64],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -368,6 +371,28 @@ class Quad:
                                                   _u64x2(alpha), _u64x2(beta), C.c_void_p(d_hc_out), C.c_void_p(d_vc_out),
                                                   C.byref(n_out)))
         return n_out.value
+
+    def sumcheck_layer(self, logv, G0, G1, alpha, beta, logw, nw, d_W, wc_in, round_cb):
+        """ProverLayers::layer (logc = 0) incl. bind_g; round_cb(hand, round, evals[3]) -> challenge, evals and
+        challenge as (lo, hi) pairs.  Returns (wc_out[2], challenges[2][logw], bound_quad)."""
+        import numpy as np
+        G0, G1 = np.ascontiguousarray(G0), np.ascontiguousarray(G1)
+
+        def cb(_user, hand, rnd, evals, out):
+            ev = [(evals[2 * k], evals[2 * k + 1]) for k in range(3)]
+            r = round_cb(hand, rnd, ev)
+            out[0], out[1] = int(r[0]), int(r[1])
+
+        cfn = SC_ROUND_FN(cb)
+        wci = (C.c_uint64 * 4)(int(wc_in[0][0]), int(wc_in[0][1]), int(wc_in[1][0]), int(wc_in[1][1]))
+        wco = (C.c_uint64 * 4)()
+        gout = (C.c_uint64 * (4 * max(1, logw)))()
+        bq = (C.c_uint64 * 2)()
+        self.gpu._ck(self.gpu.L.lfgpu_sumcheck_layer(self.h, logv, C.c_void_p(G0.ctypes.data), C.c_void_p(G1.ctypes.data),
+                                                     _u64x2(alpha), _u64x2(beta), logw, nw, C.c_void_p(d_W), wci, cfn, None,
+                                                     wco, gout, bq))
+        ch = [[(gout[(h * logw + r) * 2], gout[(h * logw + r) * 2 + 1]) for r in range(logw)] for h in range(2)]
+        return [(wco[0], wco[1]), (wco[2], wco[3])], ch, (bq[0], bq[1])
 
     def close(self):
         if self.h:

@@ -318,3 +318,133 @@ extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, c
   *n_out = *(const u32*)c->mailbox_h;
   return LFGPU_OK;
 }
+
+
+// ------------------------------------------------------------------ one sumcheck layer (host loop)
+extern "C" int lfgpu_sumcheck_partials(lfgpu_ctx*, int, size_t, const void*, const void*, uint64_t*, uint64_t*);
+extern "C" int lfgpu_qw_scatter(lfgpu_ctx*, int, size_t, const void*, const void*, int, const void*, size_t, void*);
+extern "C" int lfgpu_dense_bind(lfgpu_ctx*, int, size_t, const uint64_t*, const void*, void*);
+extern "C" int lfgpu_hquad_bind_h(lfgpu_ctx*, int, size_t, const void*, const void*, const uint64_t*, int, void*, void*, size_t*);
+
+namespace {
+struct HostField {
+  int field;
+  elt_t one, pts[3], invden[3];
+  elt_t add(elt_t a, elt_t b) const { return field == LFGPU_FIELD_GF2_128 ? gf_add(a, b) : fp_add(a, b); }
+  elt_t sub(elt_t a, elt_t b) const { return field == LFGPU_FIELD_GF2_128 ? gf_add(a, b) : fp_sub(a, b); }
+  elt_t mul(elt_t a, elt_t b) const { return field == LFGPU_FIELD_GF2_128 ? gf_mul(a, b) : fp_mul(a, b); }
+  elt_t inv(elt_t a) const { return field == LFGPU_FIELD_GF2_128 ? h_gf_inv(a) : h_fp_inv(a); }
+  explicit HostField(lfgpu_ctx* c, int f) : field(f) {
+    if (f == LFGPU_FIELD_GF2_128) {  // poly_evaluation_points_ = 0, 1, g (lib/gf2k/gf2_128.h:121-127)
+      one = elt_t{1, 0};
+      pts[0] = elt_t{0, 0};
+      pts[1] = one;
+      pts[2] = lf_gf_ctx(c, 4)->g;
+    } else {  // 0, 1, 2 (lib/algebra/fp_generic.h:114-121)
+      one = h_fp_of_scalar(1);
+      pts[0] = h_fp_of_scalar(0);
+      pts[1] = one;
+      pts[2] = h_fp_of_scalar(2);
+    }
+    for (int i = 0; i < 3; ++i) {
+      elt_t d = one;
+      for (int j = 0; j < 3; ++j)
+        if (j != i) d = mul(d, sub(pts[i], pts[j]));
+      invden[i] = inv(d);
+    }
+  }
+  // Poly<3>::eval_monomial (lib/algebra/poly.h:100-108)
+  elt_t eval_monomial(const elt_t coef[3], elt_t x) const { return add(mul(add(mul(coef[2], x), coef[1]), x), coef[0]); }
+  // value at x of the quadratic through (pts[i], ev[i]) = Poly<3>::eval_lagrange (poly.h:72-98)
+  elt_t eval_lagrange(const elt_t ev[3], elt_t x) const {
+    elt_t acc{0, 0};
+    if (field != LFGPU_FIELD_GF2_128) acc = pts[0];
+    for (int i = 0; i < 3; ++i) {
+      elt_t num = one;
+      for (int j = 0; j < 3; ++j)
+        if (j != i) num = mul(num, sub(x, pts[j]));
+      acc = add(acc, mul(ev[i], mul(num, invden[i])));
+    }
+    return acc;
+  }
+};
+}  // namespace
+
+extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                                    const uint64_t beta[2], size_t logw, size_t nw, void* d_W, const uint64_t wc_in[2][2],
+                                    lfgpu_sc_round_fn round, void* user, uint64_t wc_out[2][2], uint64_t* g_out,
+                                    uint64_t bound_quad[2]) {
+  if (!q || !alpha || !beta || !d_W || !wc_in || !round || !wc_out || !g_out || nw == 0 || logw > 40 || nw > ((size_t)1 << logw))
+    return q ? lf_fail(q->c, LFGPU_ERR_ARG, "sumcheck_layer: bad argument") : LFGPU_ERR_ARG;
+  lfgpu_ctx* c = q->c;
+  const int field = q->field;
+  LF_HIP(c, hipSetDevice(c->device));
+  const HostField F(c, field);
+  // device state: HQUAD ping-pong, QW, out-of-place buffer for the first bind of hand 0
+  void* sc = nullptr;
+  const size_t nt = q->n;
+  const size_t bytes = 2 * (nt * 8 + nt * 16) + nw * 16 + ((nw + 1) / 2) * 16 + 256;
+  if (hipMalloc(&sc, bytes) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "sumcheck_layer: %zu bytes", bytes);
+  struct Free {
+    void* p;
+    ~Free() { (void)hipFree(p); }
+  } guard{sc};
+  uint8_t* base = (uint8_t*)sc;
+  void* hc[2] = {base, base + nt * 8};
+  void* vc[2] = {base + 2 * nt * 8, base + 2 * nt * 8 + nt * 16};
+  void* qw = base + 2 * nt * 8 + 2 * nt * 16;
+  void* wtmp = (uint8_t*)qw + nw * 16;
+  size_t nh = 0;
+  LF_TRY(lfgpu_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], &nh));
+  int cur = 0;
+  const elt_t al{alpha[0], alpha[1]};
+  elt_t sum = F.add(elt_t{wc_in[0][0], wc_in[0][1]}, F.mul(al, elt_t{wc_in[1][0], wc_in[1][1]}));
+  void* WH[2] = {d_W, d_W};
+  size_t nW[2] = {nw, nw};
+  for (size_t rnd = 0; rnd < logw; ++rnd) {
+    for (int hand = 0; hand < 2; ++hand) {
+      LF_TRY(lfgpu_qw_scatter(c, field, nh, hc[cur], vc[cur], hand, WH[1 - hand], nW[hand], qw));
+      uint64_t a0[2], a2[2];
+      LF_TRY(lfgpu_sumcheck_partials(c, field, nW[hand], qw, WH[hand], a0, a2));
+      // coef[0] = eq0*a0, coef[2] = eq0*a2 with eq0 = 1 (logc = 0); coef[1] from sum (prover_layers.h:390-396)
+      elt_t coef[3];
+      coef[0] = elt_t{a0[0], a0[1]};
+      coef[2] = elt_t{a2[0], a2[1]};
+      coef[1] = F.sub(F.sub(F.sub(sum, coef[0]), coef[0]), coef[2]);
+      elt_t ev[3];
+      uint64_t evw[3][2], r[2];
+      for (int k = 0; k < 3; ++k) {
+        ev[k] = F.eval_monomial(coef, F.pts[k]);
+        evw[k][0] = ev[k].lo;
+        evw[k][1] = ev[k].hi;
+      }
+      round(user, (size_t)hand, rnd, evw, r);
+      g_out[(hand * logw + rnd) * 2] = r[0];
+      g_out[(hand * logw + rnd) * 2 + 1] = r[1];
+      sum = F.eval_lagrange(ev, elt_t{r[0], r[1]});
+      if (rnd == 0 && hand == 0) {  // hand 0 leaves the shared input out of place (prover_layers.h:222-226,255-257)
+        LF_TRY(lfgpu_dense_bind(c, field, nW[0], r, WH[0], wtmp));
+        WH[0] = wtmp;
+      } else {
+        LF_TRY(lfgpu_dense_bind(c, field, nW[hand], r, WH[hand], WH[hand]));
+      }
+      nW[hand] = (nW[hand] + 1) / 2;
+      LF_TRY(lfgpu_hquad_bind_h(c, field, nh, hc[cur], vc[cur], r, hand, hc[1 - cur], vc[1 - cur], &nh));
+      cur = 1 - cur;
+    }
+  }
+  uint64_t tmp[6];
+  LF_HIP(c, hipMemcpyAsync(tmp, WH[0], 16, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipMemcpyAsync(tmp + 2, WH[1], 16, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipMemcpyAsync(tmp + 4, vc[cur], 16, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  wc_out[0][0] = tmp[0];
+  wc_out[0][1] = tmp[1];
+  wc_out[1][0] = tmp[2];
+  wc_out[1][1] = tmp[3];
+  if (bound_quad) {
+    bound_quad[0] = tmp[4];
+    bound_quad[1] = tmp[5];
+  }
+  return LFGPU_OK;
+}

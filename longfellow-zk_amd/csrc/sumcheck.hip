@@ -75,18 +75,42 @@ __global__ __launch_bounds__(SC_THREADS) void sumcheck_final_kernel(u32 nblocks,
   }
 }
 
-// QW[h[hand]] ^= v * Wother[h[1-hand]]  -- GF(2^128): addition is XOR, so two 64-bit
-// atomic XORs per term are exact and order-independent.
+// QW[h[hand]] ^= v * Wother[h[1-hand]]  -- GF(2^128): addition is XOR, so two 64-bit atomic XORs per
+// term are exact and order-independent.  One wire (the constant 1) is the target of up to 2*10^5 terms of a
+// flatsha256 layer and its terms are mostly adjacent in canonical order, so equal-target neighbours are first
+// folded inside the wave with shuffles; only the first lane of each run of equal targets issues atomics.
 __global__ __launch_bounds__(SC_THREADS) void qw_scatter_gf_kernel(size_t n, const uint2* __restrict__ hc,
                                                                    const elt_t* __restrict__ vc, int hand,
                                                                    const elt_t* __restrict__ Wo, u64* __restrict__ QW) {
-  size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
-  if (i >= n) return;
-  uint2 h = hc[i];
-  u32 p0 = hand ? h.y : h.x, p1 = hand ? h.x : h.y;
-  elt_t t = gf_mul(ld16(&vc[i]), ld16(&Wo[p1]));
-  atomicXor(&QW[2 * (size_t)p0], t.lo);
-  atomicXor(&QW[2 * (size_t)p0 + 1], t.hi);
+  const size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
+  const u32 lane = threadIdx.x & 63;
+  const bool valid = i < n;
+  u32 key = 0xffffffffu;
+  elt_t t = elt_zero();
+  if (valid) {
+    uint2 h = hc[i];
+    key = hand ? h.y : h.x;
+    t = gf_mul(ld16(&vc[i]), ld16(&Wo[hand ? h.x : h.y]));
+  }
+  // runs of CONTIGUOUS equal targets: run id = number of run heads at or before the lane (monotone), so
+  // "same run id" implies every lane in between has the same target and the suffix fold below is exact
+  const u32 pkey = __shfl_up(key, 1, 64);
+  const bool head = lane == 0 || pkey != key;
+  const u64 hmask = __ballot(head);
+  const u32 rid = (u32)__popcll(hmask & ((2ull << lane) - 1));
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const u64 olo = __shfl_down(t.lo, off, 64), ohi = __shfl_down(t.hi, off, 64);
+    const u32 orid = __shfl_down(rid, off, 64);
+    if (lane + off < 64 && orid == rid) {
+      t.lo ^= olo;
+      t.hi ^= ohi;
+    }
+  }
+  if (valid && head) {
+    atomicXor(&QW[2 * (size_t)key], t.lo);
+    atomicXor(&QW[2 * (size_t)key + 1], t.hi);
+  }
 }
 
 // out[i] = in[2i] + r*(in[2i+1]-in[2i]);  tail: in*(1-r)   (dense.h:70-87, affine.h:26-52)

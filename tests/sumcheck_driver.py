@@ -292,3 +292,39 @@ class GpuSumcheck(SumcheckBase):
     def close(self):
         for q in self.quads:
             q.close()
+
+
+class GpuSumcheckLayerApi(GpuSumcheck):
+    """same proof through lfgpu_sumcheck_layer: the whole layer loop runs in the library's C++ host code and
+    only the transcript round (the caller's round_h + ts.round) comes back through a callback"""
+
+    def prove(self, ins, W_host, seed=b"testing"):
+        c = self.c
+        ts = Transcript(seed)
+        ts.write_array([bytes(W_host[i].tobytes()) for i in range(len(W_host))])
+        for _ in range(KMAX):
+            ts.elt_gf2128()
+        g0 = [_e(ts.elt_gf2128()) for _ in range(KMAX)]
+        G = [list(g0), list(g0)]
+        logv = c["logv"]
+        WC = [(0, 0), (0, 0)]
+        out = bytearray()
+
+        def round_cb(hand, rnd, ev):
+            nonlocal out
+            out += _b16(ev[0]) + _b16(ev[2])
+            ts.write_elt(_b16(ev[0]))
+            ts.write_elt(_b16(ev[2]))
+            return _e(ts.elt_gf2128())
+
+        for ly, layer in enumerate(c["layers"]):
+            alpha, beta = _e(ts.elt_gf2128()), _e(ts.elt_gf2128())
+            logw = layer["logw"]
+            G0 = np.array(G[0][:max(1, logv)], dtype=np.uint64)
+            G1 = np.array(G[1][:max(1, logv)], dtype=np.uint64)
+            WC, ch, _bq = self.quads[ly].sumcheck_layer(logv, G0, G1, alpha, beta, logw, layer["nw"], ins[ly].data_ptr(), WC, round_cb)
+            out += _b16(WC[0]) + _b16(WC[1])
+            ts.write_array([_b16(WC[0]), _b16(WC[1])])
+            G = [ch[0] + [(0, 0)] * (KMAX - logw), ch[1] + [(0, 0)] * (KMAX - logw)]
+            logv = logw
+        return bytes(out)

@@ -55,6 +55,11 @@ def test_sumcheck_gpu_reproduces_reference_proof(nb):
     assert ins is not None and (V == 0).all()
     got = sc.prove(ins, W)
     assert got == proof
+    # the same through lfgpu_sumcheck_layer (C++ host loop in the library, transcript behind a callback)
+    sc2 = sd.GpuSumcheckLayerApi(G.pkg, G.gpu(), circ)
+    ins, _ = sc2.eval_circuit(W)
+    assert sc2.prove(ins, W) == proof
+    sc2.close()
     # an unsatisfying witness is rejected by eval_circuit (assert-zero terms)
     W2 = W.copy()
     W2[5, 0] ^= 1

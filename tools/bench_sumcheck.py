@@ -17,6 +17,12 @@ t0 = time.perf_counter(); got = sc.prove(ins, W); t_pr = time.perf_counter() - t
 out = {"nb": nb, "nterms": info["nterms"], "round_hands": info["round_hands"], "bit_exact_vs_reference_fixture": got == proof,
        "gpu_upload_circuit_ms": t_up * 1e3, "gpu_eval_circuit_ms": t_ev * 1e3, "gpu_sumcheck_prove_ms": t_pr * 1e3,
        "note": "prove = Python host loop (transcript, 3-point polynomial via ctypes) + 5 kernel groups per round-hand"}
+sc2 = sd.GpuSumcheckLayerApi(G.pkg, G.gpu(), circ)
+ins, _ = sc2.eval_circuit(W)
+assert sc2.prove(ins, W) == proof
+ins, _ = sc2.eval_circuit(W); torch.cuda.synchronize()
+t0 = time.perf_counter(); got2 = sc2.prove(ins, W); out["gpu_sumcheck_prove_layer_api_ms"] = (time.perf_counter() - t0) * 1e3
+out["layer_api_bit_exact"] = got2 == proof
 gen = os.path.join(ROOT, "oracle", "_ref", "gen_flatsha")
 if os.path.exists(gen):
     with tempfile.TemporaryDirectory() as td:
