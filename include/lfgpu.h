@@ -186,7 +186,8 @@ typedef struct {
   size_t block_enc, block, dblock, block_ext, r, w, nwrow, nqtriples, nwqrow, nrow, mc_pathlen;
   size_t ildt, idot, iquad, iw, iq;
 } lfgpu_ligero_param;
-/* LigeroParam(nw, nq, rateinv, nreq, block_enc) ctor; LFGPU_ERR_ARG where the reference
+/* LigeroParam(nw, nq, rateinv, nreq, block_enc) ctor (block_enc = 0: the deprecated ctor that searches
+ * block_enc over powers of two for the smallest proof, ligero_param.h:152-169); LFGPU_ERR_ARG where the reference
  * would check-fail ("block_enc too large").  field selects kSubFieldBytes (GF2_128<k>: 2^k/8). */
 int lfgpu_ligero_param_init(lfgpu_ligero_param* p, int field, int subfield_log_bits, size_t nw, size_t nq,
                             size_t rateinv, size_t nreq, size_t block_enc);

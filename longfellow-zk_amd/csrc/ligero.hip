@@ -28,6 +28,44 @@ static size_t merkle_tree_len(size_t n) {  // merkle_tree.h:62-70
   return r;
 }
 
+// LigeroParam::layout (lib/ligero/ligero_param.h:185-295): fills *p for block_enc = e and returns the proof-size
+// estimate, or SIZE_MAX where the reference rejects the layout.
+static size_t ligero_layout(lfgpu_ligero_param* p, int field, int k, size_t e) {
+  const size_t max_lg_size = 28, max_size = (size_t)1 << max_lg_size;
+  const size_t field_bytes = 16, subfield_bytes = field == LFGPU_FIELD_GF2_128 ? (((size_t)1 << k) / 8) : 16;
+  const size_t nw = p->nw, nq = p->nq, rateinv = p->rateinv, nreq = p->nreq;
+  p->r = nreq;
+  p->block_enc = e;
+  size_t subfield_bits = 8 * subfield_bytes;
+  if (subfield_bits <= max_lg_size && e >= ((size_t)1 << subfield_bits)) return SIZE_MAX;
+  if (e > max_size || rateinv > max_size || (e + 1) < (2 + rateinv)) return SIZE_MAX;
+  p->block = (e + 1) / (2 + rateinv);
+  if (p->block < p->r) return SIZE_MAX;
+  p->w = p->block - p->r;
+  if (p->w < p->r) return SIZE_MAX;
+  p->dblock = 2 * p->block - 1;
+  if (e < p->dblock) return SIZE_MAX;
+  p->block_ext = e - p->dblock;
+  p->nwrow = ceildiv(nw, p->w);
+  p->nqtriples = ceildiv(nq, p->w);
+  p->nwqrow = p->nwrow + 3 * p->nqtriples;
+  p->nrow = p->nwqrow + 3;
+  if (p->nrow >= max_size / e) return SIZE_MAX;
+  if (p->block_ext == 0) return SIZE_MAX;  // merkle_commitment_len(0) is undefined; a commitment needs leaves
+  p->mc_pathlen = merkle_tree_len(p->block_ext);
+  uint64_t sz = 32;                                                     // commitment
+  sz += (uint64_t)p->mc_pathlen / 2 * (uint64_t)nreq * 32;             // Merkle openings (approximation)
+  sz += (uint64_t)p->block * field_bytes;                              // y_ldt
+  sz += (uint64_t)p->dblock * field_bytes;                             // y_dot
+  sz += (uint64_t)(p->dblock - p->w) * field_bytes;                    // y_quad
+  sz += (uint64_t)nreq * 32;                                           // nonces
+  sz += (uint64_t)p->nrow * (uint64_t)nreq * (uint64_t)subfield_bytes; // req
+  return (size_t)sz;
+}
+
+// block_enc != 0: LigeroParam(nw, nq, rateinv, nreq, block_enc) (ligero_param.h:172-178);
+// block_enc == 0: the deprecated ctor that searches block_enc over powers of two for the smallest proof
+// (ligero_param.h:152-169; what ZkProof(c, rate, req) and the benchmarks use).
 extern "C" int lfgpu_ligero_param_init(lfgpu_ligero_param* p, int field, int k, size_t nw, size_t nq, size_t rateinv,
                                        size_t nreq, size_t block_enc) {
   if (!p) return LFGPU_ERR_ARG;
@@ -36,27 +74,19 @@ extern "C" int lfgpu_ligero_param_init(lfgpu_ligero_param* p, int field, int k, 
   p->nq = nq;
   p->rateinv = rateinv;
   p->nreq = nreq;
-  p->r = nreq;
-  const size_t max_lg_size = 28, max_size = (size_t)1 << max_lg_size;
-  p->block_enc = block_enc;
-  size_t subfield_bits = field == LFGPU_FIELD_GF2_128 ? ((size_t)1 << k) : 128;
-  if (subfield_bits <= max_lg_size && block_enc >= ((size_t)1 << subfield_bits)) return LFGPU_ERR_ARG;
-  if (block_enc > max_size || rateinv > max_size || (block_enc + 1) < (2 + rateinv)) return LFGPU_ERR_ARG;
-  p->block = (block_enc + 1) / (2 + rateinv);
-  if (p->block < p->r) return LFGPU_ERR_ARG;
-  p->w = p->block - p->r;
-  if (p->w < p->r) return LFGPU_ERR_ARG;
-  p->dblock = 2 * p->block - 1;
-  if (block_enc < p->dblock) return LFGPU_ERR_ARG;
-  p->block_ext = block_enc - p->dblock;
-  p->nwrow = ceildiv(nw, p->w);
-  p->nqtriples = ceildiv(nq, p->w);
-  p->nwqrow = p->nwrow + 3 * p->nqtriples;
-  p->nrow = p->nwqrow + 3;
-  if (p->nrow >= max_size / block_enc) return LFGPU_ERR_ARG;
-  if (p->block_ext == 0) return LFGPU_ERR_ARG;
-  p->mc_pathlen = merkle_tree_len(p->block_ext);
-  if (!(block_enc > p->block)) return LFGPU_ERR_ARG;  // sanity(): block_enc > block
+  if (block_enc == 0) {
+    size_t best = SIZE_MAX, best_e = 1;
+    for (size_t e = 1; e <= ((size_t)1 << 28); e *= 2) {
+      size_t sz = ligero_layout(p, field, k, e);
+      if (sz < best) {
+        best = sz;
+        best_e = e;
+      }
+    }
+    block_enc = best_e;
+  }
+  if (ligero_layout(p, field, k, block_enc) == SIZE_MAX) return LFGPU_ERR_ARG;
+  if (!(p->block_enc > p->block)) return LFGPU_ERR_ARG;  // sanity(): block_enc > block
   p->ildt = 0;
   p->idot = 1;
   p->iquad = 2;

@@ -4,6 +4,9 @@ sumcheck prover) and stores xz-compressed fixtures under tests/golden/:
   flatsha_nb<N>.lfc1.xz  circuit in the reference's LFC1 wire format (CircuitWriter output)
   flatsha_nb<N>.w.xz     witness, ninputs x 16-byte GF2_128 elements
   flatsha_nb<N>.scproof  transmitted sumcheck evaluations of run_prover (transcript "testing")
+  flatsha_nb<N>.zkproof.xz  every component of the full ZK proof (ZkProver commit+prove, rate 7, 132 queries,
+                         transcript "test", LCG RandomEngine seed 100): root, padded sumcheck proof, y_ldt, y_dot,
+                         y_quad_0, y_quad_2, req, opened nonces, Merkle path
   flatsha_nb<N>.json     sizes + the reference's single-thread timings in this container
 Build container only (needs /root/reference)."""
 import json
@@ -25,7 +28,7 @@ def main():
         with tempfile.TemporaryDirectory() as td:
             pre = os.path.join(td, "x")
             info = json.loads(subprocess.check_output([GEN, str(nb), pre]).decode())
-            for ext, comp in ((".lfc1", True), (".w", True), (".scproof", False)):
+            for ext, comp in ((".lfc1", True), (".w", True), (".scproof", False), (".zkproof", True)):
                 data = open(pre + ext, "rb").read()
                 dst = os.path.join(OUT, "flatsha_nb%d%s" % (nb, ext + (".xz" if comp else "")))
                 with open(dst, "wb") as f:

@@ -31,9 +31,28 @@
 #include "random/transcript.h"
 #include "sumcheck/circuit.h"
 #include "sumcheck/prover.h"
+#include "gf2k/lch14_reed_solomon.h"
+#include "random/random.h"
 #include "util/log.h"
+#include "zk/zk_proof.h"
+#include "zk/zk_prover.h"
 
 using namespace proofs;
+
+// the LCG of rust/runtime/ligero/tests/ligero.rs:28-43 (the engine the reference's own C++ fixtures use)
+class LcgRng : public RandomEngine {
+ public:
+  explicit LcgRng(uint64_t seed) : s_(seed) {}
+  void bytes(uint8_t* buf, size_t n) override {
+    for (size_t i = 0; i < n; ++i) {
+      s_ = s_ * 6364136223846793005ull + 1442695040888963407ull;
+      buf[i] = static_cast<uint8_t>(s_ >> 32);
+    }
+  }
+
+ private:
+  uint64_t s_;
+};
 using F128 = GF2_128<>;
 constexpr size_t kPlucker = 2;
 
@@ -110,6 +129,7 @@ int main(int argc, char** argv) {
   dump(prefix + ".lfc1", bytes.data(), bytes.size());
   dump(prefix + ".w", W.v_.data(), 16 * C->ninputs);
 
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   // ---- reference sumcheck prover (run_prover, transcript "testing")
   Proof<F128> proof(C->nl);
   typename Prover<F128>::inputs pin;
@@ -138,14 +158,63 @@ int main(int argc, char** argv) {
     put(proof.l[ly].wc[1]);
   }
   dump(prefix + ".scproof", pr.data(), pr.size());
-  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   size_t nterms = 0, rounds = 0;
   for (auto& ly : C->l) {
     nterms += ly.nterms();
     rounds += ly.logw;
   }
+  // ---- full ZK proof (BM_ShaZK_fp2_128 body, flatsha256_circuit_test.cc:510-536) under a deterministic RNG:
+  // rate 7, 132 queries, transcript "test", LCG seed 100.  Dumps every component of the proof.
+  double zk_commit_ms = 0, zk_prove_ms = 0;
+  size_t z_block_enc = 0, z_nrow = 0, z_block = 0, z_dblock = 0, z_nw = 0;
+  {
+    using RSFactory = LCH14ReedSolomonFactory<F128>;
+    const RSFactory rsf(Fs);
+    Transcript tp((const uint8_t*)"test", 4);
+    LcgRng rng(100);
+    ZkProof<F128> zk(*C, 7, 132);
+    ZkProver<F128, RSFactory> zp(*C, Fs, rsf);
+    auto z0 = std::chrono::steady_clock::now();
+    zp.commit(zk, W, tp, rng);
+    auto z1 = std::chrono::steady_clock::now();
+    bool ok = zp.prove(zk, W, tp);
+    auto z2 = std::chrono::steady_clock::now();
+    check(ok, "zk prove failed");
+    zk_commit_ms = ms(z0, z1);
+    zk_prove_ms = ms(z1, z2);
+    const auto& P = zk.param;
+    z_block_enc = P.block_enc; z_nrow = P.nrow; z_block = P.block; z_dblock = P.dblock; z_nw = P.nw;
+    std::vector<uint8_t> zb;
+    auto pute = [&](const F128::Elt& e) {
+      uint8_t b[16];
+      Fs.to_bytes_field(b, e);
+      zb.insert(zb.end(), b, b + 16);
+    };
+    zb.insert(zb.end(), zk.com.root.data, zk.com.root.data + 32);
+    for (size_t ly = 0; ly < C->nl; ++ly) {
+      for (size_t r = 0; r < C->l[ly].logw; ++r)
+        for (size_t h = 0; h < 2; ++h) {
+          pute(zk.proof.l[ly].hp[h][r].t_[0]);
+          pute(zk.proof.l[ly].hp[h][r].t_[2]);
+        }
+      pute(zk.proof.l[ly].wc[0]);
+      pute(zk.proof.l[ly].wc[1]);
+    }
+    for (auto& e : zk.com_proof.y_ldt) pute(e);
+    for (auto& e : zk.com_proof.y_dot) pute(e);
+    for (auto& e : zk.com_proof.y_quad_0) pute(e);
+    for (auto& e : zk.com_proof.y_quad_2) pute(e);
+    for (auto& e : zk.com_proof.req) pute(e);
+    for (auto& nn : zk.com_proof.merkle.nonce) zb.insert(zb.end(), nn.bytes, nn.bytes + 32);
+    uint64_t np = zk.com_proof.merkle.path.size();
+    for (int i = 0; i < 8; ++i) zb.push_back(static_cast<uint8_t>(np >> (8 * i)));
+    for (auto& d : zk.com_proof.merkle.path) zb.insert(zb.end(), d.data, d.data + 32);
+    dump(prefix + ".zkproof", zb.data(), zb.size());
+  }
   printf("{\"nb\": %zu, \"nl\": %zu, \"ninputs\": %zu, \"npub_in\": %zu, \"nterms\": %zu, \"round_hands\": %zu, \"lfc1_bytes\": %zu, "
-         "\"ref_eval_circuit_ms\": %.2f, \"ref_sumcheck_ms\": %.2f}\n",
-         nb, (size_t)C->nl, (size_t)C->ninputs, (size_t)C->npub_in, nterms, 2 * rounds, bytes.size(), ms(t0, t1), ms(t1, t2));
+         "\"ref_eval_circuit_ms\": %.2f, \"ref_sumcheck_ms\": %.2f, \"zk_nw\": %zu, \"zk_block_enc\": %zu, \"zk_block\": %zu, "
+         "\"zk_dblock\": %zu, \"zk_nrow\": %zu, \"ref_zk_commit_ms\": %.2f, \"ref_zk_prove_ms\": %.2f}\n",
+         nb, (size_t)C->nl, (size_t)C->ninputs, (size_t)C->npub_in, nterms, 2 * rounds, bytes.size(), ms(t0, t1), ms(t1, t2),
+         z_nw, z_block_enc, z_block, z_dblock, z_nrow, zk_commit_ms, zk_prove_ms);
   return 0;
 }

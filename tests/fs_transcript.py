@@ -170,3 +170,27 @@ class Transcript:
 
     def elt_gf2128(self):  # GF2_128::sample: 16 bytes LE (lib/gf2k/gf2_128.h:182-190)
         return self.bytes(16)
+
+    # RandomEngine::nat / choose (lib/random/random.h:57-105)
+    def nat(self, n):
+        assert n > 0
+        l, nn = 0, n
+        while nn:
+            nn >>= 8
+            l += 1
+        mask = 0
+        while (n & mask) != n:
+            mask = (mask << 1) | 1
+        while True:
+            r = int.from_bytes(self.bytes(l), "little") & mask
+            if r < n:
+                return r
+
+    def choose(self, n, k):
+        A = list(range(n))
+        res = []
+        for i in range(k):
+            j = i + self.nat(n - i)
+            A[i], A[j] = A[j], A[i]
+            res.append(A[i])
+        return res

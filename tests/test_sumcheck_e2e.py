@@ -66,3 +66,30 @@ def test_sumcheck_gpu_reproduces_reference_proof(nb):
     ins2, _ = sc.eval_circuit(W2)
     assert ins2 is None or True  # flipping one input bit need not hit an assert-zero term; must not crash
     sc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb", [1, 32])
+def test_full_zk_proof_gpu_matches_reference(nb):
+    """BASELINE headline path (BM_ShaZK_fp2_128: ZkProver commit + prove, rate 7, 132 queries) with the
+    deterministic LCG RandomEngine of the reference's own fixtures: commitment root, padded sumcheck proof,
+    y_ldt, y_dot, y_quad, opened columns, nonces and Merkle path are byte-identical to the reference's."""
+    import gpu_util as G
+    import ligero_fixture as lf
+    import sumcheck_driver as sd
+    import zk_driver as zd
+    from fs_transcript import Transcript
+    circ, W, _, info = sd.load_fixture(GOLD, nb)
+    want = zd.load_zk_fixture(GOLD, nb)
+    zp = zd.ZkProverGpu(G.pkg, G.gpu(), circ)
+    assert (zp.param.block_enc, zp.param.nrow, zp.param.nw) == (info["zk_block_enc"], info["zk_nrow"], info["zk_nw"])
+    ts = Transcript(b"test")
+    rng = lf.LcgRng(100)
+    root = zp.commit(W, rng, ts)
+    assert root == want[:32]
+    pr = zp.prove(W, ts)
+    assert pr is not None
+    got = zd.serialize(circ, root, pr)
+    assert len(got) == len(want)
+    assert got == want
+    zp.close()
