@@ -101,6 +101,17 @@ struct Sampler {
   const GfHostCtx* g;
   lfgpu_rng_fn rng;
   void* user;
+  // n consecutive full-field elements.  GF2_128::sample consumes exactly 16 bytes per element
+  // (gf2_128.h:182-190), so n draws of 16 bytes equal one draw of 16n bytes for every byte-stream
+  // RandomEngine of the reference (LCG test engines, Transcript/FSPRF, SecureRandomEngine); Fp128 uses
+  // rejection sampling and is drawn element by element.
+  void elts(elt_t* out, size_t n) {
+    if (field == LFGPU_FIELD_GF2_128) {
+      rng(user, reinterpret_cast<uint8_t*>(out), 16 * n);  // little-endian host: bytes are the Elt image
+    } else {
+      for (size_t i = 0; i < n; ++i) out[i] = elt();
+    }
+  }
   elt_t elt() {
     if (field == LFGPU_FIELD_GF2_128) {  // GF2_128::sample gf2_128.h:182-190: 16 bytes LE
       uint8_t b[16];
@@ -188,28 +199,32 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
   std::vector<elt_t> H(p.nrow * hw, zero);
   auto at = [&](size_t i, size_t j) -> elt_t& { return H[i * hw + j]; };
   // layout_blinding_rows (ligero_prover.h:171-205)
-  for (size_t j = 0; j < p.block; ++j) at(p.ildt, j) = S.elt();
-  for (size_t j = 0; j < p.dblock; ++j) at(p.idot, j) = S.elt();
+  S.elts(&at(p.ildt, 0), p.block);
+  S.elts(&at(p.idot, 0), p.dblock);
   {
     elt_t sum = zero;
     for (size_t j = 0; j < p.w; ++j) sum = h_add(field, sum, at(p.idot, p.r + j));
     at(p.idot, p.r) = h_sub(field, at(p.idot, p.r), sum);
   }
-  for (size_t j = 0; j < p.dblock; ++j) at(p.iquad, j) = S.elt();
+  S.elts(&at(p.iquad, 0), p.dblock);
   for (size_t j = 0; j < p.w; ++j) at(p.iquad, p.r + j) = zero;
   // layout_witness_rows (:207-231)
   for (size_t i = 0; i < p.nwrow; ++i) {
     bool subfield_only = ((i + 1) * p.w <= subfield_boundary);
-    for (size_t j = 0; j < p.r; ++j) at(i + p.iw, j) = subfield_only ? S.subfield_elt() : S.elt();
+    if (subfield_only) {
+      for (size_t j = 0; j < p.r; ++j) at(i + p.iw, j) = S.subfield_elt();
+    } else {
+      S.elts(&at(i + p.iw, 0), p.r);
+    }
     size_t max_col = std::min(p.w, p.nw - i * p.w);
     for (size_t j = 0; j < max_col; ++j) at(i + p.iw, p.r + j) = W[i * p.w + j];
   }
   // layout_quadratic_rows (:233-270)
   const size_t iqx = p.iq, iqy = iqx + p.nqtriples, iqz = iqy + p.nqtriples;
   for (size_t i = 0; i < p.nqtriples; ++i) {
-    for (size_t j = 0; j < p.r; ++j) at(iqx + i, j) = S.elt();
-    for (size_t j = 0; j < p.r; ++j) at(iqy + i, j) = S.elt();
-    for (size_t j = 0; j < p.r; ++j) at(iqz + i, j) = S.elt();
+    S.elts(&at(iqx + i, 0), p.r);
+    S.elts(&at(iqy + i, 0), p.r);
+    S.elts(&at(iqz + i, 0), p.r);
     for (size_t j = 0; j < p.w && j + i * p.w < p.nq; ++j) {
       const size_t* l = &h_lqc[3 * (j + i * p.w)];
       if (l[0] >= p.nw || l[1] >= p.nw || l[2] >= p.nw) return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit: lqc index >= nw");
@@ -230,7 +245,7 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
   pr->d_T = nullptr;
   pr->d_layers = nullptr;
   pr->nonces.resize(p.block_ext * 32);
-  for (size_t j = 0; j < p.block_ext; ++j) rng(user, &pr->nonces[32 * j], 32);
+  rng(user, pr->nonces.data(), 32 * p.block_ext);  // one 32-byte draw per leaf, in leaf order (byte-stream engine)
 
   auto fail = [&](int rc) {
     lfgpu_ligero_free(pr);

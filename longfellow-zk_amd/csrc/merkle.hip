@@ -183,7 +183,7 @@ extern "C" int lfgpu_merkle_open(lfgpu_ctx* c, size_t n, const void* d_layers, c
   if (!h_path || idx.size() > path_cap) return lf_fail(c, LFGPU_ERR_ARG, "merkle_open: path buffer too small");
   LF_HIP(c, hipSetDevice(c->device));
   void* sc = nullptr;
-  LF_TRY(lf_scratch2(c, idx.size() * 40, &sc));
+  LF_TRY(lf_scratch2(c, idx.size() * 40 + 64, &sc));
   u64* d_idx = (u64*)sc;
   uint4* d_out = (uint4*)((u8*)sc + ((idx.size() * 8 + 15) & ~(size_t)15));
   LF_HIP(c, hipMemcpyAsync(d_idx, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, c->stream));

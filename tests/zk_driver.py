@@ -36,7 +36,7 @@ class ZkProverGpu:
     # ---- ZkProver::commit
     def commit(self, W, rng, ts):
         c, F = self.c, self.F
-        wit = [tuple(int(x) for x in W[i + self.npub]) for i in range(self.n_witness)]
+        wit = []  # pad elements only; the private inputs are concatenated as an array below
         self.pad = []  # per layer: dict(hp[(hand, round)] = (t0, t2), wc = (wc0, wc1))
         lqc = []
         pi = self.n_witness
@@ -55,7 +55,7 @@ class ZkProverGpu:
             lqc.append((cp, cp + 1, cp + 2))  # setup_lqc (zk_common.h:149-160)
             pi += layer_size(layer["logw"])
         self.lqc = lqc
-        Wv = np.array(wit, dtype=np.uint64)
+        Wv = np.concatenate([np.ascontiguousarray(W[self.npub:]), np.array(wit, dtype=np.uint64).reshape(-1, 2)])
         assert len(Wv) == self.param.nw
         sfb = c["subfield_boundary"] - self.npub if c["subfield_boundary"] >= self.npub else 0
         self.lp = self.pkg.LigeroProver(self.gpu, GF, self.param)
