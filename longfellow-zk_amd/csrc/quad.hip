@@ -112,37 +112,8 @@ __global__ __launch_bounds__(1024) void bindg_scan_kernel(u32 nblocks, u32* __re
   }
   if (threadIdx.x == 0) *total = carry;
 }
-// each run head sums its run: v' = (v == 0 ? beta : v) * eq[g]   (prep_v)
-template <int F>
-__global__ __launch_bounds__(QD_THREADS) void bindg_emit_kernel(size_t n, const corner4* __restrict__ t,
-                                                                const elt_t* __restrict__ kvec, const elt_t* __restrict__ eq,
-                                                                elt_t beta, const u32* __restrict__ block_off,
-                                                                uint2* __restrict__ hc_out, elt_t* __restrict__ vc_out) {
-  __shared__ u32 wave_off[QD_THREADS / 64];
-  size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x;
-  bool head = i < n && is_head(t, i);
-  u64 mask = __ballot(head);
-  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) wave_off[wave] = (u32)__popcll(mask);
-  __syncthreads();
-  u32 off = block_off[blockIdx.x];
-  for (u32 w = 0; w < wave; ++w) off += wave_off[w];
-  off += (u32)__popcll(mask & ((1ull << lane) - 1));
-  if (!head) return;
-  corner4 c0 = t[i];
-  elt_t acc = elt_zero();
-  for (size_t j = i; j < n; ++j) {
-    corner4 cj = t[j];
-    if (cj.h0 != c0.h0 || cj.h1 != c0.h1) break;
-    elt_t v = ld16(&kvec[cj.vi]);
-    if ((v.lo | v.hi) == 0) v = beta;
-    acc = Fld<F>::add(acc, Fld<F>::mul(v, ld16(&eq[cj.g])));
-  }
-  hc_out[off] = make_uint2(c0.h0, c0.h1);
-  st16(&vc_out[off], acc);
-}
-
-// GF2_128 variant without serial runs: a hand pair shared by very many gates (constant wires: the
+// ---- K10 step 3: every term computes v' = (v == 0 ? beta : v) * eq[g] (prep_v) and the run sums are formed in parallel.
+// GF2_128: a hand pair shared by very many gates (constant wires: the
 // 32-block flatsha256 layers hold runs of > 10^5 terms) would otherwise be summed by ONE lane.  Every
 // term computes its own product, a wave folds equal-run neighbours with shuffles (runs are contiguous
 // in canonical order), and the last lane of each run fragment issues one pair of 64-bit atomic XORs --
@@ -190,6 +161,50 @@ __global__ __launch_bounds__(QD_THREADS) void bindg_emit_gf_kernel(size_t n, con
     atomicXor(&vc_out[2 * (size_t)ri], pv.lo);
     atomicXor(&vc_out[2 * (size_t)ri + 1], pv.hi);
   }
+}
+
+// Fp128 variant: same per-term parallelism; the run sums are accumulated as plain integers in four
+// 64-bit limb accumulators per run (residues add as integers; < 2^32 terms per run) and reduced once.
+__global__ __launch_bounds__(QD_THREADS) void bindg_emit_fp_kernel(size_t n, const corner4* __restrict__ t,
+                                                                   const elt_t* __restrict__ kvec,
+                                                                   const elt_t* __restrict__ eq, elt_t beta,
+                                                                   const u32* __restrict__ block_off,
+                                                                   uint2* __restrict__ hc_out, u64* __restrict__ acc) {
+  __shared__ u32 wave_off[QD_THREADS / 64];
+  const size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x;
+  const bool valid = i < n;
+  const bool head = valid && is_head(t, i);
+  const u64 mask = __ballot(head);
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_off[wave] = (u32)__popcll(mask);
+  __syncthreads();
+  if (!valid) return;
+  u32 ri = block_off[blockIdx.x];
+  for (u32 w = 0; w < wave; ++w) ri += wave_off[w];
+  ri += (u32)__popcll(mask & ((2ull << lane) - 1)) - 1;
+  const corner4 c0 = t[i];
+  elt_t v = ld16(&kvec[c0.vi]);
+  if ((v.lo | v.hi) == 0) v = beta;
+  const elt_t pv = fp_mul(v, ld16(&eq[c0.g]));
+  if (head) hc_out[ri] = make_uint2(c0.h0, c0.h1);
+  u64* a = acc + 4 * (size_t)ri;
+  atomicAdd(&a[0], (u64)(u32)pv.lo);
+  atomicAdd(&a[1], pv.lo >> 32);
+  atomicAdd(&a[2], (u64)(u32)pv.hi);
+  atomicAdd(&a[3], pv.hi >> 32);
+}
+__global__ __launch_bounds__(QD_THREADS) void fp_limb_normalize4_kernel(const u32* __restrict__ total,
+                                                                        const u64* __restrict__ acc,
+                                                                        const elt_t* __restrict__ c, elt_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x;
+  if (i >= *total) return;
+  elt_t sum = elt_zero();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u64 a = acc[4 * i + k];
+    sum = fp_add(sum, fp_add(fp_mul(elt_t{(u64)(u32)a, 0}, ld16(&c[k])), fp_mul(elt_t{a >> 32, 0}, ld16(&c[k + 1]))));
+  }
+  st16(&out[i], sum);
 }
 
 #define QD_DISPATCH(field, KERNEL, grid, block, ...)                                    \
@@ -308,9 +323,23 @@ extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, c
     hipLaunchKernelGGL(bindg_emit_gf_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
                        (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)counts, (uint2*)d_hc_out, (u64*)d_vc_out);
   } else {
-    // Fp128 has no 128-bit atomic add: each run head sums its run (long runs serialise)
-    hipLaunchKernelGGL(bindg_emit_kernel<FIELD_FP128>, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
-                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)counts, (uint2*)d_hc_out, (elt_t*)d_vc_out);
+    // Fp128 has no 128-bit atomic add: integer limb accumulators + one reduction per run
+    if (n >> 32) return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_g: more than 2^32 terms");
+    void* accv = nullptr;
+    LF_TRY(lf_scratch2(c, n * 32 + 64, &accv));
+    void* dconst = nullptr;
+    if (!lf_table_lookup(c, "fp:pow2_32j", &dconst)) {
+      elt_t cs[5];  // Montgomery images of 2^(32j)
+      cs[0] = h_fp_of_scalar(1);
+      const elt_t two32 = h_fp_of_scalar(1ull << 32);
+      for (int j = 1; j < 5; ++j) cs[j] = fp_mul(cs[j - 1], two32);
+      LF_TRY(lf_table(c, "fp:pow2_32j", cs, sizeof(cs), &dconst));
+    }
+    LF_HIP(c, hipMemsetAsync(accv, 0, n * 32, c->stream));
+    hipLaunchKernelGGL(bindg_emit_fp_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
+                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)counts, (uint2*)d_hc_out, (u64*)accv);
+    hipLaunchKernelGGL(fp_limb_normalize4_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, (const u32*)total, (const u64*)accv,
+                       (const elt_t*)dconst, (elt_t*)d_vc_out);
   }
   LF_HIP(c, hipGetLastError());
   LF_HIP(c, hipMemcpyAsync(c->mailbox_h, total, 4, hipMemcpyDeviceToHost, c->stream));

@@ -113,6 +113,42 @@ __global__ __launch_bounds__(SC_THREADS) void qw_scatter_gf_kernel(size_t n, con
   }
 }
 
+// Fp128 has no 128-bit atomic, but residues add as plain integers: every product v*W (a canonical residue
+// < p < 2^128) is split into four 32-bit limbs that are accumulated with 64-bit atomic adds into a
+// 4 x u64 accumulator per target (no carry can be lost below 2^32 terms per target); a second kernel
+// recombines the limbs and reduces mod p once.  Exact and independent of arrival order.
+__global__ __launch_bounds__(SC_THREADS) void qw_scatter_fp_kernel(size_t n, const uint2* __restrict__ hc,
+                                                                   const elt_t* __restrict__ vc, int hand,
+                                                                   const elt_t* __restrict__ Wo, u64* __restrict__ acc) {
+  const size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
+  if (i >= n) return;
+  uint2 h = hc[i];
+  const u32 p0 = hand ? h.y : h.x, p1 = hand ? h.x : h.y;
+  elt_t t = fp_mul(ld16(&vc[i]), ld16(&Wo[p1]));
+  u64* a = acc + 4 * (size_t)p0;
+  atomicAdd(&a[0], (u64)(u32)t.lo);
+  atomicAdd(&a[1], t.lo >> 32);
+  atomicAdd(&a[2], (u64)(u32)t.hi);
+  atomicAdd(&a[3], t.hi >> 32);
+}
+// S = sum_k acc[k] * 2^(32k) mod p on PLAIN integers (S is then again a Montgomery image, because images add).
+// acc[k] = lo32 + hi32 * 2^32; piece * 2^(32j) mod p = fp_mul(piece, c[j]) with c[j] = image of 2^(32j).
+__global__ __launch_bounds__(SC_THREADS) void fp_limb_normalize_kernel(size_t n, const u64* __restrict__ acc,
+                                                                       const elt_t* __restrict__ c /*5 constants*/,
+                                                                       elt_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
+  if (i >= n) return;
+  elt_t sum = elt_zero();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u64 a = acc[4 * i + k];
+    const elt_t lo = fp_mul(elt_t{(u64)(u32)a, 0}, ld16(&c[k]));
+    const elt_t hi = fp_mul(elt_t{a >> 32, 0}, ld16(&c[k + 1]));
+    sum = fp_add(sum, fp_add(lo, hi));
+  }
+  st16(&out[i], sum);
+}
+
 // out[i] = in[2i] + r*(in[2i+1]-in[2i]);  tail: in*(1-r)   (dense.h:70-87, affine.h:26-52)
 template <int F>
 __global__ __launch_bounds__(SC_THREADS) void dense_bind_kernel(size_t n0, elt_t r, const elt_t* __restrict__ in,
@@ -278,9 +314,33 @@ extern "C" int lfgpu_sumcheck_partials(lfgpu_ctx* c, int field, size_t n, const 
 extern "C" int lfgpu_qw_scatter(lfgpu_ctx* c, int field, size_t n, const void* d_hc, const void* d_vc, int hand,
                                 const void* d_Wother, size_t nqw, void* d_QW) {
   if (!c || !d_QW || (n && (!d_hc || !d_vc || !d_Wother))) return lf_fail(c, LFGPU_ERR_ARG, "qw_scatter: null argument");
-  if (field != LFGPU_FIELD_GF2_128)
-    return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "qw_scatter: only GF2_128 (XOR atomics) is covered yet");
   LF_HIP(c, hipSetDevice(c->device));
+  if (field == LFGPU_FIELD_FP128) {
+    // integer limb accumulators + one reduction (see qw_scatter_fp_kernel)
+    if (n >> 32) return lf_fail(c, LFGPU_ERR_ARG, "qw_scatter: more than 2^32 terms");
+    void* sc = nullptr;
+    LF_TRY(lf_scratch2(c, nqw * 32 + 5 * 16 + 64, &sc));
+    u64* acc = (u64*)sc;
+    void* dconst = nullptr;
+    if (!lf_table_lookup(c, "fp:pow2_32j", &dconst)) {
+      elt_t cs[5];  // Montgomery images of 2^(32j), j = 0..4
+      cs[0] = h_fp_of_scalar(1);
+      const elt_t two32 = h_fp_of_scalar(1ull << 32);
+      for (int j = 1; j < 5; ++j) cs[j] = fp_mul(cs[j - 1], two32);
+      LF_TRY(lf_table(c, "fp:pow2_32j", cs, sizeof(cs), &dconst));
+    }
+    LF_HIP(c, hipMemsetAsync(acc, 0, nqw * 32, c->stream));
+    if (n) {
+      u32 nb = (u32)((n + SC_THREADS - 1) / SC_THREADS);
+      hipLaunchKernelGGL(qw_scatter_fp_kernel, dim3(nb), dim3(SC_THREADS), 0, c->stream, n, (const uint2*)d_hc,
+                         (const elt_t*)d_vc, hand ? 1 : 0, (const elt_t*)d_Wother, acc);
+    }
+    u32 nb2 = (u32)((nqw + SC_THREADS - 1) / SC_THREADS);
+    hipLaunchKernelGGL(fp_limb_normalize_kernel, dim3(nb2), dim3(SC_THREADS), 0, c->stream, nqw, (const u64*)acc,
+                       (const elt_t*)dconst, (elt_t*)d_QW);
+    LF_HIP(c, hipGetLastError());
+    return LFGPU_OK;
+  }
   LF_HIP(c, hipMemsetAsync(d_QW, 0, nqw * 16, c->stream));
   if (n) {
     u32 nb = (u32)((n + SC_THREADS - 1) / SC_THREADS);

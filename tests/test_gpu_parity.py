@@ -302,21 +302,28 @@ def test_hquad_bind_h_rounds(G, field):
         hand = 1 - hand
 
 
-def test_qw_scatter_gf(G):
+@pytest.mark.parametrize("field", [GF, FP])
+def test_qw_scatter(G, field):
+    """GF2_128: wave-folded atomic XOR; Fp128: 32-bit limb integer accumulators + one reduction.  A hot target
+    (index 0 hit by a third of the terms, partly in contiguous runs) exercises the contended paths."""
     import torch
     o = ol.oracle()
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(12 + field)
     nw = 4096
     n = 50000
     hc = rng.integers(0, nw, size=(n, 2)).astype(np.uint32)
-    vc = ol.rand_elts(rng, n)
-    W = ol.rand_elts(rng, nw)
+    hot = rng.random(n) < 0.33
+    hc[hot, 0] = 0
+    hc[1000:3000, 0] = 0
+    hc[5000:5100, 1] = 7
+    vc = ol.rand_elts(rng, n, field)
+    W = ol.rand_elts(rng, nw, field)
     for hand in (0, 1):
         want = np.zeros((nw, 2), dtype=np.uint64)
-        o.lfo_qw_scatter(GF, n, P(hc), P(vc), hand, P(W), nw, P(want))
+        o.lfo_qw_scatter(field, n, P(hc), P(vc), hand, P(W), nw, P(want))
         dh, dv, dw = G.to_dev(hc), G.to_dev(vc), G.to_dev(W)
         dq = torch.ones(nw * 16, dtype=torch.uint8, device="cuda")
-        G.gpu().qw_scatter(GF, n, dh.data_ptr(), dv.data_ptr(), hand, dw.data_ptr(), nw, dq.data_ptr())
+        G.gpu().qw_scatter(field, n, dh.data_ptr(), dv.data_ptr(), hand, dw.data_ptr(), nw, dq.data_ptr())
         assert (G.from_dev(dq, np.uint64, (nw, 2)) == want).all()
 
 
