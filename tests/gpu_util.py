@@ -2,8 +2,13 @@
 import numpy as np
 import torch
 
+import os
+
+import __graft_entry__ as _ge
 from __graft_entry__ import load_package
 
+if not os.path.exists(_ge.LIB):  # fresh checkout on a GPU box: build the HIP library in-tree (hipcc is in the image)
+    _ge.build()
 pkg = load_package()
 _gpu = None
 
