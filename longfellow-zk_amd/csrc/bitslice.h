@@ -64,6 +64,21 @@ LF_HD void bs_mac_lane(u32 t, const u32 (&b)[M], u32 (&dst)[M]) {
   }
 }
 
+#if defined(__HIPCC__)
+// dst ^= t * b where t is constant on aligned groups of 2^glog lanes (glog <= 6): one scalar-branched pass per
+// group with the other lanes masked off.  glog = 6 is the wave-uniform case (one pass); smaller groups cost
+// (64 >> glog) passes, still ~2x cheaper than masking every plane XOR per lane (bs_mac_lane).
+template <int M, u32 MU_LOW>
+__device__ inline void bs_mac_groups(u32 t, u32 glog, const u32 (&b)[M], u32 (&dst)[M]) {
+  const u32 lane = __lane_id();
+#pragma nounroll
+  for (u32 g = 0; g < (64u >> glog); ++g) {
+    const u32 tg = __builtin_amdgcn_readlane(t, g << glog);
+    if ((lane >> glog) == g) bs_mac_uniform<M, MU_LOW>(tg, b, dst);
+  }
+}
+#endif
+
 // 32x32 bit-matrix transpose: on return bit r of x[b] = bit b of the original x[r].
 LF_HD void bs_transpose32(u32 (&x)[32]) {
 #pragma unroll

@@ -18,7 +18,7 @@
 #include "bitslice.h"
 #include "ctx.h"
 
-#define BS_COLS 128     // columns per conversion tile
+#define BS_COLS 64      // columns per conversion tile (one wave = one plane row)
 #define BS_NB_MAX 4     // index bits per butterfly pass (array bound)
 // Butterfly tile = 2^r_log (row-group, coordinate) combos x 2^nb columns = 512 units.  r_log 5 / nb 4
 // (one masked per-lane stage per pass) or r_log 6 / nb 3 (every stage wave-uniform, more passes):
@@ -26,40 +26,49 @@
 static u32 g_bs_rlog = 5;
 #define BS_PS(units) ((units) + 1)  // LDS plane stride (words): +1 keeps the 8x4-byte scatter of a 128-byte chunk on distinct banks
 
-// ------------------------------------------------------------------ conversion in
+// ------------------------------------------------------------------ conversions
+// Tile = one row group (32 rows) x BS_COLS columns, 256 threads, 32 KiB LDS, <= 256 VGPRs: two independent
+// workgroups per CU, so one tile's HBM phase overlaps the other's XOR program (a single 512-thread WG per
+// CU ran its phases strictly one after the other).  Plane layout [p][lc ^ ((p>>5)<<3)]: the transpose
+// writes of the four dwords of a column land on distinct banks.
+#define BS_PL(p, lc) ((p) * BS_COLS + ((lc) ^ ((((u32)(p)) >> 5) << 3)))
+
 template <int K>
-__global__ __launch_bounds__(512) void bs_cin_kernel(const elt_t* __restrict__ src, size_t ld, u32 rows, u32 n,
-                                                     u32* __restrict__ dst) {
+__global__ __launch_bounds__(256, 2) void bs_cin_kernel(const elt_t* __restrict__ src, size_t ld, u32 rows, u32 n,
+                                                        u32* __restrict__ dst) {
   constexpr int M = Tower<K>::M, D = Tower<K>::D;
-  extern __shared__ u32 lds[];  // 128 x 128 words
+  extern __shared__ u32 lds[];  // 32 rows x BS_COLS x 4 words, then 128 planes x BS_COLS words
   const u32 t = threadIdx.x, rg = blockIdx.y, c0 = blockIdx.x * BS_COLS;
-  {  // phase 1: coalesced row reads (16 B per lane, 2 KiB contiguous per row)
-    const u32 lc = t & 127, rq = t >> 7;
+  {  // phase 1: coalesced row reads (16 B per lane, 1 KiB contiguous per row), all issued before the LDS writes
+    const u32 lc = t & (BS_COLS - 1), rq = t / BS_COLS;
+    uint4 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const u32 r = rq * 8 + i, row = rg * 32 + r;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (row < rows) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c0 + lc);
-      *reinterpret_cast<uint4*>(&lds[(r * 128 + lc) * 4]) = v;
+      const u32 row = rg * 32 + rq * 8 + i;
+      v[i] = make_uint4(0, 0, 0, 0);
+      if (row < rows) v[i] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c0 + lc);
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(&lds[((rq * 8 + i) * BS_COLS + lc) * 4]) = v[i];
   }
   __syncthreads();
   {  // phase 2: per (column, dword) 32x32 bit transpose
     const u32 lc = t >> 2, w = t & 3;
     u32 x[32];
 #pragma unroll
-    for (int r = 0; r < 32; ++r) x[r] = lds[(r * 128 + lc) * 4 + w];
+    for (int r = 0; r < 32; ++r) x[r] = lds[(r * BS_COLS + lc) * 4 + w];
     __syncthreads();
     bs_transpose32(x);
+    const u32 lcs = lc ^ (w << 3);
 #pragma unroll
-    for (int b = 0; b < 32; ++b) lds[(w * 32 + b) * 128 + lc] = x[b];
+    for (int b = 0; b < 32; ++b) lds[(w * 32 + b) * BS_COLS + lcs] = x[b];
   }
   __syncthreads();
-  {  // phase 3: polynomial basis -> tower basis, one coordinate per thread (wave-uniform q)
-    const u32 lc = t & 127, q0 = t >> 7;
-#define BS_IN(i) lds[(i) * 128 + lc]
+  {  // phase 3: polynomial basis -> tower basis, one coordinate per wave (wave-uniform q)
+    const u32 lc = t & (BS_COLS - 1), q0 = t / BS_COLS;
+#define BS_IN(i) lds[BS_PL(i, lc)]
 #define BS_OUT(o) out[o]
-    for (u32 q = q0; q < (u32)D; q += 4) {
+    for (u32 q = q0; q < (u32)D; q += 256 / BS_COLS) {
       u32 out[M];
       if (K == 5) {
         switch (q) {
@@ -89,32 +98,40 @@ __global__ __launch_bounds__(512) void bs_cin_kernel(const elt_t* __restrict__ s
   }
 }
 
-// ------------------------------------------------------------------ conversion out
 template <int K>
-__global__ __launch_bounds__(512) void bs_cout_kernel(const u32* __restrict__ src, size_t ld, u32 rows, u32 n,
-                                                      elt_t* __restrict__ dst) {
+__global__ __launch_bounds__(256, 2) void bs_cout_kernel(const u32* __restrict__ src, size_t ld, u32 rows, u32 n,
+                                                         elt_t* __restrict__ dst) {
   constexpr int M = Tower<K>::M, D = Tower<K>::D;
   extern __shared__ u32 lds[];
   const u32 t = threadIdx.x, rg = blockIdx.y, c0 = blockIdx.x * BS_COLS;
-  {  // units -> tower planes [p][lc]
-    const u32 lc = t & 127, q0 = t >> 7;
-    for (u32 q = q0; q < (u32)D; q += 4) {
+  {  // units -> tower planes [p][lc]; all global loads first
+    const u32 lc = t & (BS_COLS - 1), q0 = t / BS_COLS;
+    constexpr int QN = D * BS_COLS / 256;  // coordinates per thread
+    uint4 v[QN][M / 4];
+#pragma unroll
+    for (int qi = 0; qi < QN; ++qi) {
+      const u32 q = q0 + qi * (256 / BS_COLS);
       const uint4* u = reinterpret_cast<const uint4*>(src + ((size_t)(rg * D + q) * n + c0 + lc) * M);
 #pragma unroll
+      for (int j = 0; j < M / 4; ++j) v[qi][j] = u[j];
+    }
+#pragma unroll
+    for (int qi = 0; qi < QN; ++qi) {
+      const u32 q = q0 + qi * (256 / BS_COLS);
+#pragma unroll
       for (int j = 0; j < M / 4; ++j) {
-        uint4 v = u[j];
-        lds[(q * M + 4 * j + 0) * 128 + lc] = v.x;
-        lds[(q * M + 4 * j + 1) * 128 + lc] = v.y;
-        lds[(q * M + 4 * j + 2) * 128 + lc] = v.z;
-        lds[(q * M + 4 * j + 3) * 128 + lc] = v.w;
+        lds[BS_PL(q * M + 4 * j + 0, lc)] = v[qi][j].x;
+        lds[BS_PL(q * M + 4 * j + 1, lc)] = v[qi][j].y;
+        lds[BS_PL(q * M + 4 * j + 2, lc)] = v[qi][j].z;
+        lds[BS_PL(q * M + 4 * j + 3, lc)] = v[qi][j].w;
       }
     }
   }
   __syncthreads();
-  {  // tower -> poly for one dword of the element, then 32x32 transpose back to rows
-    const u32 lc = t & 127, w = t >> 7;
+  {  // tower -> poly for one dword of the element (wave-uniform w), then 32x32 transpose back to rows
+    const u32 lc = t & (BS_COLS - 1), w = t / BS_COLS;
     u32 x[32];
-#define BS_IN(i) lds[(i) * 128 + lc]
+#define BS_IN(i) lds[BS_PL(i, lc)]
 #define BS_OUT(o) x[o]
     if (K == 5) {
       switch (w) {
@@ -136,15 +153,15 @@ __global__ __launch_bounds__(512) void bs_cout_kernel(const u32* __restrict__ sr
     __syncthreads();
     bs_transpose32(x);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) lds[(r * 128 + lc) * 4 + w] = x[r];
+    for (int r = 0; r < 32; ++r) lds[(r * BS_COLS + lc) * 4 + w] = x[r];
   }
   __syncthreads();
   {
-    const u32 lc = t & 127, rq = t >> 7;
+    const u32 lc = t & (BS_COLS - 1), rq = t / BS_COLS;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const u32 r = rq * 8 + i, row = rg * 32 + r;
-      if (row < rows) *reinterpret_cast<uint4*>(dst + (size_t)row * ld + c0 + lc) = *reinterpret_cast<const uint4*>(&lds[(r * 128 + lc) * 4]);
+      if (row < rows) *reinterpret_cast<uint4*>(dst + (size_t)row * ld + c0 + lc) = *reinterpret_cast<const uint4*>(&lds[(r * BS_COLS + lc) * 4]);
     }
   }
 }
@@ -225,17 +242,16 @@ __global__ __launch_bounds__(256, 2) void bs_bfly_kernel(BflyArgs a) {
         b0[p] = lds[p * PS + s0];
         b1[p] = lds[p * PS + s1];
       }
-      const bool uniform = (R << b) >= 64;  // every lane of the wave shares u
-      if (!INV) {  // b0 ^= tw*b1; b1 ^= b0   (lch14.h:219-223)
-        if (uniform) bs_mac_uniform<M, MU>(__builtin_amdgcn_readfirstlane(tw), b1, b0);
-        else bs_mac_lane<M, MU>(tw, b1, b0);
+      // lanes sharing a twiddle: aligned groups of min(64, R << b); one scalar-branched MAC per group
+      const u32 glog = RL + b < 6 ? RL + b : 6;
+      if (INV) {  // b1 ^= b0; b0 ^= tw*b1   (lch14.h:225-229)
 #pragma unroll
         for (int p = 0; p < M; ++p) b1[p] ^= b0[p];
-      } else {  // b1 ^= b0; b0 ^= tw*b1   (lch14.h:225-229)
+      }
+      bs_mac_groups<M, MU>(tw, glog, b1, b0);  // b0 ^= tw*b1
+      if (!INV) {  // ... b1 ^= b0   (lch14.h:219-223)
 #pragma unroll
         for (int p = 0; p < M; ++p) b1[p] ^= b0[p];
-        if (uniform) bs_mac_uniform<M, MU>(__builtin_amdgcn_readfirstlane(tw), b1, b0);
-        else bs_mac_lane<M, MU>(tw, b1, b0);
       }
 #pragma unroll
       for (int p = 0; p < M; ++p) {
@@ -313,10 +329,6 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
   LF_TRY(bs_tables<K>(c, g, l, coset, &d_tw, &offs));
   static bool attr = false;
   if (!attr) {
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_cin_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_cin_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_cout_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_cout_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -325,7 +337,7 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
   }
   if (combos > nrg * D)  // padded combos: define the bits (values are never read back)
     LF_HIP(c, hipMemsetAsync((u32*)internal + (size_t)nrg * D * n * M, 0, (size_t)(combos - nrg * D) * n * M * 4, c->stream));
-  hipLaunchKernelGGL(bs_cin_kernel<K>, dim3(n / BS_COLS, nrg), dim3(512), 65536, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
+  hipLaunchKernelGGL(bs_cin_kernel<K>, dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
                      (u32*)internal);
   // bit groups of <= BS_NB_MAX index bits; FFT walks stages l-1..0, IFFT 0..l-1
   std::vector<std::pair<u32, u32>> groups;  // (lo_bit, nb), ascending
@@ -348,7 +360,7 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
     else
       hipLaunchKernelGGL((bs_bfly_kernel<K, false>), dim3(n >> (gr.second + a.cu), combos >> (g_bs_rlog - a.cu)), dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
   }
-  hipLaunchKernelGGL(bs_cout_kernel<K>, dim3(n / BS_COLS, nrg), dim3(512), 65536, c->stream, (const u32*)internal, ld, (u32)rows, n,
+  hipLaunchKernelGGL(bs_cout_kernel<K>, dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const u32*)internal, ld, (u32)rows, n,
                      (elt_t*)d_B);
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
