@@ -144,6 +144,12 @@ int lfgpu_eval_quad(lfgpu_quad* q, size_t nw, const void* d_W, void* d_V, int* o
 int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
                       const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out);
 
+/* Eqs::raw_eq2 (lib/arrays/eqs.h): eq[i] = EQ(G0, i) + alpha EQ(G1, i) for i < n <= 2^logn, the
+ * vector bind_g folds the corners with and ZkCommon::input_constraint (lib/zk/zk_common.h:406-439) puts on the
+ * inputs.  h_G0 / h_G1: logn host elements; d_eq: n device elements. */
+int lfgpu_raw_eq2(lfgpu_ctx* ctx, int field, size_t logn, size_t n, const void* h_G0, const void* h_G1,
+                  const uint64_t alpha[2], void* d_eq);
+
 /* ---- one whole sumcheck layer with the transcript behind a callback -------------------
  * Replaces the body of ProverLayers::layer for logc = 0 (every ZK use, lib/zk/zk_common.h:72) together
  * with the bind_g that precedes it (lib/sumcheck/prover_layers.h:140-146,185-271): HQUAD = bind_g(...),

@@ -1,0 +1,99 @@
+/* lfgpu_zk.h -- C ABI of the ZK prover host driver (the callers of the hot path).
+ *
+ * lfgpu.h is the kernel-level boundary; this header is one level up: the host control flow of
+ *   ZkProver::commit / ZkProver::prove        lib/zk/zk_prover.h:72-149
+ *   ZkCommon::verifier_constraints            lib/zk/zk_common.h:49-136,406-439
+ *   LigeroProver::prove                       lib/ligero/ligero_prover.h:84-146
+ *   ZkProof::write                            lib/zk/zk_proof.h:90-185
+ *   CircuitRep::from_bytes (LFC1)             lib/proto/circuit.h, lib/proto/circuit_reader.h:55-233
+ * written in C++ inside the library, with every data-parallel step on the device through the lfgpu.h kernels.
+ * Field: GF2_128<4> (the field of BM_ShaZK_fp2_128, lib/circuits/sha/flatsha256_circuit_test.cc:510-536); other
+ * field ids in the circuit header return LFGPU_ERR_UNSUPPORTED.
+ *
+ * The Fiat-Shamir transcript and the RandomEngine are the CALLER's: they are reached through the hooks below, so
+ * an integration passes thin wrappers over proofs::Transcript / proofs::RandomEngine.  A built-in
+ * transcript with the reference's exact construction (SHA-256 state + AES-256-ECB counter PRF,
+ * lib/random/transcript.h:33-190) is provided for stand-alone use and for the tests.
+ */
+#ifndef LFGPU_ZK_H_
+#define LFGPU_ZK_H_
+
+#include "lfgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- Fiat-Shamir transcript hooks (proofs::Transcript, lib/random/transcript.h:70-190) ---- */
+typedef struct lfgpu_transcript_ops {
+  void* user;
+  /* Transcript::write(const uint8_t*, size_t): tag 0 || u64 length || bytes */
+  void (*write_bytes)(void* user, const uint8_t* data, size_t n);
+  /* Transcript::write(const Elt&, F): tag 1 || to_bytes_field image (elt16 = that 16-byte image) */
+  void (*write_elt)(void* user, const uint8_t* elt16);
+  /* Transcript::write(const Elt[], ince, n, F): tag 2 || u64 count || images */
+  void (*write_elt_array)(void* user, const uint8_t* elts16, size_t n);
+  /* RandomEngine::bytes: n PRF bytes */
+  void (*gen_bytes)(void* user, uint8_t* out, size_t n);
+  /* Transcript::clone(): a new `user` with the same state (ZkProver::prove runs the sumcheck prover on a
+   * copy, zk_prover.h:117-124); release with free_clone */
+  void* (*clone)(void* user);
+  void (*free_clone)(void* user);
+} lfgpu_transcript_ops;
+
+/* built-in transcript, byte-identical to the reference's (pinned by the ZK fixtures and FIPS-197/180-4 vectors) */
+typedef struct lfgpu_transcript lfgpu_transcript;
+lfgpu_transcript* lfgpu_transcript_new(const uint8_t* init, size_t n); /* Transcript(init, n) */
+void lfgpu_transcript_free(lfgpu_transcript* t);
+void lfgpu_transcript_get_ops(lfgpu_transcript* t, lfgpu_transcript_ops* ops);
+/* direct access for tests */
+void lfgpu_transcript_write_bytes(lfgpu_transcript* t, const uint8_t* data, size_t n);
+void lfgpu_transcript_write_elt(lfgpu_transcript* t, const uint8_t* elt16);
+void lfgpu_transcript_write_elt_array(lfgpu_transcript* t, const uint8_t* elts16, size_t n);
+void lfgpu_transcript_bytes(lfgpu_transcript* t, uint8_t* out, size_t n);
+/* primitives the transcript is built from (known-answer tested) */
+void lfgpu_sha256(const uint8_t* data, size_t n, uint8_t out[32]);
+void lfgpu_aes256_ecb_block(const uint8_t key[32], const uint8_t in[16], uint8_t out[16]);
+/* SHA-NI / AES-NI dispatch: force_portable = 1 / 0 switches the portable C++ paths on / off, < 0 only queries;
+ * returns 1 when the hardware paths are active. */
+int lfgpu_crypto_hw(int force_portable);
+
+/* ---- circuit (LFC1 wire format -> device-resident layers) ---- */
+typedef struct lfgpu_circuit lfgpu_circuit;
+typedef struct {
+  int field; /* LFGPU_FIELD_* */
+  size_t nv, nc, npub_in, subfield_boundary, ninputs, nl, logv, nterms;
+  uint8_t id[32];
+} lfgpu_circuit_info;
+/* CircuitRep::from_bytes (lib/proto/circuit.h): parses the LFC1 bytes, delta-decodes every layer's corners
+ * (circuit_reader.h:55-233) and uploads them with lfgpu_quad_upload.  LFGPU_ERR_ARG on malformed input. */
+int lfgpu_circuit_from_lfc1(lfgpu_ctx* ctx, const uint8_t* bytes, size_t len, lfgpu_circuit** out);
+int lfgpu_circuit_get_info(const lfgpu_circuit* c, lfgpu_circuit_info* info);
+int lfgpu_circuit_layer_info(const lfgpu_circuit* c, size_t layer, size_t* logw, size_t* nw, size_t* nterms);
+int lfgpu_circuit_free(lfgpu_circuit* c);
+
+/* ---- ZkProver ---- */
+typedef struct lfgpu_zk_prover lfgpu_zk_prover;
+/* ZkProver(c, F, rsf) + ZkProof(c, rateinv, nreq[, block_enc]) (zk_proof.h:63-76): block_enc = 0 searches. */
+int lfgpu_zk_prover_new(lfgpu_ctx* ctx, const lfgpu_circuit* c, size_t rateinv, size_t nreq, size_t block_enc,
+                        lfgpu_zk_prover** out);
+int lfgpu_zk_prover_param(const lfgpu_zk_prover* zk, lfgpu_ligero_param* p);
+/* ZkProver::commit (zk_prover.h:72-96): fill_pad from `rng`, Ligero-commit witness||pad, root -> transcript.
+ * h_W: ninputs host elements (public inputs first). */
+int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_fn rng, void* rng_user,
+                    const lfgpu_transcript_ops* ts, uint8_t root_out[32]);
+/* ZkProver::prove (zk_prover.h:98-149): *ok = 0 when the witness does not satisfy the circuit (the reference
+ * returns false); otherwise the proof is held by the prover object. */
+int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_transcript_ops* ts, int* ok);
+/* ZkProof::write (zk_proof.h:90-185): the wire bytes of commitment || sumcheck proof || Ligero proof.
+ * Call with buf = NULL to get the size. */
+int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, size_t cap, size_t* nbytes);
+/* host milliseconds spent in the last commit / prove, split by phase:
+ * [0] commit total, [1] prove total, [2] eval_circuit, [3] sumcheck, [4] constraints, [5] ligero prove */
+int lfgpu_zk_timings(const lfgpu_zk_prover* zk, double ms[6]);
+int lfgpu_zk_prover_free(lfgpu_zk_prover* zk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFGPU_ZK_H_ */

@@ -30,7 +30,13 @@ ABI_SYMBOLS = [
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
     "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
     "lfgpu_ligero_quadratic_proof", "lfgpu_ligero_open", "lfgpu_ligero_tableau", "lfgpu_ligero_free",
-    "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g", "lfgpu_sumcheck_layer",
+    "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g", "lfgpu_sumcheck_layer", "lfgpu_raw_eq2",
+    # include/lfgpu_zk.h
+    "lfgpu_transcript_new", "lfgpu_transcript_free", "lfgpu_transcript_get_ops", "lfgpu_transcript_write_bytes",
+    "lfgpu_transcript_write_elt", "lfgpu_transcript_write_elt_array", "lfgpu_transcript_bytes", "lfgpu_sha256",
+    "lfgpu_aes256_ecb_block", "lfgpu_crypto_hw", "lfgpu_circuit_from_lfc1", "lfgpu_circuit_get_info", "lfgpu_circuit_layer_info",
+    "lfgpu_circuit_free", "lfgpu_zk_prover_new", "lfgpu_zk_prover_param", "lfgpu_zk_commit", "lfgpu_zk_prove",
+    "lfgpu_zk_proof_write", "lfgpu_zk_timings", "lfgpu_zk_prover_free",
 ]
 
 
@@ -44,6 +50,18 @@ class LigeroParam(C.Structure):
 RNG_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)  # RandomEngine::bytes
 # round callback of lfgpu_sumcheck_layer: (user, hand, round, evals[3][2], challenge_out[2])
 SC_ROUND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+
+
+class TranscriptOps(C.Structure):
+    """lfgpu_transcript_ops (include/lfgpu_zk.h): the caller's Fiat-Shamir transcript behind function pointers"""
+    _fields_ = [("user", C.c_void_p), ("write_bytes", C.c_void_p), ("write_elt", C.c_void_p),
+                ("write_elt_array", C.c_void_p), ("gen_bytes", C.c_void_p), ("clone", C.c_void_p), ("free_clone", C.c_void_p)]
+
+
+class CircuitInfo(C.Structure):
+    """lfgpu_circuit_info"""
+    _fields_ = [("field", C.c_int)] + [(n, C.c_size_t) for n in (
+        "nv", "nc", "npub_in", "subfield_boundary", "ninputs", "nl", "logv", "nterms")] + [("id", C.c_uint8 * 32)]
 
 
 class LfGpuError(RuntimeError):
@@ -98,11 +116,31 @@ def load_library():
         "lfgpu_eval_quad": [vp, sz, vp, vp, C.POINTER(ci)],
         "lfgpu_quad_bind_g": [vp, sz, vp, vp, pu64, pu64, vp, vp, C.POINTER(sz)],
         "lfgpu_sumcheck_layer": [vp, sz, vp, vp, pu64, pu64, sz, sz, vp, pu64, SC_ROUND_FN, vp, pu64, pu64, pu64],
+        "lfgpu_raw_eq2": [vp, ci, sz, sz, vp, vp, pu64, vp],
+        "lfgpu_circuit_from_lfc1": [vp, vp, sz, C.POINTER(vp)],
+        "lfgpu_circuit_get_info": [vp, C.POINTER(CircuitInfo)],
+        "lfgpu_circuit_layer_info": [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)],
+        "lfgpu_circuit_free": [vp],
+        "lfgpu_zk_prover_new": [vp, vp, sz, sz, sz, C.POINTER(vp)],
+        "lfgpu_zk_prover_param": [vp, C.POINTER(LigeroParam)],
+        "lfgpu_zk_commit": [vp, vp, RNG_FN, vp, C.POINTER(TranscriptOps), vp],
+        "lfgpu_zk_prove": [vp, vp, C.POINTER(TranscriptOps), C.POINTER(ci)],
+        "lfgpu_zk_proof_write": [vp, vp, sz, C.POINTER(sz)],
+        "lfgpu_zk_timings": [vp, C.POINTER(C.c_double)],
+        "lfgpu_zk_prover_free": [vp],
+        "lfgpu_crypto_hw": [ci],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.restype, fn.argtypes = ci, args
     L.lfgpu_last_error.restype, L.lfgpu_last_error.argtypes = C.c_char_p, [vp]
+    L.lfgpu_transcript_new.restype, L.lfgpu_transcript_new.argtypes = vp, [vp, sz]
+    for name, args in (("lfgpu_transcript_free", [vp]), ("lfgpu_transcript_get_ops", [vp, C.POINTER(TranscriptOps)]),
+                       ("lfgpu_transcript_write_bytes", [vp, vp, sz]), ("lfgpu_transcript_write_elt", [vp, vp]),
+                       ("lfgpu_transcript_write_elt_array", [vp, vp, sz]), ("lfgpu_transcript_bytes", [vp, vp, sz]),
+                       ("lfgpu_sha256", [vp, sz, vp]), ("lfgpu_aes256_ecb_block", [vp, vp, vp])):
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = None, args
     _lib = L
     return L
 
@@ -397,4 +435,127 @@ class Quad:
     def close(self):
         if self.h:
             self.gpu.L.lfgpu_quad_free(self.h)
+            self.h = None
+
+
+class FsTranscript:
+    """The library's built-in Fiat-Shamir transcript (reference lib/random/transcript.h:33-190); host only."""
+
+    def __init__(self, init=b""):
+        self.L = load_library()
+        self.h = self.L.lfgpu_transcript_new(bytes(init), len(init))
+        if not self.h:
+            raise LfGpuError("lfgpu_transcript_new failed")
+
+    def write_bytes(self, data):
+        self.L.lfgpu_transcript_write_bytes(self.h, bytes(data), len(data))
+
+    def write_elt(self, e16):
+        self.L.lfgpu_transcript_write_elt(self.h, bytes(e16))
+
+    def write_array(self, elts):
+        b = b"".join(bytes(e) for e in elts)
+        self.L.lfgpu_transcript_write_elt_array(self.h, b, len(elts))
+
+    def bytes(self, n):
+        buf = C.create_string_buffer(n)
+        self.L.lfgpu_transcript_bytes(self.h, buf, n)
+        return buf.raw
+
+    def ops(self):
+        o = TranscriptOps()
+        self.L.lfgpu_transcript_get_ops(self.h, C.byref(o))
+        return o
+
+    def close(self):
+        if self.h:
+            self.L.lfgpu_transcript_free(self.h)
+            self.h = None
+
+
+def sha256(data):
+    out = C.create_string_buffer(32)
+    load_library().lfgpu_sha256(bytes(data), len(data), out)
+    return out.raw
+
+
+def aes256_ecb_block(key, block):
+    out = C.create_string_buffer(16)
+    load_library().lfgpu_aes256_ecb_block(bytes(key), bytes(block), out)
+    return out.raw
+
+
+class Circuit:
+    """A circuit parsed from the reference's LFC1 wire bytes, layers resident on the device (lfgpu_circuit)."""
+
+    def __init__(self, gpu, lfc1_bytes):
+        self.gpu = gpu
+        h = C.c_void_p()
+        raw = bytes(lfc1_bytes)
+        gpu._ck(gpu.L.lfgpu_circuit_from_lfc1(gpu.h, raw, len(raw), C.byref(h)))
+        self.h = h
+        self.info = CircuitInfo()
+        gpu._ck(gpu.L.lfgpu_circuit_get_info(self.h, C.byref(self.info)))
+
+    def layer(self, i):
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self.gpu._ck(self.gpu.L.lfgpu_circuit_layer_info(self.h, i, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(logw=a.value, nw=b.value, nterms=c.value)
+
+    def close(self):
+        if self.h:
+            self.gpu.L.lfgpu_circuit_free(self.h)
+            self.h = None
+
+
+class ZkProver:
+    """Mirror of ZkProver<Field, RSFactory> (reference lib/zk/zk_prover.h:45-149) over include/lfgpu_zk.h: the whole
+    host control flow runs in the library's C++; `rng_bytes(n) -> bytes` plays the RandomEngine."""
+
+    def __init__(self, gpu, circuit, rate=7, nreq=132, block_enc=0):
+        self.gpu, self.circuit = gpu, circuit
+        h = C.c_void_p()
+        gpu._ck(gpu.L.lfgpu_zk_prover_new(gpu.h, circuit.h, rate, nreq, block_enc, C.byref(h)))
+        self.h = h
+        self.param = LigeroParam()
+        gpu._ck(gpu.L.lfgpu_zk_prover_param(self.h, C.byref(self.param)))
+
+    def commit(self, W, rng_bytes, transcript):
+        import numpy as np
+
+        def cb(_user, buf, n):
+            C.memmove(buf, rng_bytes(n), n)
+
+        self._cb = RNG_FN(cb)
+        W = np.ascontiguousarray(W)
+        root = (C.c_uint8 * 32)()
+        ops = transcript.ops()
+        self.gpu._ck(self.gpu.L.lfgpu_zk_commit(self.h, C.c_void_p(W.ctypes.data), self._cb, None, C.byref(ops), root))
+        return bytes(root)
+
+    def prove(self, W, transcript):
+        """-> True (proof held by the object; wire() serializes it) or False (witness does not satisfy the circuit)"""
+        import numpy as np
+        W = np.ascontiguousarray(W)
+        ok = C.c_int()
+        ops = transcript.ops()
+        self.gpu._ck(self.gpu.L.lfgpu_zk_prove(self.h, C.c_void_p(W.ctypes.data), C.byref(ops), C.byref(ok)))
+        return bool(ok.value)
+
+    def wire(self):
+        """ZkProof::write bytes"""
+        n = C.c_size_t()
+        self.gpu._ck(self.gpu.L.lfgpu_zk_proof_write(self.h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self.gpu._ck(self.gpu.L.lfgpu_zk_proof_write(self.h, buf, n.value, C.byref(n)))
+        return buf.raw[:n.value]
+
+    def timings(self):
+        ms = (C.c_double * 6)()
+        self.gpu._ck(self.gpu.L.lfgpu_zk_timings(self.h, ms))
+        return dict(zip(("commit", "prove", "eval_circuit", "sumcheck", "constraints", "ligero_prove"), list(ms)))
+
+    def close(self):
+        if self.h:
+            self.gpu.L.lfgpu_zk_prover_free(self.h)
             self.h = None

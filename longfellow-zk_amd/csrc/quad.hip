@@ -285,6 +285,36 @@ extern "C" int lfgpu_eval_quad(lfgpu_quad* q, size_t nw, const void* d_W, void* 
   return LFGPU_OK;
 }
 
+// Eqs::raw_eq2 (lib/arrays/eqs.h): eq[i] = EQ(G0, i) + alpha EQ(G1, i), i < n <= 2^logn
+extern "C" int lfgpu_raw_eq2(lfgpu_ctx* c, int field, size_t logn, size_t n, const void* h_G0, const void* h_G1,
+                             const uint64_t alpha[2], void* d_eq) {
+  if (!c || !alpha || !d_eq || (logn && (!h_G0 || !h_G1)) || (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128))
+    return LFGPU_ERR_ARG;
+  if (logn > 40 || ((size_t)1 << logn) < n || (n >> 32)) return lf_fail(c, LFGPU_ERR_ARG, "raw_eq2: n out of range");
+  if (n == 0) return LFGPU_OK;
+  LF_HIP(c, hipSetDevice(c->device));
+  const elt_t one = field == LFGPU_FIELD_GF2_128 ? elt_t{1, 0} : h_fp_of_scalar(1);
+  // table [G0 | G1 | 1-G0 | 1-G1]
+  std::vector<elt_t> Gt(4 * logn + 1);
+  const elt_t* G0 = (const elt_t*)h_G0;
+  const elt_t* G1 = (const elt_t*)h_G1;
+  for (size_t l = 0; l < logn; ++l) {
+    Gt[l] = G0[l];
+    Gt[logn + l] = G1[l];
+    Gt[2 * logn + l] = field == LFGPU_FIELD_GF2_128 ? gf_add(one, G0[l]) : fp_sub(one, G0[l]);
+    Gt[3 * logn + l] = field == LFGPU_FIELD_GF2_128 ? gf_add(one, G1[l]) : fp_sub(one, G1[l]);
+  }
+  void* d_G = nullptr;
+  LF_TRY(lf_scratch2(c, Gt.size() * 16, &d_G));
+  LF_HIP(c, hipMemcpyAsync(d_G, Gt.data(), Gt.size() * 16, hipMemcpyHostToDevice, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));  // Gt is a stack-lifetime host buffer
+  const elt_t al{alpha[0], alpha[1]};
+  QD_DISPATCH(field, raw_eq2_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, (u32)n,
+              (const elt_t*)d_G, al, one, (elt_t*)d_eq);
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
 extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
                                  const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out) {
   if (!q || !alpha || !beta || !d_hc_out || !d_vc_out || !n_out || (logv && (!h_G0 || !h_G1))) return LFGPU_ERR_ARG;
@@ -292,30 +322,15 @@ extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, c
   if (logv > 40 || ((size_t)1 << logv) < q->nv) return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_g: 2^logv < nv");
   LF_HIP(c, hipSetDevice(c->device));
   const int field = q->field;
-  const elt_t one = field == LFGPU_FIELD_GF2_128 ? elt_t{1, 0} : h_fp_of_scalar(1);
-  // table [G0 | G1 | 1-G0 | 1-G1]
-  std::vector<elt_t> Gt(4 * logv + 1);
-  const elt_t* G0 = (const elt_t*)h_G0;
-  const elt_t* G1 = (const elt_t*)h_G1;
-  for (size_t l = 0; l < logv; ++l) {
-    Gt[l] = G0[l];
-    Gt[logv + l] = G1[l];
-    Gt[2 * logv + l] = field == LFGPU_FIELD_GF2_128 ? gf_add(one, G0[l]) : fp_sub(one, G0[l]);
-    Gt[3 * logv + l] = field == LFGPU_FIELD_GF2_128 ? gf_add(one, G1[l]) : fp_sub(one, G1[l]);
-  }
   const size_t n = q->n;
   const u32 nb = (u32)((n + QD_THREADS - 1) / QD_THREADS);
   void* sc = nullptr;
-  LF_TRY(lf_scratch3(c, q->nv * 16 + Gt.size() * 16 + (size_t)nb * 4 + 256, &sc));
+  LF_TRY(lf_scratch3(c, q->nv * 16 + (size_t)nb * 4 + 256, &sc));
   elt_t* d_eq = (elt_t*)sc;
-  elt_t* d_G = d_eq + q->nv;
-  u32* counts = (u32*)(d_G + Gt.size());
+  u32* counts = (u32*)(d_eq + q->nv);
   u32* total = (u32*)((uint8_t*)c->mailbox_d + 192);
-  LF_HIP(c, hipMemcpyAsync(d_G, Gt.data(), Gt.size() * 16, hipMemcpyHostToDevice, c->stream));
-  LF_HIP(c, hipStreamSynchronize(c->stream));  // Gt is a stack-lifetime host buffer
-  elt_t al{alpha[0], alpha[1]}, be{beta[0], beta[1]};
-  QD_DISPATCH(field, raw_eq2_kernel, dim3((u32)((q->nv + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logv,
-              (u32)q->nv, (const elt_t*)d_G, al, one, d_eq);
+  elt_t be{beta[0], beta[1]};
+  LF_TRY(lfgpu_raw_eq2(c, field, logv, q->nv, h_G0, h_G1, alpha, d_eq));
   hipLaunchKernelGGL(bindg_count_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton, counts);
   hipLaunchKernelGGL(bindg_scan_kernel, dim3(1), dim3(1024), 0, c->stream, nb, counts, total);
   if (field == LFGPU_FIELD_GF2_128) {
@@ -355,49 +370,7 @@ extern "C" int lfgpu_qw_scatter(lfgpu_ctx*, int, size_t, const void*, const void
 extern "C" int lfgpu_dense_bind(lfgpu_ctx*, int, size_t, const uint64_t*, const void*, void*);
 extern "C" int lfgpu_hquad_bind_h(lfgpu_ctx*, int, size_t, const void*, const void*, const uint64_t*, int, void*, void*, size_t*);
 
-namespace {
-struct HostField {
-  int field;
-  elt_t one, pts[3], invden[3];
-  elt_t add(elt_t a, elt_t b) const { return field == LFGPU_FIELD_GF2_128 ? gf_add(a, b) : fp_add(a, b); }
-  elt_t sub(elt_t a, elt_t b) const { return field == LFGPU_FIELD_GF2_128 ? gf_add(a, b) : fp_sub(a, b); }
-  elt_t mul(elt_t a, elt_t b) const { return field == LFGPU_FIELD_GF2_128 ? gf_mul(a, b) : fp_mul(a, b); }
-  elt_t inv(elt_t a) const { return field == LFGPU_FIELD_GF2_128 ? h_gf_inv(a) : h_fp_inv(a); }
-  explicit HostField(lfgpu_ctx* c, int f) : field(f) {
-    if (f == LFGPU_FIELD_GF2_128) {  // poly_evaluation_points_ = 0, 1, g (lib/gf2k/gf2_128.h:121-127)
-      one = elt_t{1, 0};
-      pts[0] = elt_t{0, 0};
-      pts[1] = one;
-      pts[2] = lf_gf_ctx(c, 4)->g;
-    } else {  // 0, 1, 2 (lib/algebra/fp_generic.h:114-121)
-      one = h_fp_of_scalar(1);
-      pts[0] = h_fp_of_scalar(0);
-      pts[1] = one;
-      pts[2] = h_fp_of_scalar(2);
-    }
-    for (int i = 0; i < 3; ++i) {
-      elt_t d = one;
-      for (int j = 0; j < 3; ++j)
-        if (j != i) d = mul(d, sub(pts[i], pts[j]));
-      invden[i] = inv(d);
-    }
-  }
-  // Poly<3>::eval_monomial (lib/algebra/poly.h:100-108)
-  elt_t eval_monomial(const elt_t coef[3], elt_t x) const { return add(mul(add(mul(coef[2], x), coef[1]), x), coef[0]); }
-  // value at x of the quadratic through (pts[i], ev[i]) = Poly<3>::eval_lagrange (poly.h:72-98)
-  elt_t eval_lagrange(const elt_t ev[3], elt_t x) const {
-    elt_t acc{0, 0};
-    if (field != LFGPU_FIELD_GF2_128) acc = pts[0];
-    for (int i = 0; i < 3; ++i) {
-      elt_t num = one;
-      for (int j = 0; j < 3; ++j)
-        if (j != i) num = mul(num, sub(x, pts[j]));
-      acc = add(acc, mul(ev[i], mul(num, invden[i])));
-    }
-    return acc;
-  }
-};
-}  // namespace
+#include "hostfield.h"
 
 extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
                                     const uint64_t beta[2], size_t logw, size_t nw, void* d_W, const uint64_t wc_in[2][2],

@@ -1,0 +1,746 @@
+// zk.hip -- host driver of the ZK prover over the device kernels (include/lfgpu_zk.h).
+//
+// Host control flow restated from the reference (no reference code is linked or copied):
+//   Transcript / FSPRF                 lib/random/transcript.h:33-190, lib/random/random.h:57-105
+//   CircuitRep::from_bytes (LFC1)      lib/proto/circuit_reader.h:55-233, circuit_writer.h:103-114
+//   ZkProver::commit / fill_pad        lib/zk/zk_prover.h:72-96,152-188
+//   ZkProver::prove                    lib/zk/zk_prover.h:98-149
+//   ProverLayers::prove (padded)       lib/sumcheck/prover_layers.h:106-183,320-344
+//   ZkCommon::verifier_constraints     lib/zk/zk_common.h:49-136,406-439
+//   LigeroProver::prove                lib/ligero/ligero_prover.h:84-146, inner_product_vector ligero_param.h:382-421
+//   ZkProof::write                     lib/zk/zk_proof.h:90-185
+// Every data-parallel step is a kernel behind lfgpu.h (eval_quad, sumcheck_layer, raw_eq2, ligero_*); what runs
+// here is the sequential bookkeeping the reference also keeps on the host.  This file has no device code.
+#include <chrono>
+#include <memory>
+
+#include "../../include/lfgpu_zk.h"
+#include "fs_crypto.h"
+#include "hostfield.h"
+
+extern "C" int lfgpu_raw_eq2(lfgpu_ctx*, int, size_t, size_t, const void*, const void*, const uint64_t*, void*);
+
+namespace {
+constexpr size_t kMaxBindings = 40;  // Proof::kMaxBindings (lib/sumcheck/circuit.h:84)
+
+}  // namespace
+
+// ------------------------------------------------------------------ built-in transcript
+struct lfgpu_transcript {  // Transcript + FSPRF (lib/random/transcript.h:33-190)
+  Sha256 sha;
+  bool prf = false;
+  Aes256 aes;
+  u64 nblock = 0;
+  uint8_t saved[16];
+  size_t rdptr = 16;
+  void upd(const uint8_t* p, size_t n) {
+    prf = false;  // any write invalidates the PRF (:174-178)
+    sha.update(p, n);
+  }
+  void tag_len(uint8_t tag, u64 n) {
+    uint8_t h[9] = {tag};
+    for (int i = 0; i < 8; ++i) h[1 + i] = (uint8_t)(n >> (8 * i));
+    upd(h, 9);
+  }
+  void write_bytes(const uint8_t* d, size_t n) {  // tag 0 || u64 length || bytes (:115-120)
+    tag_len(0, n);
+    if (n) upd(d, n);
+  }
+  void write_elt(const uint8_t* e) {  // tag 1 || image (:136-140)
+    const uint8_t t = 1;
+    upd(&t, 1);
+    upd(e, 16);
+  }
+  void write_elt_array(const uint8_t* e, size_t n) {  // tag 2 || u64 count || images (:144-152)
+    tag_len(2, n);
+    if (n) upd(e, 16 * n);
+  }
+  void bytes(uint8_t* out, size_t n) {
+    if (!prf) {  // key = SHA-256 of a copy of the running state (:160-172)
+      uint8_t key[32];
+      sha.digest(key);
+      aes.set_key(key);
+      nblock = 0;
+      rdptr = 16;
+      prf = true;
+    }
+    while (n) {
+      if (rdptr == 16) {
+        if (n >= 16) {  // whole blocks straight into the output (bulk RandomEngine draws)
+          const size_t nb = n / 16;
+          aes.ctr_blocks(nblock, nb, out);
+          nblock += nb;
+          out += 16 * nb;
+          n -= 16 * nb;
+          continue;
+        }
+        aes.ctr_blocks(nblock, 1, saved);  // FSPRF::refill (:53-60): AES(LE64 counter || 0^8)
+        ++nblock;
+        rdptr = 0;
+      }
+      const size_t take = n < 16 - rdptr ? n : 16 - rdptr;
+      memcpy(out, saved + rdptr, take);
+      out += take; rdptr += take; n -= take;
+    }
+  }
+};
+
+extern "C" {
+lfgpu_transcript* lfgpu_transcript_new(const uint8_t* init, size_t n) {
+  if (n && !init) return nullptr;
+  lfgpu_transcript* t = new (std::nothrow) lfgpu_transcript();
+  if (t) t->write_bytes(init, n);
+  return t;
+}
+void lfgpu_transcript_free(lfgpu_transcript* t) { delete t; }
+void lfgpu_transcript_write_bytes(lfgpu_transcript* t, const uint8_t* d, size_t n) { t->write_bytes(d, n); }
+void lfgpu_transcript_write_elt(lfgpu_transcript* t, const uint8_t* e) { t->write_elt(e); }
+void lfgpu_transcript_write_elt_array(lfgpu_transcript* t, const uint8_t* e, size_t n) { t->write_elt_array(e, n); }
+void lfgpu_transcript_bytes(lfgpu_transcript* t, uint8_t* out, size_t n) { t->bytes(out, n); }
+void lfgpu_sha256(const uint8_t* data, size_t n, uint8_t out[32]) {
+  Sha256 s;
+  s.update(data, n);
+  s.digest(out);
+}
+int lfgpu_crypto_hw(int force_portable) {
+  if (force_portable >= 0) fs_crypto_force_portable(force_portable);
+  return fs_crypto_hw();
+}
+void lfgpu_aes256_ecb_block(const uint8_t key[32], const uint8_t in[16], uint8_t out[16]) {
+  Aes256 a;
+  a.set_key(key);
+  a.encrypt(in, out);
+}
+static void op_write_bytes(void* u, const uint8_t* d, size_t n) { ((lfgpu_transcript*)u)->write_bytes(d, n); }
+static void op_write_elt(void* u, const uint8_t* e) { ((lfgpu_transcript*)u)->write_elt(e); }
+static void op_write_arr(void* u, const uint8_t* e, size_t n) { ((lfgpu_transcript*)u)->write_elt_array(e, n); }
+static void op_bytes(void* u, uint8_t* o, size_t n) { ((lfgpu_transcript*)u)->bytes(o, n); }
+static void* op_clone(void* u) {  // Transcript::clone copies the hash state only; the PRF restarts (:95-99)
+  lfgpu_transcript* t = new (std::nothrow) lfgpu_transcript();
+  if (t) t->sha = ((lfgpu_transcript*)u)->sha;
+  return t;
+}
+static void op_free(void* u) { delete (lfgpu_transcript*)u; }
+void lfgpu_transcript_get_ops(lfgpu_transcript* t, lfgpu_transcript_ops* ops) {
+  ops->user = t;
+  ops->write_bytes = op_write_bytes;
+  ops->write_elt = op_write_elt;
+  ops->write_elt_array = op_write_arr;
+  ops->gen_bytes = op_bytes;
+  ops->clone = op_clone;
+  ops->free_clone = op_free;
+}
+}  // extern "C"
+
+namespace {
+// the caller's transcript seen through the hooks, plus the samplers built on RandomEngine::bytes
+struct Ts {
+  const lfgpu_transcript_ops* o;
+  void* u;
+  void write_bytes(const uint8_t* d, size_t n) const { o->write_bytes(u, d, n); }
+  void write_elt(elt_t e) const { o->write_elt(u, (const uint8_t*)&e); }  // GF2_128 image = the 16 LE bytes
+  void write_array(const elt_t* e, size_t n) const { o->write_elt_array(u, (const uint8_t*)e, n); }
+  elt_t elt() const {  // GF2_128::sample (lib/gf2k/gf2_128.h:182-190)
+    elt_t e;
+    o->gen_bytes(u, (uint8_t*)&e, 16);
+    return e;
+  }
+  size_t nat(size_t n) const {  // RandomEngine::nat (lib/random/random.h:57-87): rejection sampling under a bit mask
+    size_t l = 0, mask = 0;
+    for (size_t nn = n; nn; nn >>= 8) ++l;
+    while ((n & mask) != n) mask = (mask << 1) | 1;
+    for (;;) {
+      uint8_t b[8] = {0};
+      o->gen_bytes(u, b, l);
+      size_t r = 0;
+      for (size_t i = 0; i < l; ++i) r |= (size_t)b[i] << (8 * i);
+      r &= mask;
+      if (r < n) return r;
+    }
+  }
+  void choose(size_t n, size_t k, size_t* res) const {  // RandomEngine::choose (:89-105): partial Fisher-Yates
+    std::vector<size_t> A(n);
+    for (size_t i = 0; i < n; ++i) A[i] = i;
+    for (size_t i = 0; i < k; ++i) {
+      const size_t j = i + nat(n - i);
+      std::swap(A[i], A[j]);
+      res[i] = A[i];
+    }
+  }
+};
+
+inline size_t layer_size(size_t logw) { return 4 * logw + 3; }  // PadLayout::layer_size (zk_common.h:210-222)
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+// ------------------------------------------------------------------ circuit
+struct lfgpu_circuit {
+  lfgpu_ctx* c = nullptr;
+  lfgpu_circuit_info info{};
+  struct Layer {
+    size_t logw, nw, nterms;
+    lfgpu_quad* q;
+  };
+  std::vector<Layer> layers;
+  ~lfgpu_circuit() {
+    for (auto& l : layers)
+      if (l.q) lfgpu_quad_free(l.q);
+  }
+};
+
+extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t len, lfgpu_circuit** out) {
+  if (!c || !b || !out) return LFGPU_ERR_ARG;
+  size_t pos = 0;
+  auto need = [&](size_t n) { return len - pos >= n; };
+  auto num = [&](size_t* v) {  // 3-byte little-endian (circuit_reader.h:217-233)
+    if (!need(3)) return false;
+    *v = (size_t)b[pos] | (size_t)b[pos + 1] << 8 | (size_t)b[pos + 2] << 16;
+    pos += 3;
+    return true;
+  };
+  if (len < 1 || b[0] != 1) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: bad version byte");
+  pos = 1;
+  size_t fid, nv, nc, npub, sfb, nin, nl, nk;
+  if (!num(&fid) || !num(&nv) || !num(&nc) || !num(&npub) || !num(&sfb) || !num(&nin) || !num(&nl) || !num(&nk))
+    return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated header");
+  if (fid != 4) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "LFC1: field id %zu (only GF2_128 = 4 is supported by the ZK driver)", fid);
+  if (nc != 1) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "LFC1: nc = %zu copies (logc must be 0)", nc);
+  if (npub > nin || nv == 0 || nl == 0) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: inconsistent header");
+  if (!need(16 * nk)) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated constant table");
+  std::vector<elt_t> kvec(nk ? nk : 1);
+  memcpy(kvec.data(), b + pos, 16 * nk);  // GF2_128 of_bytes_field image: 16 little-endian bytes
+  pos += 16 * nk;
+  std::unique_ptr<lfgpu_circuit> C(new lfgpu_circuit());
+  C->c = c;
+  size_t nterms = 0, nout = nv;
+  std::vector<u32> g, h0, h1, vi;
+  for (size_t ly = 0; ly < nl; ++ly) {
+    size_t logw, nw, nq;
+    if (!num(&logw) || !num(&nw) || !num(&nq)) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated layer header");
+    if (logw > kMaxBindings || nw == 0 || nw > ((size_t)1 << logw) || !need(12 * nq))
+      return lf_fail(c, LFGPU_ERR_ARG, "LFC1: bad layer %zu", ly);
+    g.resize(nq); h0.resize(nq); h1.resize(nq); vi.resize(nq);
+    int64_t acc[3] = {0, 0, 0};
+    for (size_t t = 0; t < nq; ++t) {
+      size_t v[4];
+      for (int j = 0; j < 4; ++j) num(&v[j]);
+      for (int j = 0; j < 3; ++j) {  // delta with the sign in the LSB (circuit_writer.h:103-114)
+        const int64_t d = (int64_t)(v[j] >> 1);
+        acc[j] += (v[j] & 1) ? -d : d;
+      }
+      if (acc[0] < 0 || (size_t)acc[0] >= nout || acc[1] < 0 || (size_t)acc[1] >= nw || acc[2] < 0 || (size_t)acc[2] >= nw || v[3] >= nk)
+        return lf_fail(c, LFGPU_ERR_ARG, "LFC1: layer %zu term %zu out of range", ly, t);
+      g[t] = (u32)acc[0]; h0[t] = (u32)acc[1]; h1[t] = (u32)acc[2]; vi[t] = (u32)v[3];
+    }
+    lfgpu_circuit::Layer L{logw, nw, nq, nullptr};
+    LF_TRY(lfgpu_quad_upload(c, LFGPU_FIELD_GF2_128, nq, g.data(), h0.data(), h1.data(), vi.data(), nk, kvec.data(), nout, &L.q));
+    C->layers.push_back(L);
+    nterms += nq;
+    nout = nw;
+  }
+  if (!need(32) || pos + 32 != len) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: bad trailer");
+  if (nout != nin) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: input layer width %zu != ninputs %zu", nout, nin);
+  lfgpu_circuit_info& I = C->info;
+  I.field = LFGPU_FIELD_GF2_128;
+  I.nv = nv; I.nc = nc; I.npub_in = npub; I.subfield_boundary = sfb; I.ninputs = nin; I.nl = nl; I.nterms = nterms;
+  I.logv = lf_log2(nv);
+  memcpy(I.id, b + pos, 32);
+  *out = C.release();
+  return LFGPU_OK;
+}
+extern "C" int lfgpu_circuit_get_info(const lfgpu_circuit* C, lfgpu_circuit_info* info) {
+  if (!C || !info) return LFGPU_ERR_ARG;
+  *info = C->info;
+  return LFGPU_OK;
+}
+extern "C" int lfgpu_circuit_layer_info(const lfgpu_circuit* C, size_t layer, size_t* logw, size_t* nw, size_t* nterms) {
+  if (!C || layer >= C->layers.size()) return LFGPU_ERR_ARG;
+  if (logw) *logw = C->layers[layer].logw;
+  if (nw) *nw = C->layers[layer].nw;
+  if (nterms) *nterms = C->layers[layer].nterms;
+  return LFGPU_OK;
+}
+extern "C" int lfgpu_circuit_free(lfgpu_circuit* C) {
+  if (!C) return LFGPU_ERR_ARG;
+  delete C;
+  return LFGPU_OK;
+}
+
+// ------------------------------------------------------------------ ZkProver
+struct lfgpu_zk_prover {
+  lfgpu_ctx* c = nullptr;
+  const lfgpu_circuit* C = nullptr;
+  lfgpu_ligero_param param{};
+  size_t npub = 0, n_witness = 0, pad_size = 0;
+  struct LayerPad {  // Proof-shaped pad (zk_prover.h:152-188): hp[hand][round] = {t0, t2}, wc[2]
+    std::vector<elt_t> hp[2];
+    elt_t wc[2];
+  };
+  std::vector<LayerPad> pad, proof;  // proof: the padded (transmitted) values, same shape
+  std::vector<elt_t> aux;            // ProofAux::bound_quad per layer
+  std::vector<size_t> lqc;
+  lfgpu_ligero_prover* lp = nullptr;
+  uint8_t root[32] = {0};
+  std::vector<elt_t> y_ldt, y_dot, y_q0, y_q2, req;
+  std::vector<uint8_t> nonces, path;
+  size_t npath = 0;
+  bool have_proof = false;
+  // subfield solver for the wire format (GF2_128::solve, lib/gf2k/gf2_128.h:496-508): echelon rows of beta
+  struct Row {
+    elt_t v;
+    u32 comb;
+    int pivot;
+  };
+  std::vector<Row> ech;
+  // device buffers of the layer inputs (eval_circuit) and the circuit output
+  std::vector<void*> d_in;
+  void* d_V = nullptr;
+  double ms[6] = {0, 0, 0, 0, 0, 0};
+  ~lfgpu_zk_prover() {
+    if (lp) lfgpu_ligero_free(lp);
+    for (void* p : d_in)
+      if (p) (void)hipFree(p);
+    if (d_V) (void)hipFree(d_V);
+  }
+};
+
+namespace {
+int top_bit(elt_t v) { return v.hi ? 64 + (63 - __builtin_clzll(v.hi)) : v.lo ? 63 - __builtin_clzll(v.lo) : -1; }
+bool bit_of(elt_t v, int j) { return j >= 64 ? (v.hi >> (j - 64)) & 1 : (v.lo >> j) & 1; }
+
+void build_subfield_solver(lfgpu_zk_prover* zk, const GfHostCtx* g) {
+  for (unsigned i = 0; i < g->sub_bits; ++i) {
+    elt_t v = g->beta[i];
+    u32 comb = 1u << i;
+    for (const auto& r : zk->ech)
+      if (bit_of(v, r.pivot)) {
+        v = gf_add(v, r.v);
+        comb ^= r.comb;
+      }
+    zk->ech.push_back({v, comb, top_bit(v)});  // beta is a basis: v != 0
+  }
+}
+// (residue, coordinates): residue == 0 iff e lies in the subfield, and then e = sum_i bit_i(u) beta_i
+std::pair<elt_t, u32> solve_subfield(const lfgpu_zk_prover* zk, elt_t e) {
+  u32 u = 0;
+  for (const auto& r : zk->ech)
+    if (bit_of(e, r.pivot)) {
+      e = gf_add(e, r.v);
+      u ^= r.comb;
+    }
+  return {e, u};
+}
+
+struct RoundCtx {  // round_h of the padded prover (prover_layers.h:320-329): transmit poly - pad
+  const HostField* F;
+  const Ts* tst;
+  const lfgpu_zk_prover::LayerPad* pad;
+  lfgpu_zk_prover::LayerPad* out;
+};
+void zk_round_cb(void* user, size_t hand, size_t rnd, const uint64_t ev[3][2], uint64_t chal[2]) {
+  RoundCtx* r = (RoundCtx*)user;
+  const elt_t t0 = r->F->sub(elt_t{ev[0][0], ev[0][1]}, r->pad->hp[hand][2 * rnd]);
+  const elt_t t2 = r->F->sub(elt_t{ev[2][0], ev[2][1]}, r->pad->hp[hand][2 * rnd + 1]);
+  r->out->hp[hand][2 * rnd] = t0;
+  r->out->hp[hand][2 * rnd + 1] = t2;
+  r->tst->write_elt(t0);
+  r->tst->write_elt(t2);
+  const elt_t c = r->tst->elt();
+  chal[0] = c.lo;
+  chal[1] = c.hi;
+}
+}  // namespace
+
+extern "C" int lfgpu_zk_prover_new(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc,
+                                   lfgpu_zk_prover** out) {
+  if (!c || !C || !out || C->c != c) return LFGPU_ERR_ARG;
+  std::unique_ptr<lfgpu_zk_prover> zk(new lfgpu_zk_prover());
+  zk->c = c;
+  zk->C = C;
+  zk->npub = C->info.npub_in;
+  zk->n_witness = C->info.ninputs - C->info.npub_in;
+  for (const auto& l : C->layers) zk->pad_size += layer_size(l.logw);
+  // ZkProof: LigeroParam(n_witness + pad_size, nl quadratic constraints, rate, nreq[, block_enc]) (zk_proof.h:63-76)
+  LF_TRY(lfgpu_ligero_param_init(&zk->param, LFGPU_FIELD_GF2_128, 4, zk->n_witness + zk->pad_size, C->info.nl, rateinv, nreq, block_enc));
+  const GfHostCtx* g = lf_gf_ctx(c, 4);
+  if (!g) return LFGPU_ERR_ARG;
+  build_subfield_solver(zk.get(), g);
+  LF_HIP(c, hipSetDevice(c->device));
+  zk->d_in.assign(C->layers.size(), nullptr);
+  for (size_t l = 0; l < C->layers.size(); ++l)
+    if (hipMalloc(&zk->d_in[l], C->layers[l].nw * 16) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "zk: layer %zu inputs", l);
+  if (hipMalloc(&zk->d_V, C->info.nv * 16) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "zk: outputs");
+  *out = zk.release();
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_zk_prover_param(const lfgpu_zk_prover* zk, lfgpu_ligero_param* p) {
+  if (!zk || !p) return LFGPU_ERR_ARG;
+  *p = zk->param;
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_fn rng, void* rng_user,
+                               const lfgpu_transcript_ops* ts, uint8_t root_out[32]) {
+  if (!zk || !h_W || !rng || !ts) return LFGPU_ERR_ARG;
+  const double t0 = now_ms();
+  lfgpu_ctx* c = zk->c;
+  const lfgpu_circuit* C = zk->C;
+  const size_t nl = C->layers.size();
+  auto draw = [&]() {
+    elt_t e;
+    rng(rng_user, (uint8_t*)&e, 16);
+    return e;
+  };
+  // witness = private inputs || pad; fill_pad draws, per layer: (t0, t2) for hand 0 then hand 1 of every round,
+  // then wc0, wc1 and stores wc0*wc1 (zk_prover.h:152-188, logc = 0)
+  std::vector<elt_t> Wv(zk->param.nw);
+  memcpy(Wv.data(), (const elt_t*)h_W + zk->npub, zk->n_witness * 16);
+  zk->pad.assign(nl, {});
+  zk->lqc.assign(3 * nl, 0);
+  size_t pi = zk->n_witness;
+  for (size_t ly = 0; ly < nl; ++ly) {
+    const size_t logw = C->layers[ly].logw;
+    auto& P = zk->pad[ly];
+    P.hp[0].resize(2 * logw);
+    P.hp[1].resize(2 * logw);
+    size_t w = pi;
+    for (size_t j = 0; j < logw; ++j)
+      for (int h = 0; h < 2; ++h) {
+        P.hp[h][2 * j] = draw();
+        P.hp[h][2 * j + 1] = draw();
+        Wv[w++] = P.hp[h][2 * j];
+        Wv[w++] = P.hp[h][2 * j + 1];
+      }
+    P.wc[0] = draw();
+    P.wc[1] = draw();
+    Wv[w++] = P.wc[0];
+    Wv[w++] = P.wc[1];
+    Wv[w++] = gf_mul(P.wc[0], P.wc[1]);
+    const size_t cp = pi + 4 * logw;  // setup_lqc (zk_common.h:149-160): claim_pad(0..2)
+    zk->lqc[3 * ly] = cp;
+    zk->lqc[3 * ly + 1] = cp + 1;
+    zk->lqc[3 * ly + 2] = cp + 2;
+    pi += layer_size(logw);
+  }
+  if (pi != zk->param.nw) return lf_fail(c, LFGPU_ERR_ASSERT, "zk_commit: witness layout");
+  const size_t sfb = C->info.subfield_boundary >= zk->npub ? C->info.subfield_boundary - zk->npub : 0;
+  if (zk->lp) {
+    lfgpu_ligero_free(zk->lp);
+    zk->lp = nullptr;
+  }
+  zk->have_proof = false;
+  LF_TRY(lfgpu_ligero_commit(c, LFGPU_FIELD_GF2_128, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), rng, rng_user, zk->root, &zk->lp));
+  ts->write_bytes(ts->user, zk->root, 32);  // LigeroTranscript::write_commitment
+  if (root_out) memcpy(root_out, zk->root, 32);
+  zk->ms[0] = now_ms() - t0;
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_transcript_ops* tso, int* ok) {
+  if (!zk || !h_W || !tso || !ok) return LFGPU_ERR_ARG;
+  lfgpu_ctx* c = zk->c;
+  if (!zk->lp) return lf_fail(c, LFGPU_ERR_ARG, "zk_prove: must run commit before prove");
+  const double t_start = now_ms();
+  const lfgpu_circuit* C = zk->C;
+  const lfgpu_circuit_info& I = C->info;
+  const size_t nl = C->layers.size();
+  const elt_t* W = (const elt_t*)h_W;
+  const HostField F(c, LFGPU_FIELD_GF2_128);
+  const Ts ts{tso, tso->user};
+  *ok = 0;
+  zk->have_proof = false;
+  LF_HIP(c, hipSetDevice(c->device));
+
+  // initialize_sumcheck_fiat_shamir (zk_common.h:163-180)
+  ts.write_bytes(I.id, 32);
+  for (size_t i = 0; i < zk->npub; ++i) ts.write_elt(W[i]);
+  ts.write_elt(elt_t{0, 0});
+  {
+    std::vector<uint8_t> z(I.nterms, 0);
+    ts.write_bytes(z.data(), z.size());
+  }
+  void* cl = tso->clone(tso->user);
+  if (!cl) return lf_fail(c, LFGPU_ERR_NOMEM, "zk_prove: transcript clone");
+  struct CloneGuard {
+    const lfgpu_transcript_ops* o;
+    void* u;
+    ~CloneGuard() { o->free_clone(u); }
+  } cg{tso, cl};
+  const Ts tst{tso, cl};
+
+  // eval_circuit (prover_layers.h:52-104): layer inputs stay resident for the sumcheck
+  double t0 = now_ms();
+  LF_HIP(c, hipMemcpyAsync(zk->d_in[nl - 1], W, I.ninputs * 16, hipMemcpyHostToDevice, c->stream));
+  for (size_t l = nl; l-- > 0;) {
+    void* dst = l ? zk->d_in[l - 1] : zk->d_V;
+    int good = 0;
+    LF_TRY(lfgpu_eval_quad(C->layers[l].q, C->layers[l].nw, zk->d_in[l], dst, &good));
+    if (!good) return LFGPU_OK;  // an assert-zero term is non-zero: eval_circuit returns nullptr
+  }
+  {
+    std::vector<elt_t> V(I.nv);
+    LF_HIP(c, hipMemcpyAsync(V.data(), zk->d_V, I.nv * 16, hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(c, hipStreamSynchronize(c->stream));
+    for (const elt_t& v : V)
+      if (v.lo | v.hi) return LFGPU_OK;  // "V->v_[i] != F.zero()"
+  }
+  zk->ms[2] = now_ms() - t0;
+
+  // padded sumcheck (ProverLayers::prove with pad, transcript copy tst)
+  t0 = now_ms();
+  zk->proof.assign(nl, {});
+  zk->aux.assign(nl, elt_t{0, 0});
+  std::vector<elt_t> G[2];
+  {
+    for (size_t i = 0; i < kMaxBindings; ++i) (void)tst.elt();  // begin_circuit: Q then G (transcript_sumcheck.h:49-52)
+    G[0].resize(kMaxBindings);
+    for (size_t i = 0; i < kMaxBindings; ++i) G[0][i] = tst.elt();
+    G[1] = G[0];
+  }
+  size_t logv = I.logv;
+  uint64_t WC[2][2] = {{0, 0}, {0, 0}};
+  std::vector<uint64_t> gout;
+  for (size_t ly = 0; ly < nl; ++ly) {
+    const auto& L = C->layers[ly];
+    const elt_t alpha = tst.elt(), beta = tst.elt();
+    auto& P = zk->proof[ly];
+    P.hp[0].resize(2 * L.logw);
+    P.hp[1].resize(2 * L.logw);
+    RoundCtx rc{&F, &tst, &zk->pad[ly], &P};
+    gout.assign(4 * L.logw + 2, 0);
+    uint64_t wc_out[2][2], bq[2];
+    const uint64_t al[2] = {alpha.lo, alpha.hi}, be[2] = {beta.lo, beta.hi};
+    LF_TRY(lfgpu_sumcheck_layer(L.q, logv, G[0].data(), G[1].data(), al, be, L.logw, L.nw, zk->d_in[ly], WC, zk_round_cb, &rc, wc_out,
+                                gout.data(), bq));
+    // end_layer (:331-344): transmit wc - pad
+    P.wc[0] = F.sub(elt_t{wc_out[0][0], wc_out[0][1]}, zk->pad[ly].wc[0]);
+    P.wc[1] = F.sub(elt_t{wc_out[1][0], wc_out[1][1]}, zk->pad[ly].wc[1]);
+    tst.write_array(P.wc, 2);
+    zk->aux[ly] = elt_t{bq[0], bq[1]};
+    memcpy(WC, wc_out, sizeof(WC));
+    for (int h = 0; h < 2; ++h) {
+      G[h].assign(kMaxBindings, elt_t{0, 0});
+      for (size_t r = 0; r < L.logw; ++r) G[h][r] = elt_t{gout[(h * L.logw + r) * 2], gout[(h * L.logw + r) * 2 + 1]};
+    }
+    logv = L.logw;
+  }
+  zk->ms[3] = now_ms() - t0;
+
+  // verifier_constraints with aux (zk_common.h:49-136): replay the verifier symbolically on the ORIGINAL transcript
+  t0 = now_ms();
+  struct Term {
+    size_t c, w;
+    elt_t k;
+  };
+  std::vector<Term> a;
+  size_t ci = 0;
+  elt_t alpha_in;
+  std::vector<elt_t> gh[2];
+  {
+    for (size_t i = 0; i < kMaxBindings; ++i) (void)ts.elt();
+    for (size_t i = 0; i < kMaxBindings; ++i) (void)ts.elt();  // G: only the hand bindings of the last layer are used below
+    elt_t claims[2] = {elt_t{0, 0}, elt_t{0, 0}};
+    size_t pi = zk->n_witness;
+    std::vector<elt_t> sym;
+    for (size_t ly = 0; ly < nl; ++ly) {
+      const size_t logw = C->layers[ly].logw;
+      const elt_t alpha = ts.elt();
+      (void)ts.elt();  // beta
+      const size_t n = 3 + layer_size(logw);  // ovp_layer_size
+      elt_t known{0, 0};
+      sym.assign(n, elt_t{0, 0});
+      auto axpy = [&](size_t var, elt_t kv, elt_t k) {
+        known = F.add(known, F.mul(k, kv));
+        sym[var] = F.add(sym[var], k);
+      };
+      axpy(0, claims[0], F.one);  // ConstraintBuilder::first
+      axpy(1, claims[1], alpha);
+      gh[0].assign(logw, elt_t{0, 0});
+      gh[1].assign(logw, elt_t{0, 0});
+      const auto& P = zk->proof[ly];
+      for (size_t rnd = 0; rnd < logw; ++rnd)
+        for (int hand = 0; hand < 2; ++hand) {
+          const size_t r = 2 * rnd + hand;
+          const elt_t t0e = P.hp[hand][2 * rnd], t2e = P.hp[hand][2 * rnd + 1];
+          ts.write_elt(t0e);
+          ts.write_elt(t2e);
+          const elt_t chal = ts.elt();
+          gh[hand][rnd] = chal;
+          elt_t lag[3];  // dot_interpolation coefficients: p(chal) = sum_i lag[i] p(P_i)
+          for (int i = 0; i < 3; ++i) {
+            elt_t num = F.one;
+            for (int j = 0; j < 3; ++j)
+              if (j != i) num = F.mul(num, F.sub(chal, F.pts[j]));
+            lag[i] = F.mul(num, F.invden[i]);
+          }
+          axpy(3 + 2 * r, t0e, F.one);  // p(1) = claim - p(0)  (axmy == axpy in characteristic 2)
+          known = F.mul(known, lag[1]);  // scale
+          for (auto& s : sym)
+            if (s.lo | s.hi) s = F.mul(s, lag[1]);
+          axpy(3 + 2 * r, t0e, lag[0]);
+          axpy(3 + 2 * r + 1, t2e, lag[2]);
+        }
+      const elt_t eqq = zk->aux[ly];  // Eq::eval with logc = 0 is 1
+      const size_t cp = 3 + 4 * logw;  // finalize
+      sym[cp] = F.add(sym[cp], F.mul(eqq, P.wc[1]));
+      sym[cp + 1] = F.add(sym[cp + 1], F.mul(eqq, P.wc[0]));
+      sym[cp + 2] = F.add(sym[cp + 2], eqq);
+      for (size_t i = ly == 0 ? 3 : 0; i < n; ++i) a.push_back({ci, pi + i - 3, sym[i]});
+      ++ci;
+      ts.write_array(P.wc, 2);
+      claims[0] = P.wc[0];
+      claims[1] = P.wc[1];
+      pi += layer_size(logw);
+    }
+    alpha_in = ts.elt();
+    a.push_back({ci, pi - 3, F.one});  // input_constraint (zk_common.h:406-439): claims of the input layer
+    a.push_back({ci, pi - 2, alpha_in});
+    ++ci;
+  }
+  const size_t nconstraints = ci, dense_c = ci - 1;
+  // dense part of the input constraint: EQ(g0, i) + alpha EQ(g1, i) over the inputs, on the device
+  const lfgpu_ligero_param& p = zk->param;
+  std::vector<elt_t> A(p.nwqrow * p.w, elt_t{0, 0});
+  std::vector<elt_t> bi(zk->n_witness);
+  {
+    const size_t logn = C->layers[nl - 1].logw;
+    void* d_eq = nullptr;
+    LF_TRY(lf_scratch3(c, I.ninputs * 16, &d_eq));
+    std::vector<elt_t> g0(logn ? logn : 1, elt_t{0, 0}), g1(logn ? logn : 1, elt_t{0, 0});
+    for (size_t i = 0; i < logn; ++i) {
+      g0[i] = gh[0][i];
+      g1[i] = gh[1][i];
+    }
+    const uint64_t al[2] = {alpha_in.lo, alpha_in.hi};
+    LF_TRY(lfgpu_raw_eq2(c, LFGPU_FIELD_GF2_128, logn, I.ninputs, g0.data(), g1.data(), al, d_eq));
+    if (zk->n_witness) {
+      LF_HIP(c, hipMemcpyAsync(bi.data(), (const elt_t*)d_eq + zk->npub, zk->n_witness * 16, hipMemcpyDeviceToHost, c->stream));
+      LF_HIP(c, hipStreamSynchronize(c->stream));
+    }
+  }
+  zk->ms[4] = now_ms() - t0;
+
+  // LigeroProver::prove (ligero_prover.h:84-146)
+  t0 = now_ms();
+  {
+    uint8_t hash_of_A[32] = {0xde, 0xad, 0xbe, 0xef};  // zk_prover.h:143
+    ts.write_bytes(hash_of_A, 32);
+    std::vector<elt_t> u_ldt(p.nwqrow);
+    for (auto& e : u_ldt) e = ts.elt();
+    zk->y_ldt.assign(p.block, elt_t{0, 0});
+    LF_TRY(lfgpu_ligero_low_degree_proof(zk->lp, u_ldt.data(), zk->y_ldt.data()));
+    std::vector<elt_t> alphal(nconstraints), alphaq(3 * p.nq);
+    for (auto& e : alphal) e = ts.elt();
+    for (auto& e : alphaq) e = ts.elt();
+    // inner_product_vector (ligero_param.h:382-421)
+    for (size_t w = 0; w < zk->n_witness; ++w) A[w] = gf_mul(alphal[dense_c], bi[w]);
+    for (const Term& t : a) A[t.w] = gf_add(A[t.w], gf_mul(t.k, alphal[t.c]));
+    const size_t base = p.nwrow * p.w;
+    const size_t Ax = base, Ay = base + p.nqtriples * p.w, Az = base + 2 * p.nqtriples * p.w;
+    for (size_t iw = 0; iw < p.nq; ++iw) {
+      const size_t off[3] = {Ax + iw, Ay + iw, Az + iw};
+      for (int j = 0; j < 3; ++j) {
+        const elt_t aq = alphaq[3 * iw + j];
+        A[off[j]] = gf_add(A[off[j]], aq);
+        const size_t tgt = zk->lqc[3 * iw + j];
+        A[tgt] = gf_add(A[tgt], aq);
+      }
+    }
+    zk->y_dot.assign(p.dblock, elt_t{0, 0});
+    LF_TRY(lfgpu_ligero_dot_proof(zk->lp, A.data(), zk->y_dot.data()));
+    std::vector<elt_t> u_quad(p.nqtriples ? p.nqtriples : 1);
+    for (size_t i = 0; i < p.nqtriples; ++i) u_quad[i] = ts.elt();
+    zk->y_q0.assign(p.r, elt_t{0, 0});
+    zk->y_q2.assign(p.dblock - p.block, elt_t{0, 0});
+    LF_TRY(lfgpu_ligero_quadratic_proof(zk->lp, u_quad.data(), zk->y_q0.data(), zk->y_q2.data()));
+    ts.write_array(zk->y_ldt.data(), zk->y_ldt.size());
+    ts.write_array(zk->y_dot.data(), zk->y_dot.size());
+    ts.write_array(zk->y_q0.data(), zk->y_q0.size());
+    ts.write_array(zk->y_q2.data(), zk->y_q2.size());
+    std::vector<size_t> idx(p.nreq);
+    ts.choose(p.block_ext, p.nreq, idx.data());
+    zk->req.assign(p.nrow * p.nreq, elt_t{0, 0});
+    zk->nonces.assign(p.nreq * 32, 0);
+    const size_t cap = p.nreq * p.mc_pathlen + 1;
+    zk->path.assign(cap * 32, 0);
+    LF_TRY(lfgpu_ligero_open(zk->lp, idx.data(), zk->req.data(), zk->nonces.data(), zk->path.data(), cap, &zk->npath));
+  }
+  zk->ms[5] = now_ms() - t0;
+  zk->ms[1] = now_ms() - t_start;
+  zk->have_proof = true;
+  *ok = 1;
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, size_t cap, size_t* nbytes) {
+  if (!zk || !nbytes) return LFGPU_ERR_ARG;
+  if (!zk->have_proof) return lf_fail(zk->c, LFGPU_ERR_ARG, "zk_proof_write: no proof");
+  std::vector<uint8_t> o;
+  auto pute = [&](elt_t e) { o.insert(o.end(), (const uint8_t*)&e, (const uint8_t*)&e + 16); };
+  auto putsz = [&](size_t g) {  // write_size: 4 bytes LE (zk_proof.h:211-216)
+    for (int i = 0; i < 4; ++i) o.push_back((uint8_t)(g >> (8 * i)));
+  };
+  o.insert(o.end(), zk->root, zk->root + 32);  // write_com
+  for (size_t ly = 0; ly < zk->proof.size(); ++ly) {  // write_sc_proof: p(0) and p(2) of both hands per round, then wc
+    const auto& P = zk->proof[ly];
+    const size_t logw = zk->C->layers[ly].logw;
+    for (size_t wi = 0; wi < logw; ++wi)
+      for (int k = 0; k < 2; ++k) {
+        pute(P.hp[0][2 * wi + k]);
+        pute(P.hp[1][2 * wi + k]);
+      }
+    pute(P.wc[0]);
+    pute(P.wc[1]);
+  }
+  for (elt_t e : zk->y_ldt) pute(e);  // write_com_proof
+  for (elt_t e : zk->y_dot) pute(e);
+  for (elt_t e : zk->y_q0) pute(e);
+  for (elt_t e : zk->y_q2) pute(e);
+  o.insert(o.end(), zk->nonces.begin(), zk->nonces.end());
+  // opened columns: alternating runs of full-field / subfield elements, run-length prefixed (:156-178)
+  constexpr size_t kMaxRunLen = (size_t)1 << 25;
+  const size_t nreq_elts = zk->req.size();
+  size_t ci = 0;
+  bool subfield_run = false;
+  while (ci < nreq_elts) {
+    size_t runlen = 0;
+    while (ci + runlen < nreq_elts && runlen < kMaxRunLen) {
+      const elt_t res = solve_subfield(zk, zk->req[ci + runlen]).first;
+      if (((res.lo | res.hi) == 0) != subfield_run) break;
+      ++runlen;
+    }
+    putsz(runlen);
+    for (size_t i = ci; i < ci + runlen; ++i) {
+      if (subfield_run) {
+        const u32 u = solve_subfield(zk, zk->req[i]).second;  // to_bytes_subfield: 2 bytes LE
+        o.push_back((uint8_t)u);
+        o.push_back((uint8_t)(u >> 8));
+      } else {
+        pute(zk->req[i]);
+      }
+    }
+    ci += runlen;
+    subfield_run = !subfield_run;
+  }
+  putsz(zk->npath);
+  o.insert(o.end(), zk->path.begin(), zk->path.begin() + 32 * zk->npath);
+  *nbytes = o.size();
+  if (buf) {
+    if (cap < o.size()) return lf_fail(zk->c, LFGPU_ERR_ARG, "zk_proof_write: buffer too small (%zu < %zu)", cap, o.size());
+    memcpy(buf, o.data(), o.size());
+  }
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_zk_timings(const lfgpu_zk_prover* zk, double ms[6]) {
+  if (!zk || !ms) return LFGPU_ERR_ARG;
+  memcpy(ms, zk->ms, sizeof(zk->ms));
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_zk_prover_free(lfgpu_zk_prover* zk) {
+  if (!zk) return LFGPU_ERR_ARG;
+  delete zk;
+  return LFGPU_OK;
+}

@@ -7,8 +7,10 @@ sumcheck prover) and stores xz-compressed fixtures under tests/golden/:
   flatsha_nb<N>.zkproof.xz  every component of the full ZK proof (ZkProver commit+prove, rate 7, 132 queries,
                          transcript "test", LCG RandomEngine seed 100): root, padded sumcheck proof, y_ldt, y_dot,
                          y_quad_0, y_quad_2, req, opened nonces, Merkle path
+                         (+ length and SHA-256 of the reference's own wire serialization, ZkProof::write, in the json)
   flatsha_nb<N>.json     sizes + the reference's single-thread timings in this container
 Build container only (needs /root/reference)."""
+import hashlib
 import json
 import lzma
 import os
@@ -34,6 +36,9 @@ def main():
                 with open(dst, "wb") as f:
                     f.write(lzma.compress(data, preset=9 | lzma.PRESET_EXTREME) if comp else data)
                 print(dst, os.path.getsize(dst))
+            wire = open(pre + ".zkwire", "rb").read()  # ZkProof::write bytes: kept as length + SHA-256 only
+            info["zk_wire_bytes"] = len(wire)
+            info["zk_wire_sha256"] = hashlib.sha256(wire).hexdigest()
             with open(os.path.join(OUT, "flatsha_nb%d.json" % nb), "w") as f:
                 json.dump(info, f)
             print(info)

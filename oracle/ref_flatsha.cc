@@ -210,6 +210,9 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 8; ++i) zb.push_back(static_cast<uint8_t>(np >> (8 * i)));
     for (auto& d : zk.com_proof.merkle.path) zb.insert(zb.end(), d.data, d.data + 32);
     dump(prefix + ".zkproof", zb.data(), zb.size());
+    std::vector<uint8_t> wire;  // the reference's own serialization (ZkProof::write, zk_proof.h:90-185)
+    zk.write(wire, Fs);
+    dump(prefix + ".zkwire", wire.data(), wire.size());
   }
   printf("{\"nb\": %zu, \"nl\": %zu, \"ninputs\": %zu, \"npub_in\": %zu, \"nterms\": %zu, \"round_hands\": %zu, \"lfc1_bytes\": %zu, "
          "\"ref_eval_circuit_ms\": %.2f, \"ref_sumcheck_ms\": %.2f, \"zk_nw\": %zu, \"zk_block_enc\": %zu, \"zk_block\": %zu, "

@@ -24,7 +24,7 @@ def pkg():
 
 def test_library_exports_every_declared_symbol(pkg):
     L = pkg.load_library()
-    hdr = open(os.path.join(ROOT, "include", "lfgpu.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "lfgpu.h")).read() + open(os.path.join(ROOT, "include", "lfgpu_zk.h")).read()
     declared = sorted(set(re.findall(r"\b(lfgpu_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 30
     for name in declared:

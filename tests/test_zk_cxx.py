@@ -1,0 +1,135 @@
+"""The C++ host driver of the ZK prover (include/lfgpu_zk.h, csrc/zk.hip).
+
+GPU: lfgpu_zk_commit + lfgpu_zk_prove on the reference's flatsha256 circuits produce the reference's own wire bytes
+(ZkProof::write, lib/zk/zk_proof.h:90-185; length + SHA-256 recorded by oracle/gen_flatsha_fixtures.py from the
+real reference run with the same LCG RandomEngine and transcript seed).
+CPU: the built-in transcript primitives against FIPS vectors / hashlib / the harness transcript."""
+import hashlib
+import json
+import lzma
+import os
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    return load_package()
+
+
+@pytest.mark.parametrize("portable", [0, 1])
+def test_sha256_and_aes256_known_answers(pkg, portable):
+    """both the SHA-NI / AES-NI paths and the portable C++ (csrc/fs_crypto.cc)"""
+    L = pkg.load_library()
+    L.lfgpu_crypto_hw(portable)
+    try:
+        _known_answers(pkg)
+        t = pkg.FsTranscript(b"prf")
+        stream = t.bytes(16 * 37 + 5) + t.bytes(3) + t.bytes(64)  # bulk path, tail, refill
+        t.close()
+        L.lfgpu_crypto_hw(1)
+        t = pkg.FsTranscript(b"prf")
+        assert stream == t.bytes(len(stream))  # one call, portable cipher: same stream
+        t.close()
+    finally:
+        L.lfgpu_crypto_hw(0)
+
+
+def _known_answers(pkg):
+    assert pkg.sha256(b"abc").hex() == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"  # FIPS 180-4 B.1
+    rs = np.random.RandomState(5)
+    for n in (0, 1, 55, 56, 57, 63, 64, 65, 119, 120, 121, 4096, 100003):
+        d = rs.bytes(n)
+        assert pkg.sha256(d) == hashlib.sha256(d).digest(), n
+    key = bytes(range(32))  # FIPS-197 C.3
+    assert pkg.aes256_ecb_block(key, bytes.fromhex("00112233445566778899aabbccddeeff")).hex() == "8ea2b7ca516745bfeafc49904b496089"
+
+
+def test_builtin_transcript_matches_harness_transcript(pkg):
+    """same byte stream as tests/fs_transcript.py (which is pinned by the reference fixtures) under interleaved
+    writes and reads, including the PRF reset on every write and reads that straddle AES blocks"""
+    from fs_transcript import Transcript
+    a, b = Transcript(b"test"), pkg.FsTranscript(b"test")
+    rs = np.random.RandomState(11)
+    for step in range(60):
+        op = rs.randint(4)
+        if op == 0:
+            d = rs.bytes(rs.randint(0, 200))
+            a.write_bytes(d)
+            b.write_bytes(d)
+        elif op == 1:
+            e = rs.bytes(16)
+            a.write_elt(e)
+            b.write_elt(e)
+        elif op == 2:
+            es = [rs.bytes(16) for _ in range(rs.randint(0, 5))]
+            a.write_array(es)
+            b.write_array(es)
+        for _ in range(rs.randint(1, 4)):
+            n = int(rs.randint(1, 50))
+            assert a.bytes(n) == b.bytes(n), step
+    b.close()
+
+
+def _load(nb):
+    raw = lzma.decompress(open(os.path.join(GOLD, "flatsha_nb%d.lfc1.xz" % nb), "rb").read())
+    W = np.frombuffer(lzma.decompress(open(os.path.join(GOLD, "flatsha_nb%d.w.xz" % nb), "rb").read()), dtype=np.uint64).reshape(-1, 2).copy()
+    info = json.load(open(os.path.join(GOLD, "flatsha_nb%d.json" % nb)))
+    return raw, W, info
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb", [1, 32])
+def test_zk_cxx_driver_emits_reference_wire_bytes(nb):
+    import gpu_util as G
+    import ligero_fixture as lf
+    raw, W, info = _load(nb)
+    want = lzma.decompress(open(os.path.join(GOLD, "flatsha_nb%d.zkproof.xz" % nb), "rb").read())
+    circ = G.pkg.Circuit(G.gpu(), raw)
+    ci = circ.info
+    assert (ci.nl, ci.ninputs, ci.npub_in, ci.nterms) == (info["nl"], info["ninputs"], info["npub_in"], info["nterms"])
+    zk = G.pkg.ZkProver(G.gpu(), circ, 7, 132)
+    assert (zk.param.block_enc, zk.param.nrow, zk.param.nw) == (info["zk_block_enc"], info["zk_nrow"], info["zk_nw"])
+    for rep in range(2):  # the prover object is reusable: a second commit + prove gives the same proof
+        ts = G.pkg.FsTranscript(b"test")
+        rng = lf.LcgRng(100)
+        root = zk.commit(W, rng.bytes, ts)
+        assert root == want[:32]
+        assert zk.prove(W, ts)
+        wire = zk.wire()
+        assert len(wire) == info["zk_wire_bytes"]
+        assert hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"]
+        ts.close()
+    zk.close()
+    circ.close()
+
+
+@pytest.mark.gpu
+def test_zk_cxx_driver_rejects_bad_witness_and_bad_circuits():
+    import gpu_util as G
+    import ligero_fixture as lf
+    raw, W, _ = _load(1)
+    gpu = G.gpu()
+    for bad in (raw[:-1], raw[:100], b"\x02" + raw[1:], raw + b"\x00"):
+        with pytest.raises(G.pkg.LfGpuError):
+            G.pkg.Circuit(gpu, bad)
+    circ = G.pkg.Circuit(gpu, raw)
+    zk = G.pkg.ZkProver(gpu, circ, 7, 132)
+    W2 = W.copy()
+    W2[1:, 0] ^= np.uint64(1)  # break (almost) every wire: the circuit's assert-zero terms / outputs must catch it
+    ts = G.pkg.FsTranscript(b"test")
+    zk.commit(W2, lf.LcgRng(100).bytes, ts)
+    assert zk.prove(W2, ts) is False
+    with pytest.raises(G.pkg.LfGpuError):
+        zk.wire()
+    ts.close()
+    zk.close()
+    circ.close()
