@@ -99,6 +99,61 @@ def ligero_commit_shape(gpu, torch, np, stream, with_cpu):
     return res
 
 
+def zk_prove_flatsha(pkg, gpu, np, nb, with_cpu, reps=3):
+    """BASELINE's first metric, "flatsha256 fp2_128 prove ms" (BM_ShaZK_fp2_128, lib/circuits/sha/
+    flatsha256_circuit_test.cc:510-536: ZkProver commit + prove, rate 7, 132 queries): the library's C++ ZK driver
+    (include/lfgpu_zk.h) on the committed fixture circuit + witness (tests/golden, made by the real reference).  The wire
+    bytes are first checked against the reference's (LCG RandomEngine of the fixture); the timed repetitions use a
+    C-speed engine, as the reference benchmark uses SecureRandomEngine.  CPU figure: the reference prover itself
+    (oracle/_ref/gen_flatsha, single thread) on this host."""
+    import hashlib
+    import lzma
+    import subprocess
+    import tempfile
+    import ligero_fixture as lf
+    gold = os.path.join(ROOT, "tests", "golden")
+    raw = lzma.decompress(open(os.path.join(gold, "flatsha_nb%d.lfc1.xz" % nb), "rb").read())
+    W = np.frombuffer(lzma.decompress(open(os.path.join(gold, "flatsha_nb%d.w.xz" % nb), "rb").read()), dtype=np.uint64).reshape(-1, 2).copy()
+    info = json.load(open(os.path.join(gold, "flatsha_nb%d.json" % nb)))
+    circ = pkg.Circuit(gpu, raw)
+    zk = pkg.ZkProver(gpu, circ, 7, 132)
+    ts = pkg.FsTranscript(b"test")
+    zk.commit(W, lf.LcgRng(100).bytes, ts)
+    ok = zk.prove(W, ts)
+    wire = zk.wire() if ok else b""
+    ts.close()
+    identical = ok and len(wire) == info["zk_wire_bytes"] and hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"]
+    L = gpu.L
+    rng_t = pkg.FsTranscript(b"rng")
+    rng_fn = C.cast(L.lfgpu_transcript_bytes, pkg.RNG_FN)
+    Wp, root, okc = C.c_void_p(W.ctypes.data), (C.c_uint8 * 32)(), C.c_int()
+    best = None
+    for _ in range(reps):
+        ts = pkg.FsTranscript(b"test")
+        ops = ts.ops()
+        t0 = time.perf_counter()
+        gpu._ck(L.lfgpu_zk_commit(zk.h, Wp, rng_fn, rng_t.h, C.byref(ops), root))
+        t1 = time.perf_counter()
+        gpu._ck(L.lfgpu_zk_prove(zk.h, Wp, C.byref(ops), C.byref(okc)))
+        t2 = time.perf_counter()
+        ts.close()
+        cur = {"commit_ms": (t1 - t0) * 1e3, "prove_ms": (t2 - t1) * 1e3, "total_ms": (t2 - t0) * 1e3}
+        if best is None or cur["total_ms"] < best["total_ms"]:
+            best = dict(cur, phases_ms=zk.timings())
+    res = {"sha_blocks": nb, "nterms": info["nterms"], "wire_bytes_identical_to_reference": bool(identical)}
+    res.update(best)
+    gen = os.path.join(ROOT, "oracle", "_ref", "gen_flatsha")
+    if with_cpu and os.path.exists(gen):
+        with tempfile.TemporaryDirectory() as td:
+            r = json.loads(subprocess.check_output([gen, str(nb), os.path.join(td, "x")]).decode())
+        res["cpu_reference"] = {"commit_ms": r["ref_zk_commit_ms"], "prove_ms": r["ref_zk_prove_ms"],
+                                "total_ms": r["ref_zk_commit_ms"] + r["ref_zk_prove_ms"], "cores": 1, "kind": "reference"}
+    rng_t.close()
+    zk.close()
+    circ.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +279,8 @@ def main():
                                    "algo_GBps": 2.0 * nelem * 16 / (ms * 1e-3) / 1e9}
     if rank == 0 and not args.no_secondary:
         out["ligero_commit_flatsha32"] = ligero_commit_shape(gpu, torch, np, stream, not args.no_cpu_baseline)
+        del A  # the ZK path allocates its own buffers
+        out["zk_prove_flatsha256"] = zk_prove_flatsha(pkg, gpu, np, 32, not args.no_cpu_baseline)
     if dist is not None:
         dist.barrier()
     if rank == 0:

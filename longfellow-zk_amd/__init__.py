@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblfgpu.so")
+LIB_PATH = os.environ.get("LFGPU_LIB") or os.path.join(_HERE, "liblfgpu.so")  # LFGPU_LIB: an instrumented build of the same sources
 
 FIELD_GF2_128 = 4  # FieldID, reference lib/proto/circuit_io.h:24-36
 FIELD_FP128 = 6

@@ -130,10 +130,21 @@ int lfgpu_init(int device, lfgpu_ctx** out) {
   c->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_khz = (u64)khz;
   if (hipHostMalloc(&c->mailbox_h, 4096) != hipSuccess || hipMalloc(&c->mailbox_d, 4096) != hipSuccess) {
     delete c;
     return LFGPU_ERR_NOMEM;
   }
+  void* ph = nullptr;
+  if (hipHostMalloc(&ph, 4096, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+    hipHostFree(c->mailbox_h);
+    hipFree(c->mailbox_d);
+    delete c;
+    return LFGPU_ERR_NOMEM;
+  }
+  memset(ph, 0, 4096);
+  c->poll_h = (volatile u64*)ph;
   *out = c;
   return LFGPU_OK;
 }
@@ -147,6 +158,7 @@ int lfgpu_shutdown(lfgpu_ctx* c) {
   if (c->scratch2) hipFree(c->scratch2);
   if (c->scratch3) hipFree(c->scratch3);
   if (c->mailbox_h) hipHostFree(c->mailbox_h);
+  if (c->poll_h) hipHostFree((void*)c->poll_h);
   if (c->mailbox_d) hipFree(c->mailbox_d);
   delete c;
   return LFGPU_OK;

@@ -40,7 +40,13 @@ struct lfgpu_ctx {
   // small pinned host mailbox for results read back every call (roots, partial sums)
   void* mailbox_h = nullptr;
   void* mailbox_d = nullptr;
+  // coherent (fine-grained) pinned words a running kernel writes and the host polls: results of the fused
+  // sumcheck steps come back without a stream synchronisation
+  volatile u64* poll_h = nullptr;
+  u64 poll_seq = 0, poll_next = 0;
+  int resident_state = 0;  // 0 untested, 1 the resident sumcheck kernel may be used, -1 it may not
   int num_cu = 256;
+  u64 wall_khz = 100000;  // rate of wall_clock64() (hipDeviceAttributeWallClockRate)
 };
 
 int lf_fail(lfgpu_ctx* c, int code, const char* fmt, ...);
@@ -70,6 +76,34 @@ elt_t h_fp_inv(elt_t a);
 elt_t h_fp_of_scalar(u64 u);
 const GfHostCtx* lf_gf_ctx(lfgpu_ctx* c, int k);
 elt_t h_lch14_twiddle(const GfHostCtx* g, unsigned i, u64 u);
+
+// fused single-workgroup sumcheck step (sumcheck.hip): [bind of the previous round-hand] -> [QW scatter + the two
+// partial sums of the next one]; results land in c->poll_h = {a0.lo, a0.hi, a2.lo, a2.hi, nh, seq, scalar.lo, scalar.hi, status}; the resident variant reads
+// its challenges from c->poll_h + 64 = {r.lo, r.hi, seq}
+struct ScSmall {
+  int field;
+  int do_bind, bind_hand;
+  elt_t r;
+  int do_eval, eval_hand;
+  uint2* hc_in;   // current HQUAD corners / values
+  elt_t* vc_in;
+  uint2* hc_out;  // destination of the bind (the other half of the ping-pong)
+  elt_t* vc_out;
+  u32 nh;         // HQUAD size before the bind (host-known)
+  elt_t* W[2];    // hand arrays before the bind
+  u32 nW[2];
+  elt_t* Wdst;    // destination of the dense bind (== W[bind_hand] for in place)
+  u64* QW;        // scratch: GF 2 words / Fp 4 limb accumulators per target, then the QW elements
+  const elt_t* fp_pow;  // Fp128: Montgomery images of 2^(32j), j < 5
+};
+int lf_sc_small_step(lfgpu_ctx* c, const ScSmall& a, u64 out[8]);
+int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_W_shared, void* wtmp);
+int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]);
+bool lf_sc_resident_ok(lfgpu_ctx* c);
+int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hcA, void* vcA, void* hcB, void* vcB, size_t nh, void* dW, size_t nw,
+                     void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, const void* fp_pow, size_t logw, void* d_state);
+#define LF_SC_GRID_STATE_BYTES (256 + 4 * 256)
+#define LF_SC_SMALL_MAX 8192  // largest HQUAD / hand array the single-workgroup step takes
 
 static inline unsigned lf_log2(size_t n) {
   unsigned l = 0;

@@ -382,20 +382,32 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   const int field = q->field;
   LF_HIP(c, hipSetDevice(c->device));
   const HostField F(c, field);
-  // device state: HQUAD ping-pong, QW, out-of-place buffer for the first bind of hand 0
+  // device state: HQUAD ping-pong, QW, out-of-place buffer for the first bind of hand 0 (context scratch: no
+  // allocation per layer)
   void* sc = nullptr;
   const size_t nt = q->n;
-  const size_t bytes = 2 * (nt * 8 + nt * 16) + nw * 16 + ((nw + 1) / 2) * 16 + 256;
-  if (hipMalloc(&sc, bytes) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "sumcheck_layer: %zu bytes", bytes);
-  struct Free {
-    void* p;
-    ~Free() { (void)hipFree(p); }
-  } guard{sc};
+  const size_t qw_bytes = nw * (field == LFGPU_FIELD_FP128 ? 32 : 16);  // Fp128 fused steps keep 4 limb words per target
+  const size_t half = ((nw + 1) / 2) * 16;
+  const size_t bytes = 2 * (nt * 8 + nt * 16) + qw_bytes + 4 * half + LF_SC_GRID_STATE_BYTES + 256;
+  LF_TRY(lf_scratch(c, bytes, &sc));
   uint8_t* base = (uint8_t*)sc;
   void* hc[2] = {base, base + nt * 8};
   void* vc[2] = {base + 2 * nt * 8, base + 2 * nt * 8 + nt * 16};
   void* qw = base + 2 * nt * 8 + 2 * nt * 16;
-  void* wtmp = (uint8_t*)qw + nw * 16;
+  void* wtmp = (uint8_t*)qw + qw_bytes;  // 4 half-size hand buffers; the first is the detach buffer of the step paths
+  void* grid_state = (uint8_t*)wtmp + 4 * half;
+  const elt_t* fp_pow = nullptr;
+  if (field == LFGPU_FIELD_FP128) {
+    void* dconst = nullptr;
+    if (!lf_table_lookup(c, "fp:pow2_32j", &dconst)) {
+      elt_t cs[5];  // Montgomery images of 2^(32j)
+      cs[0] = h_fp_of_scalar(1);
+      const elt_t two32 = h_fp_of_scalar(1ull << 32);
+      for (int j = 1; j < 5; ++j) cs[j] = fp_mul(cs[j - 1], two32);
+      LF_TRY(lf_table(c, "fp:pow2_32j", cs, sizeof(cs), &dconst));
+    }
+    fp_pow = (const elt_t*)dconst;
+  }
   size_t nh = 0;
   LF_TRY(lfgpu_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], &nh));
   int cur = 0;
@@ -403,11 +415,121 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   elt_t sum = F.add(elt_t{wc_in[0][0], wc_in[0][1]}, F.mul(al, elt_t{wc_in[1][0], wc_in[1][1]}));
   void* WH[2] = {d_W, d_W};
   size_t nW[2] = {nw, nw};
+  // LFGPU_SC_MODE = resident (default: multi-kernel path for the large rounds, then ONE single-workgroup kernel for
+  // the rest of the layer) | launch (same, one fused kernel per small round-hand) | grid (the whole layer in one
+  // cooperative launch with device-wide barriers; measured slower) | off (multi-kernel path throughout)
+  static const int sc_mode = [] {
+    const char* e = getenv("LFGPU_SC_MODE");
+    return !e ? 2 : !strcmp(e, "off") ? 0 : !strcmp(e, "launch") ? 1 : !strcmp(e, "grid") ? 3 : 2;
+  }();
+  const bool no_fuse = sc_mode == 0;
+  const bool use_resident = sc_mode == 2 && lf_sc_resident_ok(c);
+  bool resident = false, have_r = false;
+  u64 last_r[2] = {0, 0};
+  bool small = false, pending = false;  // pending: the binds of (phand, pr) ride in the next fused step
+  int phand = 0;
+  elt_t pr{0, 0};
+  // the fused step with the current host-side state; applies the pending bind's bookkeeping after it ran
+  auto small_step = [&](int do_eval, int eval_hand, u64 out[8]) -> int {
+    ScSmall a{};
+    a.field = field;
+    a.do_bind = pending ? 1 : 0;
+    a.bind_hand = phand;
+    a.r = pr;
+    a.do_eval = do_eval;
+    a.eval_hand = eval_hand;
+    a.hc_in = (uint2*)hc[cur];
+    a.vc_in = (elt_t*)vc[cur];
+    a.hc_out = (uint2*)hc[1 - cur];
+    a.vc_out = (elt_t*)vc[1 - cur];
+    a.nh = (u32)nh;
+    a.W[0] = (elt_t*)WH[0];
+    a.W[1] = (elt_t*)WH[1];
+    a.nW[0] = (u32)nW[0];
+    a.nW[1] = (u32)nW[1];
+    a.Wdst = (elt_t*)((pending && phand == 0 && WH[0] == d_W) ? wtmp : WH[phand]);  // hand 0 detaches from the shared input
+    a.QW = (u64*)qw;
+    a.fp_pow = fp_pow;
+    LF_TRY(lf_sc_small_step(c, a, out));
+    if (pending) {
+      WH[phand] = a.Wdst;
+      nW[phand] = (nW[phand] + 1) / 2;
+      nh = (size_t)out[4];
+      cur = 1 - cur;
+      pending = false;
+    }
+    return LFGPU_OK;
+  };
+  if (sc_mode == 3 && logw > 0 && lf_sc_resident_ok(c)) {
+    // one cooperative launch for the layer; the host only turns posts into challenges
+    uint8_t* wb = (uint8_t*)wtmp;
+    LF_TRY(lf_sc_grid_begin(c, field, hc[0], vc[0], hc[1], vc[1], nh, d_W, nw, wb, wb + half, wb + 2 * half, wb + 3 * half, qw, fp_pow,
+                            logw, grid_state));
+    u64 out[8];
+    uint64_t r[2] = {0, 0};
+    for (size_t rnd = 0; rnd < logw; ++rnd)
+      for (int hand = 0; hand < 2; ++hand) {
+        LF_TRY(lf_sc_layer_next(c, (rnd || hand) ? (const u64*)r : nullptr, out));
+        elt_t coef[3];
+        coef[0] = elt_t{out[0], out[1]};
+        coef[2] = elt_t{out[2], out[3]};
+        coef[1] = F.sub(F.sub(F.sub(sum, coef[0]), coef[0]), coef[2]);
+        elt_t ev[3];
+        uint64_t evw[3][2];
+        for (int k = 0; k < 3; ++k) {
+          ev[k] = F.eval_monomial(coef, F.pts[k]);
+          evw[k][0] = ev[k].lo;
+          evw[k][1] = ev[k].hi;
+        }
+        round(user, (size_t)hand, rnd, evw, r);
+        g_out[(hand * logw + rnd) * 2] = r[0];
+        g_out[(hand * logw + rnd) * 2 + 1] = r[1];
+        sum = F.eval_lagrange(ev, elt_t{r[0], r[1]});
+      }
+    LF_TRY(lf_sc_layer_next(c, (const u64*)r, out));
+    wc_out[0][0] = out[0];
+    wc_out[0][1] = out[1];
+    wc_out[1][0] = out[2];
+    wc_out[1][1] = out[3];
+    if (bound_quad) {
+      bound_quad[0] = out[6];
+      bound_quad[1] = out[7];
+    }
+    return LFGPU_OK;
+  }
   for (size_t rnd = 0; rnd < logw; ++rnd) {
     for (int hand = 0; hand < 2; ++hand) {
-      LF_TRY(lfgpu_qw_scatter(c, field, nh, hc[cur], vc[cur], hand, WH[1 - hand], nW[hand], qw));
+      if (!small && !no_fuse && nh <= LF_SC_SMALL_MAX && nW[0] <= LF_SC_SMALL_MAX && nW[1] <= LF_SC_SMALL_MAX) small = true;
       uint64_t a0[2], a2[2];
-      LF_TRY(lfgpu_sumcheck_partials(c, field, nW[hand], qw, WH[hand], a0, a2));
+      if (small && use_resident) {
+        if (!resident) {  // hand the rest of the layer to the resident workgroup
+          ScSmall a{};
+          a.field = field;
+          a.hc_in = (uint2*)hc[cur];
+          a.vc_in = (elt_t*)vc[cur];
+          a.hc_out = (uint2*)hc[1 - cur];
+          a.vc_out = (elt_t*)vc[1 - cur];
+          a.nh = (u32)nh;
+          a.W[0] = (elt_t*)WH[0];
+          a.W[1] = (elt_t*)WH[1];
+          a.nW[0] = (u32)nW[0];
+          a.nW[1] = (u32)nW[1];
+          a.QW = (u64*)qw;
+          a.fp_pow = fp_pow;
+          LF_TRY(lf_sc_layer_begin(c, a, (u32)(2 * rnd + hand), (u32)(2 * logw), d_W, wtmp));
+          resident = true;
+        }
+        u64 out[8];
+        LF_TRY(lf_sc_layer_next(c, have_r ? last_r : nullptr, out));
+        a0[0] = out[0]; a0[1] = out[1]; a2[0] = out[2]; a2[1] = out[3];
+      } else if (small) {
+        u64 out[8];
+        LF_TRY(small_step(1, hand, out));
+        a0[0] = out[0]; a0[1] = out[1]; a2[0] = out[2]; a2[1] = out[3];
+      } else {
+        LF_TRY(lfgpu_qw_scatter(c, field, nh, hc[cur], vc[cur], hand, WH[1 - hand], nW[hand], qw));
+        LF_TRY(lfgpu_sumcheck_partials(c, field, nW[hand], qw, WH[hand], a0, a2));
+      }
       // coef[0] = eq0*a0, coef[2] = eq0*a2 with eq0 = 1 (logc = 0); coef[1] from sum (prover_layers.h:390-396)
       elt_t coef[3];
       coef[0] = elt_t{a0[0], a0[1]};
@@ -424,7 +546,19 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
       g_out[(hand * logw + rnd) * 2] = r[0];
       g_out[(hand * logw + rnd) * 2 + 1] = r[1];
       sum = F.eval_lagrange(ev, elt_t{r[0], r[1]});
-      if (rnd == 0 && hand == 0) {  // hand 0 leaves the shared input out of place (prover_layers.h:222-226,255-257)
+      if (resident) {  // the challenge goes to the resident workgroup with the next wait
+        last_r[0] = r[0];
+        last_r[1] = r[1];
+        have_r = true;
+        continue;
+      }
+      if (small) {  // the binds run at the head of the next fused step
+        pending = true;
+        phand = hand;
+        pr = elt_t{r[0], r[1]};
+        continue;
+      }
+      if (WH[hand] == d_W && hand == 0) {  // hand 0 leaves the shared input out of place (prover_layers.h:222-226,255-257)
         LF_TRY(lfgpu_dense_bind(c, field, nW[0], r, WH[0], wtmp));
         WH[0] = wtmp;
       } else {
@@ -436,10 +570,20 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     }
   }
   uint64_t tmp[6];
-  LF_HIP(c, hipMemcpyAsync(tmp, WH[0], 16, hipMemcpyDeviceToHost, c->stream));
-  LF_HIP(c, hipMemcpyAsync(tmp + 2, WH[1], 16, hipMemcpyDeviceToHost, c->stream));
-  LF_HIP(c, hipMemcpyAsync(tmp + 4, vc[cur], 16, hipMemcpyDeviceToHost, c->stream));
-  LF_HIP(c, hipStreamSynchronize(c->stream));
+  if (resident) {  // last challenge in, W[0][0], W[1][0] and the HQUAD scalar out
+    u64 out[8];
+    LF_TRY(lf_sc_layer_next(c, last_r, out));
+    tmp[0] = out[0]; tmp[1] = out[1]; tmp[2] = out[2]; tmp[3] = out[3]; tmp[4] = out[6]; tmp[5] = out[7];
+  } else if (small) {  // last binds + read-out of W[0][0], W[1][0], HQUAD scalar in one step
+    u64 out[8];
+    LF_TRY(small_step(0, 0, out));
+    tmp[0] = out[0]; tmp[1] = out[1]; tmp[2] = out[2]; tmp[3] = out[3]; tmp[4] = out[6]; tmp[5] = out[7];
+  } else {
+    LF_HIP(c, hipMemcpyAsync(tmp, WH[0], 16, hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(c, hipMemcpyAsync(tmp + 2, WH[1], 16, hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(c, hipMemcpyAsync(tmp + 4, vc[cur], 16, hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(c, hipStreamSynchronize(c->stream));
+  }
   wc_out[0][0] = tmp[0];
   wc_out[0][1] = tmp[1];
   wc_out[1][0] = tmp[2];

@@ -247,6 +247,288 @@ __global__ __launch_bounds__(SC_THREADS) void hquad_emit_kernel(size_t n, const 
   st16(&vc_out[off], v);
 }
 
+// ---- fused single-workgroup steps for the small rounds of a layer.
+// Once the HQUAD and both hand arrays have <= LF_SC_SMALL_MAX entries the per-round work is microseconds and the
+// round is bound by launches and synchronisations (6 kernels + 2 stream syncs per round-hand on the path above).
+// One 1024-thread workgroup then does everything between two transcript interactions: the binds of the previous
+// round-hand (Dense::bind + HQuad::bind_h with the challenge the host just drew) and the two partial sums of the
+// next one (QW scatter + evaluations), posted to coherent pinned memory the host polls.  Two drivers:
+//   sc_small_step_kernel   one launch per round-hand, no stream synchronisation
+//   sc_small_layer_kernel  ONE launch for all remaining round-hands of the layer: the workgroup stays resident and
+//                          receives each challenge through a second coherent word (bounded wait, see below)
+// Same arithmetic and the same order-preserving compaction as the kernels above, so the results are identical.
+#define SM_THREADS 1024
+struct ScState {  // the layer's device state as the workgroup tracks it
+  const uint2* hc;
+  const elt_t* vc;
+  uint2* hc_other;
+  elt_t* vc_other;
+  u32 nh;
+  elt_t* W[2];
+  u32 nW[2];
+};
+struct ScShared {
+  u32 wave[SM_THREADS / 64];
+  u32 carry;
+  elt_t red[2][SM_THREADS / 64];
+  u64 cmd[3];
+};
+
+// Dense::bind of hand bh into Wdst (may alias the source) + HQuad::bind_h into the other half of the ping-pong
+template <int F>
+__device__ __forceinline__ void sc_bind(ScState& st, ScShared& sh, int bh, elt_t r, elt_t* Wdst) {
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {  // chunk k reads inputs [2048k, 2048k+2048) and then writes outputs [1024k, 1024k+1024): the writes never reach
+     // the inputs of a later chunk, and a barrier separates them from this chunk's own reads
+    const u32 n0 = st.nW[bh], nout = (n0 + 1) / 2;
+    const elt_t* in = st.W[bh];
+    for (u32 base = 0; base < nout; base += SM_THREADS) {
+      const u32 i = base + tid;
+      elt_t v = elt_zero();
+      if (i < nout) {
+        const elt_t f0 = ld16(&in[2 * i]);
+        if (2 * i + 1 < n0) {
+          const elt_t f1 = ld16(&in[2 * i + 1]);
+          v = Fld<F>::add(f0, Fld<F>::mul(Fld<F>::sub(f1, f0), r));
+        } else {
+          v = Fld<F>::sub(f0, Fld<F>::mul(f0, r));
+        }
+      }
+      __syncthreads();
+      if (i < nout) st16(&Wdst[i], v);
+    }
+    st.W[bh] = Wdst;
+    st.nW[bh] = nout;
+  }
+  if (tid == 0) sh.carry = 0;
+  __syncthreads();
+  const uint2* hc = st.hc;
+  const elt_t* vc = st.vc;
+  const u32 nh = st.nh;
+  for (u32 base = 0; base < nh; base += SM_THREADS) {
+    const u32 i = base + tid;
+    const bool head = i < nh && !is_second(hc, i, bh);
+    const u64 mask = __ballot(head);
+    if (lane == 0) sh.wave[wave] = (u32)__popcll(mask);
+    __syncthreads();
+    u32 off = sh.carry;
+    for (u32 w = 0; w < wave; ++w) off += sh.wave[w];
+    off += (u32)__popcll(mask & ((1ull << lane) - 1));
+    if (head) {
+      uint2 h = hc[i];
+      const u32 hh = bh ? h.y : h.x;
+      const elt_t v0 = ld16(&vc[i]);
+      elt_t v;
+      if (i + 1 < nh && is_second(hc, i + 1, bh)) {
+        const elt_t v1 = ld16(&vc[i + 1]);
+        v = Fld<F>::add(v0, Fld<F>::mul(Fld<F>::sub(v1, v0), r));
+      } else if ((hh & 1) == 0) {
+        v = Fld<F>::sub(v0, Fld<F>::mul(v0, r));
+      } else {
+        v = Fld<F>::mul(v0, r);
+      }
+      if (bh) h.y = hh >> 1; else h.x = hh >> 1;
+      st.hc_other[off] = h;
+      st16(&st.vc_other[off], v);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      u32 tot = 0;
+      for (u32 w = 0; w < SM_THREADS / 64; ++w) tot += sh.wave[w];
+      sh.carry += tot;
+    }
+    __syncthreads();
+  }
+  st.nh = sh.carry;
+  uint2* oh = const_cast<uint2*>(st.hc);
+  elt_t* ov = const_cast<elt_t*>(st.vc);
+  st.hc = st.hc_other;
+  st.vc = st.vc_other;
+  st.hc_other = oh;
+  st.vc_other = ov;
+  __threadfence_block();
+  __syncthreads();
+}
+
+// QW scatter + ProverLayers::evaluations for hand eh; the sums are valid in thread 0
+template <int F>
+__device__ __forceinline__ void sc_eval(const ScState& st, ScShared& sh, int eh, u64* QW, const elt_t* fp_pow, elt_t& a0, elt_t& a2) {
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 nq = st.nW[eh], nh = st.nh;
+  const elt_t* Wo = st.W[1 - eh];
+  const uint2* hc = st.hc;
+  const elt_t* vc = st.vc;
+  const u32 words = (F == FIELD_GF2_128 ? 2u : 4u) * nq;
+  for (u32 i = tid; i < words; i += SM_THREADS) QW[i] = 0;
+  __syncthreads();
+  for (u32 base = 0; base < nh; base += SM_THREADS) {  // QW[h[hand]] += v * Wother[h[1-hand]]
+    const u32 i = base + tid;
+    const bool valid = i < nh;
+    u32 key = 0xffffffffu;
+    elt_t t = elt_zero();
+    if (valid) {
+      const uint2 h = hc[i];
+      key = eh ? h.y : h.x;
+      t = Fld<F>::mul(ld16(&vc[i]), ld16(&Wo[eh ? h.x : h.y]));
+    }
+    if (F == FIELD_GF2_128) {  // fold runs of equal targets inside the wave first (see qw_scatter_gf_kernel)
+      const u32 pkey = __shfl_up(key, 1, 64);
+      const bool head = lane == 0 || pkey != key;
+      const u64 hmask = __ballot(head);
+      const u32 rid = (u32)__popcll(hmask & ((2ull << lane) - 1));
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const u64 olo = __shfl_down(t.lo, off, 64), ohi = __shfl_down(t.hi, off, 64);
+        const u32 orid = __shfl_down(rid, off, 64);
+        if (lane + off < 64 && orid == rid) {
+          t.lo ^= olo;
+          t.hi ^= ohi;
+        }
+      }
+      if (valid && head) {
+        atomicXor(&QW[2 * (size_t)key], t.lo);
+        atomicXor(&QW[2 * (size_t)key + 1], t.hi);
+      }
+    } else if (valid) {  // integer limb accumulators (see qw_scatter_fp_kernel)
+      u64* acc = QW + 4 * (size_t)key;
+      atomicAdd(&acc[0], (u64)(u32)t.lo);
+      atomicAdd(&acc[1], t.lo >> 32);
+      atomicAdd(&acc[2], (u64)(u32)t.hi);
+      atomicAdd(&acc[3], t.hi >> 32);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const elt_t* Wh = st.W[eh];
+  const u32 nodd = nq / 2;
+  auto qw_at = [&](u32 j) -> elt_t {
+    if (F == FIELD_GF2_128) return elt_t{QW[2 * (size_t)j], QW[2 * (size_t)j + 1]};
+    elt_t sum = elt_zero();  // recombine the limbs and reduce once (see fp_limb_normalize_kernel)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u64 x = QW[4 * (size_t)j + k];
+      sum = fp_add(sum, fp_add(fp_mul(elt_t{(u64)(u32)x, 0}, ld16(&fp_pow[k])), fp_mul(elt_t{x >> 32, 0}, ld16(&fp_pow[k + 1]))));
+    }
+    return sum;
+  };
+  a0 = elt_zero();
+  a2 = elt_zero();
+  for (u32 i = tid; i < nodd; i += SM_THREADS) {
+    const elt_t q0 = qw_at(2 * i), q1 = qw_at(2 * i + 1);
+    const elt_t w0 = ld16(&Wh[2 * i]), w1 = ld16(&Wh[2 * i + 1]);
+    a0 = Fld<F>::add(a0, Fld<F>::mul(q0, w0));
+    a2 = Fld<F>::add(a2, Fld<F>::mul(Fld<F>::sub(q1, q0), Fld<F>::sub(w1, w0)));
+  }
+  if (tid == 0 && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388)
+    const elt_t t = Fld<F>::mul(qw_at(2 * nodd), ld16(&Wh[2 * nodd]));
+    a0 = Fld<F>::add(a0, t);
+    a2 = Fld<F>::add(a2, t);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    elt_t o0, o2;
+    o0.lo = __shfl_down(a0.lo, off, 64); o0.hi = __shfl_down(a0.hi, off, 64);
+    o2.lo = __shfl_down(a2.lo, off, 64); o2.hi = __shfl_down(a2.hi, off, 64);
+    a0 = Fld<F>::add(a0, o0);
+    a2 = Fld<F>::add(a2, o2);
+  }
+  if (lane == 0) {
+    sh.red[0][wave] = a0;
+    sh.red[1][wave] = a2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    a0 = sh.red[0][0];
+    a2 = sh.red[1][0];
+    for (u32 w = 1; w < SM_THREADS / 64; ++w) {
+      a0 = Fld<F>::add(a0, sh.red[0][w]);
+      a2 = Fld<F>::add(a2, sh.red[1][w]);
+    }
+  }
+  __syncthreads();
+}
+
+// thread 0: post {x0, x1, nh, scalar} and then the sequence number, visible to the host in that order
+__device__ __forceinline__ void sc_post(const ScState& st, elt_t x0, elt_t x1, u64 seq, u64 status, volatile u64* post) {
+  const elt_t s = st.nh ? ld16(&st.vc[0]) : elt_zero();
+  post[0] = x0.lo; post[1] = x0.hi; post[2] = x1.lo; post[3] = x1.hi;
+  post[4] = st.nh;
+  post[6] = s.lo; post[7] = s.hi;
+  post[8] = status;
+  __threadfence_system();
+  __hip_atomic_store((u64*)&post[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ ScState sc_state_of(const ScSmall& a) {
+  ScState st;
+  st.hc = a.hc_in; st.vc = a.vc_in; st.hc_other = a.hc_out; st.vc_other = a.vc_out;
+  st.nh = a.nh;
+  st.W[0] = a.W[0]; st.W[1] = a.W[1];
+  st.nW[0] = a.nW[0]; st.nW[1] = a.nW[1];
+  return st;
+}
+
+template <int F>
+__global__ __launch_bounds__(SM_THREADS) void sc_small_step_kernel(ScSmall a, u64 seq, volatile u64* __restrict__ post) {
+  __shared__ ScShared sh;
+  ScState st = sc_state_of(a);
+  if (a.do_bind) sc_bind<F>(st, sh, a.bind_hand, a.r, a.Wdst);
+  elt_t a0 = elt_zero(), a2 = elt_zero();
+  if (a.do_eval) sc_eval<F>(st, sh, a.eval_hand, a.QW, a.fp_pow, a0, a2);
+  if (threadIdx.x == 0) {
+    if (!a.do_eval) {  // end of the layer: the two bound hand arrays (and the HQUAD scalar)
+      a0 = st.nW[0] ? ld16(&st.W[0][0]) : elt_zero();
+      a2 = st.nW[1] ? ld16(&st.W[1][0]) : elt_zero();
+    }
+    sc_post(st, a0, a2, seq, 0, post);
+  }
+}
+
+// All remaining round-hands [rh0, rh1) of a layer in one launch.  After posting a round's sums under sequence
+// number seq0 + k the workgroup waits until the host answers with the challenge in cmd[0..1] and cmd[2] == seq0 + k.
+// The wait is BOUNDED: after `timeout_ticks` of the constant-rate wall clock the kernel posts status 1 and every
+// wave leaves, so a host that went away can never leave the workgroup resident.
+template <int F>
+__global__ __launch_bounds__(SM_THREADS) void sc_small_layer_kernel(ScSmall a, u32 rh0, u32 rh1, elt_t* d_W_shared, elt_t* wtmp,
+                                                                    u64 seq0, u64 timeout_ticks, volatile u64* __restrict__ post,
+                                                                    const volatile u64* __restrict__ cmd) {
+  __shared__ ScShared sh;
+  ScState st = sc_state_of(a);
+  u64 seq = seq0;
+  for (u32 rh = rh0; rh < rh1; ++rh, ++seq) {
+    const int hand = (int)(rh & 1);
+    elt_t a0, a2;
+    sc_eval<F>(st, sh, hand, a.QW, a.fp_pow, a0, a2);
+    if (threadIdx.x == 0) {
+      sc_post(st, a0, a2, seq, 0, post);
+      const u64 t0 = wall_clock64();
+      u64 got = 0;
+      for (;;) {
+        got = __hip_atomic_load((const u64*)&cmd[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (got == seq) break;
+        if (wall_clock64() - t0 > timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      sh.cmd[2] = got;
+      sh.cmd[0] = __hip_atomic_load((const u64*)&cmd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      sh.cmd[1] = __hip_atomic_load((const u64*)&cmd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (sh.cmd[2] != seq) {  // uniform: the host did not answer in time
+      if (threadIdx.x == 0) sc_post(st, elt_zero(), elt_zero(), seq, 1, post);
+      return;
+    }
+    const elt_t r{sh.cmd[0], sh.cmd[1]};
+    __syncthreads();
+    elt_t* dst = (hand == 0 && st.W[0] == d_W_shared) ? wtmp : st.W[hand];  // hand 0 detaches from the shared input
+    sc_bind<F>(st, sh, hand, r, dst);
+  }
+  if (threadIdx.x == 0) {
+    const elt_t w0 = st.nW[0] ? ld16(&st.W[0][0]) : elt_zero();
+    const elt_t w1 = st.nW[1] ? ld16(&st.W[1][0]) : elt_zero();
+    sc_post(st, w0, w1, seq, 0, post);
+  }
+}
+
 // y[j] += sum_i u[i]*T[i][j]
 template <int F>
 __global__ __launch_bounds__(SC_THREADS) void rows_axpy_kernel(u32 nrows, size_t n, elt_t* __restrict__ y,
@@ -286,6 +568,569 @@ __global__ __launch_bounds__(SC_THREADS) void field_binop_kernel(int op, size_t 
     else                                                                                             \
       return lf_fail(c, LFGPU_ERR_ARG, "unknown field %d", (int)(field));                            \
   } while (0)
+
+
+// ---- the whole layer in ONE cooperative launch (every round, any size).
+// A single workgroup is compute-bound beyond ~10^3 terms (a GF(2^128) product is ~600 VALU ops), so the resident
+// idea is extended to a grid of one 1024-thread workgroup per CU with device-wide barriers: per round-hand
+//   scatter | barrier | partial sums -> last-arriving workgroup posts to the host | wait for the challenge |
+//   dense bind + head counts + clear QW | barrier | emit (order-preserving, workgroup g owns a contiguous range)
+//   | barrier
+// i.e. three device barriers and one host round trip instead of ~10 launches and 2 stream synchronisations.
+// Only workgroup 0 polls host memory; the others take the challenge from a device-memory slot.  Every wait is
+// bounded (abort flag + wall-clock timeout), so all waves always leave.  Launched with
+// hipLaunchCooperativeKernel, which guarantees that all workgroups are resident.
+struct ScGridSync {  // device memory, zeroed before every launch
+  u32 count, gen, abort, arrive;
+  u64 acc[8];
+  u64 chal[2];
+  u64 chal_seq;
+};
+struct ScGrid {
+  int field;
+  uint2* hcA;
+  elt_t* vcA;
+  uint2* hcB;
+  elt_t* vcB;
+  u32 nh;
+  elt_t* dW;
+  u32 nw;
+  elt_t* Wb[2][2];  // bind destinations per hand (ping-pong), (nw+1)/2 elements each
+  u64* QW;
+  const elt_t* fp_pow;
+  u32 rh1;          // 2 * logw
+  u64 seq0, timeout_ticks;
+  volatile u64* post;
+  const volatile u64* cmd;
+  ScGridSync* gs;
+  u32* counts;      // gridDim.x words
+};
+
+__device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32& gen, u64 timeout_ticks) {
+  __syncthreads();
+  __shared__ u32 s_abort;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    u32 ab = 0;
+    const u64 t0 = wall_clock64();
+    const u32 t = __hip_atomic_fetch_add(&gs->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      __hip_atomic_store(&gs->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&gs->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(&gs->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          ab = 1;
+          break;
+        }
+        if (wall_clock64() - t0 > 2 * timeout_ticks) {  // never reached in a healthy run: no wait is unbounded
+          __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          ab = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __threadfence();
+    s_abort = ab;
+  }
+  ++gen;
+  __syncthreads();
+  return s_abort == 0;
+}
+
+template <int F>
+__global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
+  __shared__ ScShared sh;
+  __shared__ u32 s_off, s_tot;
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 G = gridDim.x, g = blockIdx.x;
+  const u32 GT = G * SM_THREADS, gtid = g * SM_THREADS + tid;
+  const u32 qwords = F == FIELD_GF2_128 ? 2u : 4u;
+  ScGridSync* gs = a.gs;
+  const uint2* hc = a.hcA;
+  const elt_t* vc = a.vcA;
+  uint2* hc_o = a.hcB;
+  elt_t* vc_o = a.vcB;
+  u32 nh = a.nh;
+  const elt_t* W[2] = {a.dW, a.dW};
+  u32 nW[2] = {a.nw, a.nw};
+  u32 wsel[2] = {0, 0};
+  u32 gen = 0;
+  u64 seq = a.seq0;
+  for (u32 i = gtid; i < qwords * nW[0]; i += GT) a.QW[i] = 0;
+  if (!sc_grid_barrier(gs, gen, a.timeout_ticks)) return;
+#ifdef LF_SC_PROF
+  u64 pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 tl = wall_clock64();
+#define SC_LAP(k) do { const u64 tn_ = wall_clock64(); pt[k] += tn_ - tl; tl = tn_; } while (0)
+#else
+#define SC_LAP(k) do { } while (0)
+#endif
+  for (u32 rh = 0; rh < a.rh1; ++rh, ++seq) {
+    const int hand = (int)(rh & 1);
+    // ---- QW[h[hand]] += v * Wother[h[1-hand]]
+    {
+      const elt_t* Wo = W[1 - hand];
+      for (u32 base = g * SM_THREADS; base < nh; base += GT) {
+        const u32 i = base + tid;
+        const bool valid = i < nh;
+        u32 key = 0xffffffffu;
+        elt_t t = elt_zero();
+        if (valid) {
+          const uint2 h = hc[i];
+          key = hand ? h.y : h.x;
+          t = Fld<F>::mul(ld16(&vc[i]), ld16(&Wo[hand ? h.x : h.y]));
+        }
+        if (F == FIELD_GF2_128) {  // fold runs of equal targets inside the wave first (see qw_scatter_gf_kernel)
+          const u32 pkey = __shfl_up(key, 1, 64);
+          const bool head = lane == 0 || pkey != key;
+          const u64 hmask = __ballot(head);
+          const u32 rid = (u32)__popcll(hmask & ((2ull << lane) - 1));
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const u64 olo = __shfl_down(t.lo, off, 64), ohi = __shfl_down(t.hi, off, 64);
+            const u32 orid = __shfl_down(rid, off, 64);
+            if (lane + off < 64 && orid == rid) {
+              t.lo ^= olo;
+              t.hi ^= ohi;
+            }
+          }
+          if (valid && head) {
+            atomicXor(&a.QW[2 * (size_t)key], t.lo);
+            atomicXor(&a.QW[2 * (size_t)key + 1], t.hi);
+          }
+        } else if (valid) {  // integer limb accumulators (see qw_scatter_fp_kernel)
+          u64* acc = a.QW + 4 * (size_t)key;
+          atomicAdd(&acc[0], (u64)(u32)t.lo);
+          atomicAdd(&acc[1], t.lo >> 32);
+          atomicAdd(&acc[2], (u64)(u32)t.hi);
+          atomicAdd(&acc[3], t.hi >> 32);
+        }
+      }
+    }
+    SC_LAP(0);
+    if (!sc_grid_barrier(gs, gen, a.timeout_ticks)) return;
+    SC_LAP(1);
+    // ---- ProverLayers::evaluations: a0, a2
+    {
+      const u32 nq = nW[hand], nodd = nq / 2;
+      const elt_t* Wh = W[hand];
+      auto qw_at = [&](u32 j) -> elt_t {
+        if (F == FIELD_GF2_128) return elt_t{a.QW[2 * (size_t)j], a.QW[2 * (size_t)j + 1]};
+        elt_t sum = elt_zero();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u64 x = a.QW[4 * (size_t)j + k];
+          sum = fp_add(sum, fp_add(fp_mul(elt_t{(u64)(u32)x, 0}, ld16(&a.fp_pow[k])), fp_mul(elt_t{x >> 32, 0}, ld16(&a.fp_pow[k + 1]))));
+        }
+        return sum;
+      };
+      elt_t a0 = elt_zero(), a2 = elt_zero();
+      for (u32 i = gtid; i < nodd; i += GT) {
+        const elt_t q0 = qw_at(2 * i), q1 = qw_at(2 * i + 1);
+        const elt_t w0 = ld16(&Wh[2 * i]), w1 = ld16(&Wh[2 * i + 1]);
+        a0 = Fld<F>::add(a0, Fld<F>::mul(q0, w0));
+        a2 = Fld<F>::add(a2, Fld<F>::mul(Fld<F>::sub(q1, q0), Fld<F>::sub(w1, w0)));
+      }
+      if (gtid == 0 && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388)
+        const elt_t t = Fld<F>::mul(qw_at(2 * nodd), ld16(&Wh[2 * nodd]));
+        a0 = Fld<F>::add(a0, t);
+        a2 = Fld<F>::add(a2, t);
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        elt_t o0, o2;
+        o0.lo = __shfl_down(a0.lo, off, 64); o0.hi = __shfl_down(a0.hi, off, 64);
+        o2.lo = __shfl_down(a2.lo, off, 64); o2.hi = __shfl_down(a2.hi, off, 64);
+        a0 = Fld<F>::add(a0, o0);
+        a2 = Fld<F>::add(a2, o2);
+      }
+      if (lane == 0) {
+        sh.red[0][wave] = a0;
+        sh.red[1][wave] = a2;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        a0 = sh.red[0][0];
+        a2 = sh.red[1][0];
+        for (u32 w = 1; w < SM_THREADS / 64; ++w) {
+          a0 = Fld<F>::add(a0, sh.red[0][w]);
+          a2 = Fld<F>::add(a2, sh.red[1][w]);
+        }
+        // fold the workgroup sums device-wide: XOR words (GF) / 32-bit limbs as integers (Fp); the last arrival posts
+        if (F == FIELD_GF2_128) {
+          atomicXor(&gs->acc[0], a0.lo); atomicXor(&gs->acc[1], a0.hi);
+          atomicXor(&gs->acc[2], a2.lo); atomicXor(&gs->acc[3], a2.hi);
+        } else {
+          atomicAdd(&gs->acc[0], (u64)(u32)a0.lo); atomicAdd(&gs->acc[1], a0.lo >> 32);
+          atomicAdd(&gs->acc[2], (u64)(u32)a0.hi); atomicAdd(&gs->acc[3], a0.hi >> 32);
+          atomicAdd(&gs->acc[4], (u64)(u32)a2.lo); atomicAdd(&gs->acc[5], a2.lo >> 32);
+          atomicAdd(&gs->acc[6], (u64)(u32)a2.hi); atomicAdd(&gs->acc[7], a2.hi >> 32);
+        }
+        __threadfence();
+        const u32 t = __hip_atomic_fetch_add(&gs->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == G - 1) {
+          __threadfence();
+          u64 w[8];
+          for (int k = 0; k < 8; ++k) w[k] = __hip_atomic_exchange(&gs->acc[k], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&gs->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          elt_t s0, s2;
+          if (F == FIELD_GF2_128) {
+            s0 = elt_t{w[0], w[1]};
+            s2 = elt_t{w[2], w[3]};
+          } else {
+            s0 = elt_zero();
+            s2 = elt_zero();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              s0 = fp_add(s0, fp_add(fp_mul(elt_t{(u64)(u32)w[k], 0}, ld16(&a.fp_pow[k])), fp_mul(elt_t{w[k] >> 32, 0}, ld16(&a.fp_pow[k + 1]))));
+              s2 = fp_add(s2, fp_add(fp_mul(elt_t{(u64)(u32)w[4 + k], 0}, ld16(&a.fp_pow[k])), fp_mul(elt_t{w[4 + k] >> 32, 0}, ld16(&a.fp_pow[k + 1]))));
+            }
+          }
+          a.post[0] = s0.lo; a.post[1] = s0.hi; a.post[2] = s2.lo; a.post[3] = s2.hi;
+          a.post[4] = nh;
+          a.post[8] = 0;
+          __threadfence_system();
+          __hip_atomic_store((u64*)&a.post[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+    SC_LAP(2);
+    // ---- the challenge: workgroup 0 takes it from the host, the others from the device slot
+    if (tid == 0) {
+      const u64 t0 = wall_clock64();
+      u64 got = 0;
+      if (g == 0) {
+        for (;;) {
+          got = __hip_atomic_load((const u64*)&a.cmd[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (got == seq) break;
+          if (wall_clock64() - t0 > a.timeout_ticks) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if (got == seq) {
+          gs->chal[0] = __hip_atomic_load((const u64*)&a.cmd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          gs->chal[1] = __hip_atomic_load((const u64*)&a.cmd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __threadfence();
+          __hip_atomic_store(&gs->chal_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {  // the host went away: release every workgroup and report
+          __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          a.post[8] = 1;
+          __threadfence_system();
+          __hip_atomic_store((u64*)&a.post[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      } else {
+        for (;;) {
+          got = __hip_atomic_load(&gs->chal_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if (got == seq) break;
+          if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+          if (wall_clock64() - t0 > 2 * a.timeout_ticks) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      __threadfence();
+      sh.cmd[2] = got;
+      sh.cmd[0] = __hip_atomic_load(&gs->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sh.cmd[1] = __hip_atomic_load(&gs->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (sh.cmd[2] != seq) return;  // uniform per workgroup; the barriers of the others see the abort flag
+    const elt_t r{sh.cmd[0], sh.cmd[1]};
+    SC_LAP(3);
+    // ---- Dense::bind of W[hand] (out of place), head counts of this workgroup's HQUAD range, clear QW
+    const u32 n0 = nW[hand], nout = (n0 + 1) / 2;
+    {
+      const elt_t* in = W[hand];
+      elt_t* out = a.Wb[hand][wsel[hand]];
+      for (u32 i = gtid; i < nout; i += GT) {
+        const elt_t f0 = ld16(&in[2 * i]);
+        elt_t v;
+        if (2 * i + 1 < n0) {
+          const elt_t f1 = ld16(&in[2 * i + 1]);
+          v = Fld<F>::add(f0, Fld<F>::mul(Fld<F>::sub(f1, f0), r));
+        } else {
+          v = Fld<F>::sub(f0, Fld<F>::mul(f0, r));
+        }
+        st16(&out[i], v);
+      }
+      W[hand] = out;
+      nW[hand] = nout;
+      wsel[hand] ^= 1;
+    }
+    const u32 R = ((nh + G - 1) / G + SM_THREADS - 1) / SM_THREADS * SM_THREADS;  // range per workgroup, whole chunks
+    const u32 lo = (u64)g * R < nh ? g * R : nh, hi = (u64)lo + R < nh ? lo + R : nh;
+    {
+      if (tid == 0) sh.carry = 0;
+      __syncthreads();
+      u32 mine = 0;
+      for (u32 base = lo; base < hi; base += SM_THREADS) {
+        const u32 i = base + tid;
+        const bool head = i < hi && !is_second(hc, i, hand);
+        mine += (u32)__popcll(__ballot(head));
+      }
+      if (lane == 0 && mine) atomicAdd(&sh.carry, mine);
+      __syncthreads();
+      if (tid == 0) a.counts[g] = sh.carry;
+    }
+    {
+      const u32 nnext = nW[(rh + 1) & 1];  // the next evaluation is for the other hand (sizes after this bind)
+      for (u32 i = gtid; i < qwords * nnext; i += GT) a.QW[i] = 0;
+    }
+    SC_LAP(4);
+    if (!sc_grid_barrier(gs, gen, a.timeout_ticks)) return;
+    SC_LAP(5);
+    // ---- HQuad::bind_h: emit this workgroup's range at its offset
+    {
+      if (tid == 0) {
+        s_off = 0;
+        s_tot = 0;
+      }
+      __syncthreads();
+      if (tid < G) {
+        const u32 cnt = a.counts[tid];
+        if (cnt) {
+          atomicAdd(&s_tot, cnt);
+          if (tid < g) atomicAdd(&s_off, cnt);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) sh.carry = s_off;
+      __syncthreads();
+      for (u32 base = lo; base < hi; base += SM_THREADS) {
+        const u32 i = base + tid;
+        const bool head = i < hi && !is_second(hc, i, hand);
+        const u64 mask = __ballot(head);
+        if (lane == 0) sh.wave[wave] = (u32)__popcll(mask);
+        __syncthreads();
+        u32 off = sh.carry;
+        for (u32 w = 0; w < wave; ++w) off += sh.wave[w];
+        off += (u32)__popcll(mask & ((1ull << lane) - 1));
+        if (head) {
+          uint2 h = hc[i];
+          const u32 hh = hand ? h.y : h.x;
+          const elt_t v0 = ld16(&vc[i]);
+          elt_t v;
+          if (i + 1 < nh && is_second(hc, i + 1, hand)) {
+            const elt_t v1 = ld16(&vc[i + 1]);
+            v = Fld<F>::add(v0, Fld<F>::mul(Fld<F>::sub(v1, v0), r));
+          } else if ((hh & 1) == 0) {
+            v = Fld<F>::sub(v0, Fld<F>::mul(v0, r));
+          } else {
+            v = Fld<F>::mul(v0, r);
+          }
+          if (hand) h.y = hh >> 1; else h.x = hh >> 1;
+          hc_o[off] = h;
+          st16(&vc_o[off], v);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          u32 tot = 0;
+          for (u32 w = 0; w < SM_THREADS / 64; ++w) tot += sh.wave[w];
+          sh.carry += tot;
+        }
+        __syncthreads();
+      }
+      nh = s_tot;
+      uint2* th = const_cast<uint2*>(hc);
+      elt_t* tv = const_cast<elt_t*>(vc);
+      hc = hc_o;
+      vc = vc_o;
+      hc_o = th;
+      vc_o = tv;
+    }
+    SC_LAP(6);
+    if (!sc_grid_barrier(gs, gen, a.timeout_ticks)) return;
+    SC_LAP(7);
+  }
+#ifdef LF_SC_PROF
+  if (gtid == 0)
+    for (int k = 0; k < 8; ++k) a.post[16 + k] = pt[k];
+#endif
+  if (gtid == 0) {  // end of the layer: W[R,C], W[L,C] and HQUAD->scalar()
+    const elt_t w0 = nW[0] ? ld16(&W[0][0]) : elt_zero();
+    const elt_t w1 = nW[1] ? ld16(&W[1][0]) : elt_zero();
+    const elt_t sc = nh ? ld16(&vc[0]) : elt_zero();
+    a.post[0] = w0.lo; a.post[1] = w0.hi; a.post[2] = w1.lo; a.post[3] = w1.hi;
+    a.post[4] = nh;
+    a.post[6] = sc.lo; a.post[7] = sc.hi;
+    a.post[8] = 0;
+    __threadfence_system();
+    __hip_atomic_store((u64*)&a.post[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// waits until the post carries `seq`; polls coherent memory and watches the stream so a dead kernel is noticed
+static int sc_wait_post(lfgpu_ctx* c, u64 seq) {
+  u64 spins = 0;
+  while (__atomic_load_n((const u64*)&c->poll_h[5], __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0xfff) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {  // the kernel is over: its post must be visible now
+        if (__atomic_load_n((const u64*)&c->poll_h[5], __ATOMIC_ACQUIRE) == seq) break;
+        return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck step: kernel finished without posting");
+      }
+      if (q != hipErrorNotReady) return lf_fail(c, LFGPU_ERR_HIP, "sumcheck step: %s", hipGetErrorString(q));
+    }
+  }
+  if (c->poll_h[8] != 0) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck layer kernel: challenge wait timed out");
+  return LFGPU_OK;
+}
+
+// launches one fused step and waits for its post
+int lf_sc_small_step(lfgpu_ctx* c, const ScSmall& a, u64 out[8]) {
+  if (a.nh > LF_SC_SMALL_MAX || a.nW[0] > LF_SC_SMALL_MAX || a.nW[1] > LF_SC_SMALL_MAX)
+    return lf_fail(c, LFGPU_ERR_ARG, "sc_small_step: operands larger than the single-workgroup bound");
+  const u64 seq = ++c->poll_seq;
+  if (a.field == LFGPU_FIELD_GF2_128)
+    hipLaunchKernelGGL(sc_small_step_kernel<FIELD_GF2_128>, dim3(1), dim3(SM_THREADS), 0, c->stream, a, seq, c->poll_h);
+  else
+    hipLaunchKernelGGL(sc_small_step_kernel<FIELD_FP128>, dim3(1), dim3(SM_THREADS), 0, c->stream, a, seq, c->poll_h);
+  LF_HIP(c, hipGetLastError());
+  LF_TRY(sc_wait_post(c, seq));
+  for (int i = 0; i < 8; ++i) out[i] = c->poll_h[i];
+  return LFGPU_OK;
+}
+
+// one round trip of the resident protocol on a 1-thread kernel with a short timeout: decides once per context
+// whether coherent pinned memory lets a RUNNING kernel see host writes on this system (otherwise the per-step
+// launches are used)
+__global__ void sc_handshake_test_kernel(u64 seq, u64 timeout_ticks, volatile u64* post, const volatile u64* cmd) {
+  post[8] = 0;
+  __threadfence_system();
+  __hip_atomic_store((u64*)&post[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const u64 t0 = wall_clock64();
+  u64 ok = 0;
+  while (wall_clock64() - t0 <= timeout_ticks) {
+    if (__hip_atomic_load((const u64*)&cmd[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == seq) {
+      ok = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  post[8] = ok ? 0 : 1;
+  post[0] = ok ? __hip_atomic_load((const u64*)&cmd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+  __threadfence_system();
+  __hip_atomic_store((u64*)&post[5], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+bool lf_sc_resident_ok(lfgpu_ctx* c) {
+  if (c->resident_state) return c->resident_state > 0;
+  c->resident_state = -1;
+  const u64 seq = c->poll_seq + 1;
+  c->poll_seq += 2;
+  volatile u64* cmd = c->poll_h + 64;
+  hipLaunchKernelGGL(sc_handshake_test_kernel, dim3(1), dim3(1), 0, c->stream, seq, 200ull * c->wall_khz /*0.2 s*/, c->poll_h, cmd);
+  if (hipGetLastError() != hipSuccess) return false;
+  bool seen = false;  // the first post must arrive while the kernel is still waiting for us
+  for (u64 spins = 0; spins < (1ull << 34); ++spins) {
+    if (__atomic_load_n((const u64*)&c->poll_h[5], __ATOMIC_ACQUIRE) == seq) {
+      seen = true;
+      break;
+    }
+    if ((spins & 0xfff) == 0xfff && hipStreamQuery(c->stream) != hipErrorNotReady) break;
+  }
+  if (seen) {
+    cmd[0] = 0x5eed5eed5eedull;
+    cmd[1] = 0;
+    __atomic_store_n((u64*)&cmd[2], seq, __ATOMIC_RELEASE);
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+  if (seen && c->poll_h[5] == seq + 1 && c->poll_h[8] == 0 && c->poll_h[0] == 0x5eed5eed5eedull) c->resident_state = 1;
+  if (getenv("LFGPU_VERBOSE"))
+    fprintf(stderr, "lfgpu: resident sumcheck handshake %s (first post seen while running: %d, status %llu)\n",
+            c->resident_state > 0 ? "ok" : "unavailable", (int)seen, (unsigned long long)c->poll_h[8]);
+  return c->resident_state > 0;
+}
+
+// resident variant: launch once for round-hands [rh0, rh1), then lf_sc_layer_next per round-hand and a last call
+// for the end-of-layer read-out
+int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_W_shared, void* wtmp) {
+  if (a.nh > LF_SC_SMALL_MAX || a.nW[0] > LF_SC_SMALL_MAX || a.nW[1] > LF_SC_SMALL_MAX || rh0 >= rh1)
+    return lf_fail(c, LFGPU_ERR_ARG, "sc_layer_begin: bad operands");
+  const u64 seq0 = c->poll_seq + 1;
+  c->poll_seq += (u64)(rh1 - rh0) + 1;
+  c->poll_next = seq0;
+  const u64 timeout_ticks = 5000ull * c->wall_khz;  // 5 s of the constant-rate wall clock
+  volatile u64* post = c->poll_h;
+  const volatile u64* cmd = c->poll_h + 64;
+  if (a.field == LFGPU_FIELD_GF2_128)
+    hipLaunchKernelGGL(sc_small_layer_kernel<FIELD_GF2_128>, dim3(1), dim3(SM_THREADS), 0, c->stream, a, rh0, rh1, (elt_t*)d_W_shared,
+                       (elt_t*)wtmp, seq0, timeout_ticks, post, cmd);
+  else
+    hipLaunchKernelGGL(sc_small_layer_kernel<FIELD_FP128>, dim3(1), dim3(SM_THREADS), 0, c->stream, a, rh0, rh1, (elt_t*)d_W_shared,
+                       (elt_t*)wtmp, seq0, timeout_ticks, post, cmd);
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+// the whole layer as one cooperative launch; d_state: device scratch for ScGridSync + the per-workgroup counts
+int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hcA, void* vcA, void* hcB, void* vcB, size_t nh, void* dW, size_t nw,
+                     void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, const void* fp_pow, size_t logw, void* d_state) {
+  if (logw == 0 || (nh >> 31) || (nw >> 31)) return lf_fail(c, LFGPU_ERR_ARG, "sc_grid_begin: bad operands");
+  static int max_blocks[2] = {0, 0};
+  const int fi = field == LFGPU_FIELD_GF2_128 ? 0 : 1;
+  if (!max_blocks[fi]) {
+    int per_cu = 0;
+    const void* fn = fi == 0 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
+    LF_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SM_THREADS, 0));
+    max_blocks[fi] = per_cu > 0 ? c->num_cu : -1;  // one workgroup per CU
+  }
+  if (max_blocks[fi] < 0) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "sc_grid_begin: kernel cannot be resident");
+  u32 G = (u32)max_blocks[fi];
+  if (G > 256) G = 256;
+  {  // small layers: no more workgroups than 1024-term chunks (fewer arrivals per barrier)
+    const size_t big = nh > nw ? nh : nw;
+    const size_t want = (big + SM_THREADS - 1) / SM_THREADS;
+    if (want < G) G = want ? (u32)want : 1;
+  }
+  ScGrid a{};
+  a.field = field;
+  a.hcA = (uint2*)hcA; a.vcA = (elt_t*)vcA; a.hcB = (uint2*)hcB; a.vcB = (elt_t*)vcB;
+  a.nh = (u32)nh;
+  a.dW = (elt_t*)dW;
+  a.nw = (u32)nw;
+  a.Wb[0][0] = (elt_t*)Wb00; a.Wb[0][1] = (elt_t*)Wb01; a.Wb[1][0] = (elt_t*)Wb10; a.Wb[1][1] = (elt_t*)Wb11;
+  a.QW = (u64*)qw;
+  a.fp_pow = (const elt_t*)fp_pow;
+  a.rh1 = (u32)(2 * logw);
+  a.seq0 = c->poll_seq + 1;
+  c->poll_seq += 2 * logw + 1;
+  c->poll_next = a.seq0;
+  a.timeout_ticks = 5000ull * c->wall_khz;
+  a.post = c->poll_h;
+  a.cmd = c->poll_h + 64;
+  a.gs = (ScGridSync*)d_state;
+  a.counts = (u32*)((uint8_t*)d_state + 256);
+  LF_HIP(c, hipMemsetAsync(d_state, 0, 256 + 4 * 256, c->stream));
+  void* args[] = {&a};
+  const void* fn = fi == 0 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
+  LF_HIP(c, hipLaunchCooperativeKernel(fn, dim3(G), dim3(SM_THREADS), args, 0, c->stream));
+  return LFGPU_OK;
+}
+
+// waits for the next post of the resident kernel; r != nullptr answers the PREVIOUS post with its challenge first
+int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]) {
+  if (r) {
+    volatile u64* cmd = c->poll_h + 64;
+    cmd[0] = r[0];
+    cmd[1] = r[1];
+    __atomic_store_n((u64*)&cmd[2], c->poll_next - 1, __ATOMIC_RELEASE);
+  }
+  LF_TRY(sc_wait_post(c, c->poll_next));
+  ++c->poll_next;
+  for (int i = 0; i < 8; ++i) out[i] = c->poll_h[i];
+#ifdef LF_SC_PROF
+  if (c->poll_next == c->poll_seq + 1) {  // final post of a layer: fold the phase clocks
+    static u64 tot[8];
+    static int layers = 0;
+    for (int k = 0; k < 8; ++k) tot[k] += c->poll_h[16 + k];
+    if (++layers % 13 == 0) {
+      fprintf(stderr, "sc_grid phases (us, %d layers): scatter %.0f bar1 %.0f partials %.0f wait %.0f bind %.0f bar2 %.0f emit %.0f bar3 %.0f\n", layers,
+              tot[0] * 1e3 / c->wall_khz, tot[1] * 1e3 / c->wall_khz, tot[2] * 1e3 / c->wall_khz, tot[3] * 1e3 / c->wall_khz,
+              tot[4] * 1e3 / c->wall_khz, tot[5] * 1e3 / c->wall_khz, tot[6] * 1e3 / c->wall_khz, tot[7] * 1e3 / c->wall_khz);
+      for (int k = 0; k < 8; ++k) tot[k] = 0;
+    }
+  }
+#endif
+  return LFGPU_OK;
+}
 
 extern "C" int lfgpu_sumcheck_partials(lfgpu_ctx* c, int field, size_t n, const void* d_QW, const void* d_W,
                                        uint64_t a0[2], uint64_t a2[2]) {
