@@ -100,9 +100,12 @@ int lf_sc_small_step(lfgpu_ctx* c, const ScSmall& a, u64 out[8]);
 int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_W_shared, void* wtmp);
 int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]);
 bool lf_sc_resident_ok(lfgpu_ctx* c);
-int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hcA, void* vcA, void* hcB, void* vcB, size_t nh, void* dW, size_t nw,
-                     void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, const void* fp_pow, size_t logw, void* d_state);
-#define LF_SC_GRID_STATE_BYTES (256 + 4 * 256)
+int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, void* W0, size_t nW0,
+                     void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, const void* fp_pow, size_t rh0,
+                     size_t logw, void* d_state);
+#define LF_SC_GRID_WGS 64                          // most workgroups the shrinking-grid kernel starts with
+#define LF_SC_GRID_MAX (LF_SC_GRID_WGS * 1024)     // largest HQUAD / hand array it takes
+#define LF_SC_GRID_STATE_BYTES (64 + 32 * LF_SC_GRID_WGS + 4 * LF_SC_GRID_WGS + 64)
 #define LF_SC_SMALL_MAX 8192  // largest HQUAD / hand array the single-workgroup step takes
 
 static inline unsigned lf_log2(size_t n) {

@@ -370,6 +370,8 @@ extern "C" int lfgpu_qw_scatter(lfgpu_ctx*, int, size_t, const void*, const void
 extern "C" int lfgpu_dense_bind(lfgpu_ctx*, int, size_t, const uint64_t*, const void*, void*);
 extern "C" int lfgpu_hquad_bind_h(lfgpu_ctx*, int, size_t, const void*, const void*, const uint64_t*, int, void*, void*, size_t*);
 
+#include <chrono>
+
 #include "hostfield.h"
 
 extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
@@ -409,21 +411,32 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     fp_pow = (const elt_t*)dconst;
   }
   size_t nh = 0;
+  static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
+  auto clk = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tv0 = verbose ? clk() : 0;
   LF_TRY(lfgpu_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], &nh));
+  const double tv1 = verbose ? clk() : 0;
+  double t_large = 0, t_small_first = 0;
+  size_t n_large = 0;
+  const size_t nh0 = nh;
   int cur = 0;
   const elt_t al{alpha[0], alpha[1]};
   elt_t sum = F.add(elt_t{wc_in[0][0], wc_in[0][1]}, F.mul(al, elt_t{wc_in[1][0], wc_in[1][1]}));
   void* WH[2] = {d_W, d_W};
   size_t nW[2] = {nw, nw};
-  // LFGPU_SC_MODE = resident (default: multi-kernel path for the large rounds, then ONE single-workgroup kernel for
-  // the rest of the layer) | launch (same, one fused kernel per small round-hand) | grid (the whole layer in one
-  // cooperative launch with device-wide barriers; measured slower) | off (multi-kernel path throughout)
+  // LFGPU_SC_MODE: how the rounds are driven once the HQUAD and both hand arrays are small enough
+  //   grid (default)  one cooperative launch on a grid that shrinks with the data (<= LF_SC_GRID_MAX entries)
+  //   resident        one single-workgroup launch for the rest of the layer (<= LF_SC_SMALL_MAX entries)
+  //   launch          one fused single-workgroup kernel per round-hand (<= LF_SC_SMALL_MAX entries)
+  //   off             the multi-kernel path throughout
+  // Larger rounds always take the multi-kernel path (whole-GPU kernels, 2 stream synchronisations per round-hand).
   static const int sc_mode = [] {
     const char* e = getenv("LFGPU_SC_MODE");
-    return !e ? 2 : !strcmp(e, "off") ? 0 : !strcmp(e, "launch") ? 1 : !strcmp(e, "grid") ? 3 : 2;
+    return !e ? 3 : !strcmp(e, "off") ? 0 : !strcmp(e, "launch") ? 1 : !strcmp(e, "resident") ? 2 : 3;
   }();
   const bool no_fuse = sc_mode == 0;
-  const bool use_resident = sc_mode == 2 && lf_sc_resident_ok(c);
+  const bool use_resident = sc_mode >= 2 && lf_sc_resident_ok(c);
+  const size_t small_max = (sc_mode == 3 && use_resident) ? LF_SC_GRID_MAX : LF_SC_SMALL_MAX;
   bool resident = false, have_r = false;
   u64 last_r[2] = {0, 0};
   bool small = false, pending = false;  // pending: the binds of (phand, pr) ride in the next fused step
@@ -460,49 +473,18 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     }
     return LFGPU_OK;
   };
-  if (sc_mode == 3 && logw > 0 && lf_sc_resident_ok(c)) {
-    // one cooperative launch for the layer; the host only turns posts into challenges
-    uint8_t* wb = (uint8_t*)wtmp;
-    LF_TRY(lf_sc_grid_begin(c, field, hc[0], vc[0], hc[1], vc[1], nh, d_W, nw, wb, wb + half, wb + 2 * half, wb + 3 * half, qw, fp_pow,
-                            logw, grid_state));
-    u64 out[8];
-    uint64_t r[2] = {0, 0};
-    for (size_t rnd = 0; rnd < logw; ++rnd)
-      for (int hand = 0; hand < 2; ++hand) {
-        LF_TRY(lf_sc_layer_next(c, (rnd || hand) ? (const u64*)r : nullptr, out));
-        elt_t coef[3];
-        coef[0] = elt_t{out[0], out[1]};
-        coef[2] = elt_t{out[2], out[3]};
-        coef[1] = F.sub(F.sub(F.sub(sum, coef[0]), coef[0]), coef[2]);
-        elt_t ev[3];
-        uint64_t evw[3][2];
-        for (int k = 0; k < 3; ++k) {
-          ev[k] = F.eval_monomial(coef, F.pts[k]);
-          evw[k][0] = ev[k].lo;
-          evw[k][1] = ev[k].hi;
-        }
-        round(user, (size_t)hand, rnd, evw, r);
-        g_out[(hand * logw + rnd) * 2] = r[0];
-        g_out[(hand * logw + rnd) * 2 + 1] = r[1];
-        sum = F.eval_lagrange(ev, elt_t{r[0], r[1]});
-      }
-    LF_TRY(lf_sc_layer_next(c, (const u64*)r, out));
-    wc_out[0][0] = out[0];
-    wc_out[0][1] = out[1];
-    wc_out[1][0] = out[2];
-    wc_out[1][1] = out[3];
-    if (bound_quad) {
-      bound_quad[0] = out[6];
-      bound_quad[1] = out[7];
-    }
-    return LFGPU_OK;
-  }
   for (size_t rnd = 0; rnd < logw; ++rnd) {
     for (int hand = 0; hand < 2; ++hand) {
-      if (!small && !no_fuse && nh <= LF_SC_SMALL_MAX && nW[0] <= LF_SC_SMALL_MAX && nW[1] <= LF_SC_SMALL_MAX) small = true;
+      if (!small && !no_fuse && nh <= small_max && nW[0] <= small_max && nW[1] <= small_max) small = true;
       uint64_t a0[2], a2[2];
+      const double tr0 = (verbose && !small) ? clk() : 0;
+      if (verbose && small && t_small_first == 0) t_small_first = clk();
       if (small && use_resident) {
-        if (!resident) {  // hand the rest of the layer to the resident workgroup
+        if (!resident && sc_mode == 3) {  // hand the rest of the layer to the shrinking grid
+          uint8_t* wb = (uint8_t*)wtmp;
+          LF_TRY(lf_sc_grid_begin(c, field, hc[cur], vc[cur], hc[1 - cur], vc[1 - cur], nh, WH[0], nW[0], WH[1], nW[1], wb, wb + half,
+                                  wb + 2 * half, wb + 3 * half, qw, fp_pow, 2 * rnd + hand, logw, grid_state));
+        } else if (!resident) {  // ... or to the resident workgroup
           ScSmall a{};
           a.field = field;
           a.hc_in = (uint2*)hc[cur];
@@ -517,8 +499,8 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
           a.QW = (u64*)qw;
           a.fp_pow = fp_pow;
           LF_TRY(lf_sc_layer_begin(c, a, (u32)(2 * rnd + hand), (u32)(2 * logw), d_W, wtmp));
-          resident = true;
         }
+        resident = true;
         u64 out[8];
         LF_TRY(lf_sc_layer_next(c, have_r ? last_r : nullptr, out));
         a0[0] = out[0]; a0[1] = out[1]; a2[0] = out[2]; a2[1] = out[3];
@@ -567,6 +549,10 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
       nW[hand] = (nW[hand] + 1) / 2;
       LF_TRY(lfgpu_hquad_bind_h(c, field, nh, hc[cur], vc[cur], r, hand, hc[1 - cur], vc[1 - cur], &nh));
       cur = 1 - cur;
+      if (verbose) {
+        t_large += clk() - tr0;
+        ++n_large;
+      }
     }
   }
   uint64_t tmp[6];
@@ -584,6 +570,9 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     LF_HIP(c, hipMemcpyAsync(tmp + 4, vc[cur], 16, hipMemcpyDeviceToHost, c->stream));
     LF_HIP(c, hipStreamSynchronize(c->stream));
   }
+  if (verbose)
+    fprintf(stderr, "lfgpu sumcheck_layer: nterms %zu nh0 %zu nw %zu logw %zu | bind_g %.0f us | %zu large round-hands %.0f us | %zu small %.0f us\n",
+            nt, nh0, nw, logw, tv1 - tv0, n_large, t_large, 2 * logw - n_large, t_small_first ? clk() - t_small_first : 0.0);
   wc_out[0][0] = tmp[0];
   wc_out[0][1] = tmp[1];
   wc_out[1][0] = tmp[2];

@@ -570,51 +570,59 @@ __global__ __launch_bounds__(SC_THREADS) void field_binop_kernel(int op, size_t 
   } while (0)
 
 
-// ---- the whole layer in ONE cooperative launch (every round, any size).
-// A single workgroup is compute-bound beyond ~10^3 terms (a GF(2^128) product is ~600 VALU ops), so the resident
-// idea is extended to a grid of one 1024-thread workgroup per CU with device-wide barriers: per round-hand
-//   scatter | barrier | partial sums -> last-arriving workgroup posts to the host | wait for the challenge |
-//   dense bind + head counts + clear QW | barrier | emit (order-preserving, workgroup g owns a contiguous range)
-//   | barrier
-// i.e. three device barriers and one host round trip instead of ~10 launches and 2 stream synchronisations.
-// Only workgroup 0 polls host memory; the others take the challenge from a device-memory slot.  Every wait is
-// bounded (abort flag + wall-clock timeout), so all waves always leave.  Launched with
-// hipLaunchCooperativeKernel, which guarantees that all workgroups are resident.
+// ---- the rest of a layer in ONE cooperative launch on a grid that shrinks with the data.
+// A single workgroup is compute-bound beyond ~10^3 terms (a GF(2^128) product is ~600 VALU ops and a CU retires
+// ~1024 of them in 4.6 us), so for up to LF_SC_GRID_MAX entries the resident idea runs on one 1024-thread workgroup
+// per 1024 entries, synchronised by device-wide barriers.  Per round-hand:
+//   scatter | barrier | partial sums -> slots -> the last-arriving workgroup folds and posts to the host |
+//   challenge | dense bind + head counts + clear QW | barrier | emit (order-preserving: workgroup g owns a contiguous
+//   range) | barrier | workgroups beyond ceil(max size / 1024) leave
+// A device barrier costs ~2 us for 8 workgroups, 3.5 us for 32, 10 us for 128 (tools/ubench_sync.hip): hence the
+// shrinking grid, down to ONE workgroup whose barriers are plain __syncthreads.  Only workgroup 0 polls host
+// memory; the others take the challenge from a device-memory slot.  Every wait is bounded (abort flag + wall-clock
+// timeout), so all waves always leave.  hipLaunchCooperativeKernel guarantees that all workgroups are resident.
 struct ScGridSync {  // device memory, zeroed before every launch
   u32 count, gen, abort, arrive;
-  u64 acc[8];
   u64 chal[2];
   u64 chal_seq;
+  u64 pad_[3];
+  u64 slots[4 * LF_SC_GRID_WGS];  // per workgroup {a0, a2}
 };
 struct ScGrid {
   int field;
-  uint2* hcA;
+  uint2* hcA;       // current HQUAD
   elt_t* vcA;
-  uint2* hcB;
+  uint2* hcB;       // the other half of the ping-pong
   elt_t* vcB;
   u32 nh;
-  elt_t* dW;
-  u32 nw;
+  elt_t* W[2];      // hand arrays at entry
+  u32 nW[2];
   elt_t* Wb[2][2];  // bind destinations per hand (ping-pong), (nw+1)/2 elements each
   u64* QW;
   const elt_t* fp_pow;
-  u32 rh1;          // 2 * logw
+  u32 rh0, rh1;     // round-hands [rh0, rh1), rh1 = 2 * logw
   u64 seq0, timeout_ticks;
   volatile u64* post;
   const volatile u64* cmd;
   ScGridSync* gs;
-  u32* counts;      // gridDim.x words
+  u32* counts;      // one word per workgroup
 };
 
-__device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32& gen, u64 timeout_ticks) {
-  __syncthreads();
+// barrier among the first `G` workgroups; false = aborted (every caller then returns)
+__device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen, u64 timeout_ticks) {
   __shared__ u32 s_abort;
+  if (G == 1) {
+    __threadfence_block();
+    __syncthreads();
+    return true;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
     u32 ab = 0;
     const u64 t0 = wall_clock64();
     const u32 t = __hip_atomic_fetch_add(&gs->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) {
+    if (t == G - 1) {
       __hip_atomic_store(&gs->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&gs->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -628,7 +636,7 @@ __device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32& gen, u64 ti
           ab = 1;
           break;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
       }
     }
     __threadfence();
@@ -642,10 +650,10 @@ __device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32& gen, u64 ti
 template <int F>
 __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
   __shared__ ScShared sh;
-  __shared__ u32 s_off, s_tot;
+  __shared__ u32 s_off, s_tot, s_last;
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const u32 G = gridDim.x, g = blockIdx.x;
-  const u32 GT = G * SM_THREADS, gtid = g * SM_THREADS + tid;
+  const u32 g = blockIdx.x;
+  u32 G = gridDim.x;  // active workgroups: shrinks with the data
   const u32 qwords = F == FIELD_GF2_128 ? 2u : 4u;
   ScGridSync* gs = a.gs;
   const uint2* hc = a.hcA;
@@ -653,13 +661,16 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
   uint2* hc_o = a.hcB;
   elt_t* vc_o = a.vcB;
   u32 nh = a.nh;
-  const elt_t* W[2] = {a.dW, a.dW};
-  u32 nW[2] = {a.nw, a.nw};
-  u32 wsel[2] = {0, 0};
+  const elt_t* W[2] = {a.W[0], a.W[1]};
+  u32 nW[2] = {a.nW[0], a.nW[1]};
+  u32 wsel[2] = {a.W[0] == a.Wb[0][0] ? 1u : 0u, a.W[1] == a.Wb[1][0] ? 1u : 0u};
   u32 gen = 0;
   u64 seq = a.seq0;
-  for (u32 i = gtid; i < qwords * nW[0]; i += GT) a.QW[i] = 0;
-  if (!sc_grid_barrier(gs, gen, a.timeout_ticks)) return;
+  {
+    const u32 GT = G * SM_THREADS, gtid = g * SM_THREADS + tid;
+    for (u32 i = gtid; i < qwords * nW[a.rh0 & 1]; i += GT) a.QW[i] = 0;
+  }
+  if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
 #ifdef LF_SC_PROF
   u64 pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   u64 tl = wall_clock64();
@@ -667,8 +678,9 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
 #else
 #define SC_LAP(k) do { } while (0)
 #endif
-  for (u32 rh = 0; rh < a.rh1; ++rh, ++seq) {
+  for (u32 rh = a.rh0; rh < a.rh1; ++rh, ++seq) {
     const int hand = (int)(rh & 1);
+    const u32 GT = G * SM_THREADS, gtid = g * SM_THREADS + tid;
     // ---- QW[h[hand]] += v * Wother[h[1-hand]]
     {
       const elt_t* Wo = W[1 - hand];
@@ -710,7 +722,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       }
     }
     SC_LAP(0);
-    if (!sc_grid_barrier(gs, gen, a.timeout_ticks)) return;
+    if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
     SC_LAP(1);
     // ---- ProverLayers::evaluations: a0, a2
     {
@@ -738,61 +750,68 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         a0 = Fld<F>::add(a0, t);
         a2 = Fld<F>::add(a2, t);
       }
-      for (int off = 32; off > 0; off >>= 1) {
-        elt_t o0, o2;
-        o0.lo = __shfl_down(a0.lo, off, 64); o0.hi = __shfl_down(a0.hi, off, 64);
-        o2.lo = __shfl_down(a2.lo, off, 64); o2.hi = __shfl_down(a2.hi, off, 64);
-        a0 = Fld<F>::add(a0, o0);
-        a2 = Fld<F>::add(a2, o2);
-      }
-      if (lane == 0) {
-        sh.red[0][wave] = a0;
-        sh.red[1][wave] = a2;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        a0 = sh.red[0][0];
-        a2 = sh.red[1][0];
-        for (u32 w = 1; w < SM_THREADS / 64; ++w) {
-          a0 = Fld<F>::add(a0, sh.red[0][w]);
-          a2 = Fld<F>::add(a2, sh.red[1][w]);
+      // workgroup sum (wave shuffles, then the 16 wave sums through LDS)
+      auto wg_sum = [&](elt_t& x0, elt_t& x2) {
+        for (int off = 32; off > 0; off >>= 1) {
+          elt_t o0, o2;
+          o0.lo = __shfl_down(x0.lo, off, 64); o0.hi = __shfl_down(x0.hi, off, 64);
+          o2.lo = __shfl_down(x2.lo, off, 64); o2.hi = __shfl_down(x2.hi, off, 64);
+          x0 = Fld<F>::add(x0, o0);
+          x2 = Fld<F>::add(x2, o2);
         }
-        // fold the workgroup sums device-wide: XOR words (GF) / 32-bit limbs as integers (Fp); the last arrival posts
-        if (F == FIELD_GF2_128) {
-          atomicXor(&gs->acc[0], a0.lo); atomicXor(&gs->acc[1], a0.hi);
-          atomicXor(&gs->acc[2], a2.lo); atomicXor(&gs->acc[3], a2.hi);
-        } else {
-          atomicAdd(&gs->acc[0], (u64)(u32)a0.lo); atomicAdd(&gs->acc[1], a0.lo >> 32);
-          atomicAdd(&gs->acc[2], (u64)(u32)a0.hi); atomicAdd(&gs->acc[3], a0.hi >> 32);
-          atomicAdd(&gs->acc[4], (u64)(u32)a2.lo); atomicAdd(&gs->acc[5], a2.lo >> 32);
-          atomicAdd(&gs->acc[6], (u64)(u32)a2.hi); atomicAdd(&gs->acc[7], a2.hi >> 32);
+        if (lane == 0) {
+          sh.red[0][wave] = x0;
+          sh.red[1][wave] = x2;
         }
-        __threadfence();
-        const u32 t = __hip_atomic_fetch_add(&gs->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == G - 1) {
-          __threadfence();
-          u64 w[8];
-          for (int k = 0; k < 8; ++k) w[k] = __hip_atomic_exchange(&gs->acc[k], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&gs->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          elt_t s0, s2;
-          if (F == FIELD_GF2_128) {
-            s0 = elt_t{w[0], w[1]};
-            s2 = elt_t{w[2], w[3]};
-          } else {
-            s0 = elt_zero();
-            s2 = elt_zero();
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              s0 = fp_add(s0, fp_add(fp_mul(elt_t{(u64)(u32)w[k], 0}, ld16(&a.fp_pow[k])), fp_mul(elt_t{w[k] >> 32, 0}, ld16(&a.fp_pow[k + 1]))));
-              s2 = fp_add(s2, fp_add(fp_mul(elt_t{(u64)(u32)w[4 + k], 0}, ld16(&a.fp_pow[k])), fp_mul(elt_t{w[4 + k] >> 32, 0}, ld16(&a.fp_pow[k + 1]))));
-            }
+        __syncthreads();
+        if (tid == 0) {
+          x0 = sh.red[0][0];
+          x2 = sh.red[1][0];
+          for (u32 w = 1; w < SM_THREADS / 64; ++w) {
+            x0 = Fld<F>::add(x0, sh.red[0][w]);
+            x2 = Fld<F>::add(x2, sh.red[1][w]);
           }
-          a.post[0] = s0.lo; a.post[1] = s0.hi; a.post[2] = s2.lo; a.post[3] = s2.hi;
-          a.post[4] = nh;
-          a.post[8] = 0;
-          __threadfence_system();
-          __hip_atomic_store((u64*)&a.post[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        __syncthreads();
+      };
+      wg_sum(a0, a2);
+      bool poster = tid == 0;  // thread 0 of the workgroup that holds the device-wide sums
+      if (G > 1) {  // slots + arrival ticket: the last workgroup to arrive folds all slots
+        if (tid == 0) {
+          u64* sl = &gs->slots[4 * g];
+          sl[0] = a0.lo; sl[1] = a0.hi; sl[2] = a2.lo; sl[3] = a2.hi;
+          __threadfence();
+          const u32 t = __hip_atomic_fetch_add(&gs->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          s_last = t == G - 1 ? 1u : 0u;
+          if (s_last) __hip_atomic_store(&gs->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __threadfence();
+        }
+        __syncthreads();
+        poster = false;
+        if (s_last) {  // uniform per workgroup
+          a0 = elt_zero();
+          a2 = elt_zero();
+          if (tid < G) {
+            const u64* sl = &gs->slots[4 * tid];
+            a0 = elt_t{__hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+            a2 = elt_t{__hip_atomic_load(&sl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&sl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+          }
+          wg_sum(a0, a2);
+          poster = tid == 0;
+        }
+      }
+      if (poster) {
+        // the post words live in uncached pinned host memory: write them with system-scope stores, wait until they
+        // have left (workgroup-scope release = s_waitcnt, no L2 write-back), then publish the sequence number
+        u64* po = (u64*)a.post;
+        __hip_atomic_store(&po[0], a0.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[1], a0.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[2], a2.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[3], a2.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[4], (u64)nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[8], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&po[5], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     SC_LAP(2);
@@ -805,13 +824,17 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
           got = __hip_atomic_load((const u64*)&a.cmd[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
           if (got == seq) break;
           if (wall_clock64() - t0 > a.timeout_ticks) break;
-          __builtin_amdgcn_s_sleep(4);
+          __builtin_amdgcn_s_sleep(2);
         }
         if (got == seq) {
-          gs->chal[0] = __hip_atomic_load((const u64*)&a.cmd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          gs->chal[1] = __hip_atomic_load((const u64*)&a.cmd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          __threadfence();
-          __hip_atomic_store(&gs->chal_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          sh.cmd[0] = __hip_atomic_load((const u64*)&a.cmd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          sh.cmd[1] = __hip_atomic_load((const u64*)&a.cmd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (G > 1) {
+            gs->chal[0] = sh.cmd[0];
+            gs->chal[1] = sh.cmd[1];
+            __threadfence();
+            __hip_atomic_store(&gs->chal_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          }
         } else {  // the host went away: release every workgroup and report
           __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           a.post[8] = 1;
@@ -824,13 +847,13 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
           if (got == seq) break;
           if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
           if (wall_clock64() - t0 > 2 * a.timeout_ticks) break;
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(1);
         }
+        __threadfence();
+        sh.cmd[0] = __hip_atomic_load(&gs->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh.cmd[1] = __hip_atomic_load(&gs->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __threadfence();
       sh.cmd[2] = got;
-      sh.cmd[0] = __hip_atomic_load(&gs->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sh.cmd[1] = __hip_atomic_load(&gs->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (sh.cmd[2] != seq) return;  // uniform per workgroup; the barriers of the others see the abort flag
@@ -858,7 +881,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
     }
     const u32 R = ((nh + G - 1) / G + SM_THREADS - 1) / SM_THREADS * SM_THREADS;  // range per workgroup, whole chunks
     const u32 lo = (u64)g * R < nh ? g * R : nh, hi = (u64)lo + R < nh ? lo + R : nh;
-    {
+    if (G > 1) {
       if (tid == 0) sh.carry = 0;
       __syncthreads();
       u32 mine = 0;
@@ -876,7 +899,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       for (u32 i = gtid; i < qwords * nnext; i += GT) a.QW[i] = 0;
     }
     SC_LAP(4);
-    if (!sc_grid_barrier(gs, gen, a.timeout_ticks)) return;
+    if (G > 1 && !sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
     SC_LAP(5);
     // ---- HQuad::bind_h: emit this workgroup's range at its offset
     {
@@ -885,7 +908,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         s_tot = 0;
       }
       __syncthreads();
-      if (tid < G) {
+      if (G > 1 && tid < G) {
         const u32 cnt = a.counts[tid];
         if (cnt) {
           atomicAdd(&s_tot, cnt);
@@ -929,7 +952,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         }
         __syncthreads();
       }
-      nh = s_tot;
+      nh = G > 1 ? s_tot : sh.carry;
       uint2* th = const_cast<uint2*>(hc);
       elt_t* tv = const_cast<elt_t*>(vc);
       hc = hc_o;
@@ -938,14 +961,22 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       vc_o = tv;
     }
     SC_LAP(6);
-    if (!sc_grid_barrier(gs, gen, a.timeout_ticks)) return;
+    if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
     SC_LAP(7);
+    {  // shrink: one workgroup per 1024 entries of the largest array; the others are done
+      u32 big = nh > nW[0] ? nh : nW[0];
+      big = big > nW[1] ? big : nW[1];
+      u32 want = (big + SM_THREADS - 1) / SM_THREADS;
+      want = want ? want : 1;
+      if (want < G) G = want;
+      if (g >= G) return;
+    }
   }
 #ifdef LF_SC_PROF
-  if (gtid == 0)
+  if (g == 0 && tid == 0)
     for (int k = 0; k < 8; ++k) a.post[16 + k] = pt[k];
 #endif
-  if (gtid == 0) {  // end of the layer: W[R,C], W[L,C] and HQUAD->scalar()
+  if (g == 0 && tid == 0) {  // end of the layer: W[R,C], W[L,C] and HQUAD->scalar()
     const elt_t w0 = nW[0] ? ld16(&W[0][0]) : elt_zero();
     const elt_t w1 = nW[1] ? ld16(&W[1][0]) : elt_zero();
     const elt_t sc = nh ? ld16(&vc[0]) : elt_zero();
@@ -1060,47 +1091,40 @@ int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
 }
-// the whole layer as one cooperative launch; d_state: device scratch for ScGridSync + the per-workgroup counts
-int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hcA, void* vcA, void* hcB, void* vcB, size_t nh, void* dW, size_t nw,
-                     void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, const void* fp_pow, size_t logw, void* d_state) {
-  if (logw == 0 || (nh >> 31) || (nw >> 31)) return lf_fail(c, LFGPU_ERR_ARG, "sc_grid_begin: bad operands");
-  static int max_blocks[2] = {0, 0};
-  const int fi = field == LFGPU_FIELD_GF2_128 ? 0 : 1;
-  if (!max_blocks[fi]) {
-    int per_cu = 0;
-    const void* fn = fi == 0 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
-    LF_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SM_THREADS, 0));
-    max_blocks[fi] = per_cu > 0 ? c->num_cu : -1;  // one workgroup per CU
-  }
-  if (max_blocks[fi] < 0) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "sc_grid_begin: kernel cannot be resident");
-  u32 G = (u32)max_blocks[fi];
-  if (G > 256) G = 256;
-  {  // small layers: no more workgroups than 1024-term chunks (fewer arrivals per barrier)
-    const size_t big = nh > nw ? nh : nw;
-    const size_t want = (big + SM_THREADS - 1) / SM_THREADS;
-    if (want < G) G = want ? (u32)want : 1;
-  }
+// round-hands [rh0, 2*logw) of a layer as one cooperative launch on ceil(max size / 1024) workgroups;
+// d_state: LF_SC_GRID_STATE_BYTES of device scratch (ScGridSync + the per-workgroup counts)
+int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, void* W0, size_t nW0,
+                     void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, const void* fp_pow, size_t rh0,
+                     size_t logw, void* d_state) {
+  const size_t big = std::max(nh, std::max(nW0, nW1));
+  if (rh0 >= 2 * logw || big > LF_SC_GRID_MAX) return lf_fail(c, LFGPU_ERR_ARG, "sc_grid_begin: bad operands");
+  static_assert(sizeof(ScGridSync) + 4 * LF_SC_GRID_WGS <= LF_SC_GRID_STATE_BYTES, "grid state size");
+  u32 G = (u32)((big + SM_THREADS - 1) / SM_THREADS);
+  G = G ? G : 1;
+  if (G > LF_SC_GRID_WGS) G = LF_SC_GRID_WGS;
+  if ((int)G > c->num_cu) G = (u32)c->num_cu;
   ScGrid a{};
   a.field = field;
-  a.hcA = (uint2*)hcA; a.vcA = (elt_t*)vcA; a.hcB = (uint2*)hcB; a.vcB = (elt_t*)vcB;
+  a.hcA = (uint2*)hc_cur; a.vcA = (elt_t*)vc_cur; a.hcB = (uint2*)hc_oth; a.vcB = (elt_t*)vc_oth;
   a.nh = (u32)nh;
-  a.dW = (elt_t*)dW;
-  a.nw = (u32)nw;
+  a.W[0] = (elt_t*)W0; a.W[1] = (elt_t*)W1;
+  a.nW[0] = (u32)nW0; a.nW[1] = (u32)nW1;
   a.Wb[0][0] = (elt_t*)Wb00; a.Wb[0][1] = (elt_t*)Wb01; a.Wb[1][0] = (elt_t*)Wb10; a.Wb[1][1] = (elt_t*)Wb11;
   a.QW = (u64*)qw;
   a.fp_pow = (const elt_t*)fp_pow;
+  a.rh0 = (u32)rh0;
   a.rh1 = (u32)(2 * logw);
   a.seq0 = c->poll_seq + 1;
-  c->poll_seq += 2 * logw + 1;
+  c->poll_seq += (2 * logw - rh0) + 1;
   c->poll_next = a.seq0;
   a.timeout_ticks = 5000ull * c->wall_khz;
   a.post = c->poll_h;
   a.cmd = c->poll_h + 64;
   a.gs = (ScGridSync*)d_state;
-  a.counts = (u32*)((uint8_t*)d_state + 256);
-  LF_HIP(c, hipMemsetAsync(d_state, 0, 256 + 4 * 256, c->stream));
+  a.counts = (u32*)((uint8_t*)d_state + sizeof(ScGridSync));
+  LF_HIP(c, hipMemsetAsync(d_state, 0, 64, c->stream));  // counters, abort flag, challenge slot
   void* args[] = {&a};
-  const void* fn = fi == 0 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
+  const void* fn = field == LFGPU_FIELD_GF2_128 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
   LF_HIP(c, hipLaunchCooperativeKernel(fn, dim3(G), dim3(SM_THREADS), args, 0, c->stream));
   return LFGPU_OK;
 }
