@@ -44,15 +44,19 @@ __device__ __forceinline__ u32 lds_slot(u32 k, u32 c, u32 logT, u32 logC) {
 // ------------------------------------------------------------------ K1: Fp128
 // W[i << wshift] = w_T^i (i < T/2).  Optional inter-pass twiddle w_n^{j*(col)}
 // = tw_lo[e & 1023] * tw_hi[e >> 10].
+// tw_hi == nullptr with tw_lo != nullptr: tw_lo is the FULL inter-pass table [j][column] (one product per element
+// instead of two; rows of the grid then vary fastest so that a tile's slice of the table stays in L2 while the
+// batch rows stream past it).
 template <int FFT_THREADS>
 __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt_t* __restrict__ W, u32 wshift,
                                                            const elt_t* __restrict__ tw_lo,
-                                                           const elt_t* __restrict__ tw_hi) {
+                                                           const elt_t* __restrict__ tw_hi, u32 row_fast) {
   extern __shared__ elt_t s[];
   const u32 T = 1u << p.logT, C = 1u << p.logC, tid = threadIdx.x;
-  const u32 cbase = blockIdx.x << p.logC;
-  const elt_t* src = p.src + (long long)blockIdx.y * p.src_row + (long long)blockIdx.x * p.src_tile;
-  elt_t* dst = p.dst + (long long)blockIdx.y * p.dst_row + (long long)blockIdx.x * p.dst_tile;
+  const u32 bx = row_fast ? blockIdx.y : blockIdx.x, by = row_fast ? blockIdx.x : blockIdx.y;  // (tile, batch row)
+  const u32 cbase = bx << p.logC;
+  const elt_t* src = p.src + (long long)by * p.src_row + (long long)bx * p.src_tile;
+  elt_t* dst = p.dst + (long long)by * p.dst_row + (long long)bx * p.dst_tile;
 
   for (u32 e = tid; e < T * C; e += FFT_THREADS) {
     u32 k, c;
@@ -62,18 +66,42 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
     st16(&s[lds_slot(bitrev(k, p.logT), c, p.logT, p.logC)], v);
   }
   __syncthreads();
-  for (u32 st = 0; st < p.logT; ++st) {
-    const u32 m = 1u << st;
+  u32 st = 0;
+  if (p.logT & 1) {  // odd number of stages: stage 0 (twiddle 1) alone, then pairs
     for (u32 e = tid; e < (T >> 1) * C; e += FFT_THREADS) {
-      u32 c = e & (C - 1), b = e >> p.logC;
-      u32 j = b & (m - 1);
-      u32 i0 = ((b >> st) << (st + 1)) + j, i1 = i0 + m;
-      const u32 s0 = lds_slot(i0, c, p.logT, p.logC), s1 = lds_slot(i1, c, p.logT, p.logC);
-      elt_t a0 = ld16(&s[s0]);
-      elt_t a1 = ld16(&s[s1]);
-      if (j) a1 = fp_mul(a1, ld16(&W[(size_t)(j << (p.logT - 1 - st)) << wshift]));
+      const u32 c = e & (C - 1), b = e >> p.logC;
+      const u32 s0 = lds_slot(2 * b, c, p.logT, p.logC), s1 = lds_slot(2 * b + 1, c, p.logT, p.logC);
+      const elt_t a0 = ld16(&s[s0]), a1 = ld16(&s[s1]);
       st16(&s[s0], fp_add(a0, a1));
       st16(&s[s1], fp_sub(a0, a1));
+    }
+    __syncthreads();
+    st = 1;
+  }
+  // two stages per LDS round trip: x0..x3 = s[i0 + k*m]; stage st pairs (x0,x1), (x2,x3) with w_T^(j*T/2m);
+  // stage st+1 pairs (x0,x2) with w_T^(j*T/4m) and (x1,x3) with w_T^((j+m)*T/4m).  Same products, half the LDS
+  // traffic and barriers, and four independent carry chains in flight per thread.
+  for (; st + 1 < p.logT; st += 2) {
+    const u32 m = 1u << st;
+    for (u32 e = tid; e < (T >> 2) * C; e += FFT_THREADS) {
+      const u32 c = e & (C - 1), b = e >> p.logC;
+      const u32 j = b & (m - 1);
+      const u32 i0 = ((b >> st) << (st + 2)) + j;
+      const u32 q0 = lds_slot(i0, c, p.logT, p.logC), q1 = lds_slot(i0 + m, c, p.logT, p.logC);
+      const u32 q2 = lds_slot(i0 + 2 * m, c, p.logT, p.logC), q3 = lds_slot(i0 + 3 * m, c, p.logT, p.logC);
+      elt_t x0 = ld16(&s[q0]), x1 = ld16(&s[q1]), x2 = ld16(&s[q2]), x3 = ld16(&s[q3]);
+      if (j) {
+        const elt_t w1 = ld16(&W[(size_t)(j << (p.logT - 1 - st)) << wshift]);
+        x1 = fp_mul(x1, w1);
+        x3 = fp_mul(x3, w1);
+      }
+      elt_t y0 = fp_add(x0, x1), y1 = fp_sub(x0, x1), y2 = fp_add(x2, x3), y3 = fp_sub(x2, x3);
+      if (j) y2 = fp_mul(y2, ld16(&W[(size_t)(j << (p.logT - 2 - st)) << wshift]));
+      y3 = fp_mul(y3, ld16(&W[(size_t)((j + m) << (p.logT - 2 - st)) << wshift]));
+      st16(&s[q0], fp_add(y0, y2));
+      st16(&s[q2], fp_sub(y0, y2));
+      st16(&s[q1], fp_add(y1, y3));
+      st16(&s[q3], fp_sub(y1, y3));
     }
     __syncthreads();
   }
@@ -83,11 +111,15 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
     if (cbase + c >= p.nbatch) continue;
     elt_t v = ld16(&s[lds_slot(j, c, p.logT, p.logC)]);
     if (tw_lo) {
-      u32 ex = j * (cbase + c);
+      const u32 col = cbase + c, ex = j * col;
       if (ex) {
-        elt_t t = ld16(&tw_lo[ex & 1023]);
-        if (ex >> 10) t = fp_mul(t, ld16(&tw_hi[ex >> 10]));
-        v = fp_mul(v, t);
+        if (tw_hi) {
+          elt_t t = ld16(&tw_lo[ex & 1023]);
+          if (ex >> 10) t = fp_mul(t, ld16(&tw_hi[ex >> 10]));
+          v = fp_mul(v, t);
+        } else {
+          v = fp_mul(v, ld16(&tw_lo[(size_t)j * p.nbatch + col]));
+        }
       }
     }
     st16(dst + (long long)j * p.dk + (long long)c * p.dc, v);
@@ -266,31 +298,53 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     TilePlan p = plan_single(d_A, rows, logn, ld);
     u32 ntiles = (u32)((rows + (1u << p.logC) - 1) >> p.logC);
     size_t lds = ((size_t)16 << p.logT) << p.logC;
-    launch_fp(c, dim3(ntiles, 1), lds, p, (const elt_t*)dW, logTw - logn, (const elt_t*)nullptr, (const elt_t*)nullptr);
+    launch_fp(c, dim3(ntiles, 1), lds, p, (const elt_t*)dW, logTw - logn, (const elt_t*)nullptr, (const elt_t*)nullptr, 0u);
     LF_HIP(c, hipGetLastError());
     return LFGPU_OK;
   }
-  // two passes: inter-pass twiddles w_n^e = lo[e & 1023] * hi[e >> 10]
-  std::string klo = key + ":lo", khi = key + ":hi";
-  if (!lf_table_lookup(c, klo, &dlo) || !lf_table_lookup(c, khi, &dhi)) {
-    std::vector<elt_t> lo(1024), hi((size_t)1 << (logn - 10));
-    elt_t x = h_fp_of_scalar(1);
-    for (size_t i = 0; i < 1024; ++i) {
-      lo[i] = x;
-      x = fp_mul(x, wn);
+  // two passes.  Inter-pass twiddles w_n^(j1*k2): either the full [j1][k2] table (n elements, default: one product
+  // per element, table slices stay in L2 because batch rows vary fastest in the grid) or, with LFGPU_FP_TW=2, the
+  // two-level form lo[e & 1023] * hi[e >> 10] (2 KiB + n/64 bytes of tables, two products per element).
+  static const bool two_level = getenv("LFGPU_FP_TW") && atoi(getenv("LFGPU_FP_TW")) == 2;
+  const size_t n1 = (size_t)1 << logn1, n2 = (size_t)1 << logn2;
+  if (two_level) {
+    std::string klo = key + ":lo", khi = key + ":hi";
+    if (!lf_table_lookup(c, klo, &dlo) || !lf_table_lookup(c, khi, &dhi)) {
+      std::vector<elt_t> lo(1024), hi((size_t)1 << (logn - 10));
+      elt_t x = h_fp_of_scalar(1);
+      for (size_t i = 0; i < 1024; ++i) {
+        lo[i] = x;
+        x = fp_mul(x, wn);
+      }
+      elt_t w1024 = x;  // wn^1024
+      x = h_fp_of_scalar(1);
+      for (size_t i = 0; i < hi.size(); ++i) {
+        hi[i] = x;
+        x = fp_mul(x, w1024);
+      }
+      LF_TRY(lf_table(c, klo, lo.data(), lo.size() * 16, &dlo));
+      LF_TRY(lf_table(c, khi, hi.data(), hi.size() * 16, &dhi));
     }
-    elt_t w1024 = x;  // wn^1024
-    x = h_fp_of_scalar(1);
-    for (size_t i = 0; i < hi.size(); ++i) {
-      hi[i] = x;
-      x = fp_mul(x, w1024);
+  } else {
+    std::string kfull = key + ":full";
+    if (!lf_table_lookup(c, kfull, &dlo)) {
+      std::vector<elt_t> full(n1 * n2);
+      elt_t wj = h_fp_of_scalar(1);  // wn^j1
+      for (size_t j = 0; j < n1; ++j) {
+        elt_t x = h_fp_of_scalar(1);
+        elt_t* row = &full[j * n2];
+        for (size_t k = 0; k < n2; ++k) {
+          row[k] = x;
+          x = fp_mul(x, wj);
+        }
+        wj = fp_mul(wj, wn);
+      }
+      LF_TRY(lf_table(c, kfull, full.data(), full.size() * 16, &dlo));
     }
-    LF_TRY(lf_table(c, klo, lo.data(), lo.size() * 16, &dlo));
-    LF_TRY(lf_table(c, khi, hi.data(), hi.size() * 16, &dhi));
+    dhi = nullptr;
   }
   void* scratch = nullptr;
   LF_TRY(lf_scratch(c, rows * n * 16, &scratch));
-  const size_t n1 = (size_t)1 << logn1, n2 = (size_t)1 << logn2;
   {  // pass A: n1-point transforms over k1 (stride n2), C consecutive k2 per tile
     TilePlan p{};
     p.logT = logn1;
@@ -306,8 +360,10 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     p.nbatch = (u32)n2;
     p.kfast_src = p.kfast_dst = 0;
     size_t lds = ((size_t)16 << p.logT) << p.logC;
-    launch_fp(c, dim3((u32)(n2 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo,
-              (const elt_t*)dhi);
+    if (!two_level && rows <= 65535)  // rows fastest: the tile's table slice is reused by every row while it is hot
+      launch_fp(c, dim3((u32)rows, (u32)(n2 >> p.logC)), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi, 1u);
+    else
+      launch_fp(c, dim3((u32)(n2 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi, 0u);
     LF_HIP(c, hipGetLastError());
   }
   {  // pass B: n2-point transforms on contiguous rows j1; output X[j1 + n1*j2]
@@ -330,7 +386,7 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     p.kfast_dst = 0;
     size_t lds = ((size_t)16 << p.logT) << p.logC;
     launch_fp(c, dim3((u32)(n1 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn2, (const elt_t*)nullptr,
-              (const elt_t*)nullptr);
+              (const elt_t*)nullptr, 0u);
     LF_HIP(c, hipGetLastError());
   }
   return LFGPU_OK;
