@@ -28,6 +28,7 @@ struct TilePlan {
   long long sk, sc, dk, dc;      // strides of the point index k and batch index c
   u32 logT, logC, nbatch;        // nbatch: total batch columns over all tiles (bounds)
   u32 kfast_src, kfast_dst;      // 1: consecutive lanes walk k (stride-1 side), 0: walk c
+  u32 wlds;                      // Fp128: stage twiddles staged in LDS behind the tile
 };
 
 __device__ __forceinline__ u32 bitrev(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -65,6 +66,16 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
     if (cbase + c < p.nbatch) v = ld16(src + (long long)k * p.sk + (long long)c * p.sc);
     st16(&s[lds_slot(bitrev(k, p.logT), c, p.logT, p.logC)], v);
   }
+  // the T/2 stage twiddles w_T^i go behind the tile in LDS: three twiddle reads per radix-4 step then cost an LDS
+  // access instead of a vector-memory instruction each
+  const elt_t* Wl = W;  // stage twiddle i at Wl[i << wsh]
+  u32 wsh = wshift;
+  if (p.wlds) {
+    elt_t* const wl = s + ((size_t)T << p.logC);
+    for (u32 i = tid; i < (T >> 1); i += FFT_THREADS) st16(&wl[i], ld16(&W[(size_t)i << wshift]));
+    Wl = wl;
+    wsh = 0;
+  }
   __syncthreads();
   u32 st = 0;
   if (p.logT & 1) {  // odd number of stages: stage 0 (twiddle 1) alone, then pairs
@@ -91,13 +102,13 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
       const u32 q2 = lds_slot(i0 + 2 * m, c, p.logT, p.logC), q3 = lds_slot(i0 + 3 * m, c, p.logT, p.logC);
       elt_t x0 = ld16(&s[q0]), x1 = ld16(&s[q1]), x2 = ld16(&s[q2]), x3 = ld16(&s[q3]);
       if (j) {
-        const elt_t w1 = ld16(&W[(size_t)(j << (p.logT - 1 - st)) << wshift]);
+        const elt_t w1 = ld16(&Wl[(size_t)(j << (p.logT - 1 - st)) << wsh]);
         x1 = fp_mul(x1, w1);
         x3 = fp_mul(x3, w1);
       }
       elt_t y0 = fp_add(x0, x1), y1 = fp_sub(x0, x1), y2 = fp_add(x2, x3), y3 = fp_sub(x2, x3);
-      if (j) y2 = fp_mul(y2, ld16(&W[(size_t)(j << (p.logT - 2 - st)) << wshift]));
-      y3 = fp_mul(y3, ld16(&W[(size_t)((j + m) << (p.logT - 2 - st)) << wshift]));
+      if (j) y2 = fp_mul(y2, ld16(&Wl[(size_t)(j << (p.logT - 2 - st)) << wsh]));
+      y3 = fp_mul(y3, ld16(&Wl[(size_t)((j + m) << (p.logT - 2 - st)) << wsh]));
       st16(&s[q0], fp_add(y0, y2));
       st16(&s[q2], fp_sub(y0, y2));
       st16(&s[q1], fp_add(y1, y3));
@@ -196,8 +207,8 @@ static int set_lds_limit(lfgpu_ctx* c) {
       int v = atoi(e);
       if (v == 12 || v == 13) g_tile_log = v;
     }
-    LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
-    LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
+    LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     LF_HIP(c, hipFuncSetAttribute((const void*)lch_fft_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
     LF_HIP(c, hipFuncSetAttribute((const void*)lch_fft_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
     done = true;
@@ -205,6 +216,12 @@ static int set_lds_limit(lfgpu_ctx* c) {
   return LFGPU_OK;
 }
 
+// LDS of one Fp128 tile: the elements, plus the T/2 stage twiddles when both fit (p.wlds)
+static size_t fp_lds_bytes(TilePlan& p) {
+  const size_t tile = ((size_t)16 << p.logT) << p.logC, tw = (size_t)8 << p.logT;
+  p.wlds = tile + tw <= 160u * 1024u ? 1u : 0u;
+  return p.wlds ? tile + tw : tile;
+}
 template <class... Args>
 static void launch_fp(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
   if (g_tile_log == 13)
@@ -297,7 +314,7 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
   if (logn1 == 0) {
     TilePlan p = plan_single(d_A, rows, logn, ld);
     u32 ntiles = (u32)((rows + (1u << p.logC) - 1) >> p.logC);
-    size_t lds = ((size_t)16 << p.logT) << p.logC;
+    size_t lds = fp_lds_bytes(p);
     launch_fp(c, dim3(ntiles, 1), lds, p, (const elt_t*)dW, logTw - logn, (const elt_t*)nullptr, (const elt_t*)nullptr, 0u);
     LF_HIP(c, hipGetLastError());
     return LFGPU_OK;
@@ -359,7 +376,7 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     p.sc = p.dc = 1;
     p.nbatch = (u32)n2;
     p.kfast_src = p.kfast_dst = 0;
-    size_t lds = ((size_t)16 << p.logT) << p.logC;
+    size_t lds = fp_lds_bytes(p);
     if (!two_level && rows <= 65535)  // rows fastest: the tile's table slice is reused by every row while it is hot
       launch_fp(c, dim3((u32)rows, (u32)(n2 >> p.logC)), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi, 1u);
     else
@@ -384,7 +401,7 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     p.nbatch = (u32)n1;
     p.kfast_src = 1;
     p.kfast_dst = 0;
-    size_t lds = ((size_t)16 << p.logT) << p.logC;
+    size_t lds = fp_lds_bytes(p);
     launch_fp(c, dim3((u32)(n1 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn2, (const elt_t*)nullptr,
               (const elt_t*)nullptr, 0u);
     LF_HIP(c, hipGetLastError());
