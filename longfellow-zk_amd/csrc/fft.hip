@@ -45,6 +45,41 @@ __device__ __forceinline__ u32 lds_slot(u32 k, u32 c, u32 logT, u32 logC) {
 // ------------------------------------------------------------------ K1: Fp128
 // W[i << wshift] = w_T^i (i < T/2).  Optional inter-pass twiddle w_n^{j*(col)}
 // = tw_lo[e & 1023] * tw_hi[e >> 10].
+template <int R, int FFT_THREADS>
+__device__ __forceinline__ void fp_radix_round(elt_t* s, const elt_t* Wl, u32 wsh, u32 logT, u32 logC, u32 st, u32 tid) {
+  constexpr u32 N = 1u << R;
+  const u32 T = 1u << logT, C = 1u << logC, m = 1u << st;
+  for (u32 e = tid; e < (T >> R) * C; e += FFT_THREADS) {
+    const u32 c = e & (C - 1), b = e >> logC;
+    const u32 j = b & (m - 1);
+    const u32 i0 = ((b >> st) << (st + R)) + j;
+    elt_t x[N];
+    u32 q[N];
+#pragma unroll
+    for (u32 a = 0; a < N; ++a) {
+      q[a] = lds_slot(i0 + a * m, c, logT, logC);
+      x[a] = ld16(&s[q[a]]);
+    }
+#pragma unroll
+    for (u32 t = 0; t < (u32)R; ++t) {
+      const u32 half = 1u << t;
+#pragma unroll
+      for (u32 a = 0; a < N; ++a) {
+        if (a & half) continue;
+        const u32 jj = j + (a & (half - 1)) * m;
+        if (t > 0 || j) {
+          if ((a & (half - 1)) || j) x[a + half] = fp_mul(x[a + half], ld16(&Wl[(size_t)(jj << (logT - 1 - st - t)) << wsh]));
+        }
+        const elt_t u = x[a], v = x[a + half];
+        x[a] = fp_add(u, v);
+        x[a + half] = fp_sub(u, v);
+      }
+    }
+#pragma unroll
+    for (u32 a = 0; a < N; ++a) st16(&s[q[a]], x[a]);
+  }
+}
+
 // tw_hi == nullptr with tw_lo != nullptr: tw_lo is the FULL inter-pass table [j][column] (one product per element
 // instead of two; rows of the grid then vary fastest so that a tile's slice of the table stays in L2 while the
 // batch rows stream past it).
@@ -77,44 +112,18 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
     wsh = 0;
   }
   __syncthreads();
+  // R stages per LDS round trip on 2^R register-resident points x[a] = s[i0 + a*m]: sub-stage t pairs (a, a + 2^t)
+  // with w_T^(jj * T / (2m 2^t)), jj = j + (a mod 2^t) * m.  Same products as radix 2, 1/R of the LDS traffic and
+  // barriers, and 2^(R-1) independent carry chains in flight per thread.
   u32 st = 0;
-  if (p.logT & 1) {  // odd number of stages: stage 0 (twiddle 1) alone, then pairs
-    for (u32 e = tid; e < (T >> 1) * C; e += FFT_THREADS) {
-      const u32 c = e & (C - 1), b = e >> p.logC;
-      const u32 s0 = lds_slot(2 * b, c, p.logT, p.logC), s1 = lds_slot(2 * b + 1, c, p.logT, p.logC);
-      const elt_t a0 = ld16(&s[s0]), a1 = ld16(&s[s1]);
-      st16(&s[s0], fp_add(a0, a1));
-      st16(&s[s1], fp_sub(a0, a1));
-    }
+  while (st < p.logT) {
+    const u32 rem = p.logT - st;
+    const u32 R = (rem == 3 || rem > 4) ? 3 : (rem >= 2 ? 2 : 1);
+    if (R == 3) fp_radix_round<3, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
+    else if (R == 2) fp_radix_round<2, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
+    else fp_radix_round<1, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
     __syncthreads();
-    st = 1;
-  }
-  // two stages per LDS round trip: x0..x3 = s[i0 + k*m]; stage st pairs (x0,x1), (x2,x3) with w_T^(j*T/2m);
-  // stage st+1 pairs (x0,x2) with w_T^(j*T/4m) and (x1,x3) with w_T^((j+m)*T/4m).  Same products, half the LDS
-  // traffic and barriers, and four independent carry chains in flight per thread.
-  for (; st + 1 < p.logT; st += 2) {
-    const u32 m = 1u << st;
-    for (u32 e = tid; e < (T >> 2) * C; e += FFT_THREADS) {
-      const u32 c = e & (C - 1), b = e >> p.logC;
-      const u32 j = b & (m - 1);
-      const u32 i0 = ((b >> st) << (st + 2)) + j;
-      const u32 q0 = lds_slot(i0, c, p.logT, p.logC), q1 = lds_slot(i0 + m, c, p.logT, p.logC);
-      const u32 q2 = lds_slot(i0 + 2 * m, c, p.logT, p.logC), q3 = lds_slot(i0 + 3 * m, c, p.logT, p.logC);
-      elt_t x0 = ld16(&s[q0]), x1 = ld16(&s[q1]), x2 = ld16(&s[q2]), x3 = ld16(&s[q3]);
-      if (j) {
-        const elt_t w1 = ld16(&Wl[(size_t)(j << (p.logT - 1 - st)) << wsh]);
-        x1 = fp_mul(x1, w1);
-        x3 = fp_mul(x3, w1);
-      }
-      elt_t y0 = fp_add(x0, x1), y1 = fp_sub(x0, x1), y2 = fp_add(x2, x3), y3 = fp_sub(x2, x3);
-      if (j) y2 = fp_mul(y2, ld16(&Wl[(size_t)(j << (p.logT - 2 - st)) << wsh]));
-      y3 = fp_mul(y3, ld16(&Wl[(size_t)((j + m) << (p.logT - 2 - st)) << wsh]));
-      st16(&s[q0], fp_add(y0, y2));
-      st16(&s[q2], fp_sub(y0, y2));
-      st16(&s[q1], fp_add(y1, y3));
-      st16(&s[q3], fp_sub(y1, y3));
-    }
-    __syncthreads();
+    st += R;
   }
   for (u32 e = tid; e < T * C; e += FFT_THREADS) {
     u32 j, c;
