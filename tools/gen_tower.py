@@ -260,9 +260,41 @@ def emit_program(name, rows, nin, in_expr, out_expr, doc):
     def var(i):
         return in_expr % i if i < nin else "t%d_" % i
 
-    for (n, a, b) in gates:
-        lines.append("  const u32 t%d_ = %s ^ %s; \\" % (n, var(a), var(b)))
-    for o, vs in enumerate(outs):
+    # emission order: output by output, each temporary right before its first use (depth first), and the outputs
+    # in an order that keeps temporaries shared by few outputs short-lived -- the straight-line program is
+    # register-bound on the GPU (128 inputs in LDS, 32 outputs and the live temporaries in VGPRs)
+    gate = {n: (a, b) for (n, a, b) in gates}
+    need = []
+    for vs in outs:
+        seen, stack = set(), [v for v in vs if v >= nin]
+        while stack:
+            v = stack.pop()
+            if v in seen:
+                continue
+            seen.add(v)
+            stack.extend(x for x in gate[v] if x >= nin)
+        need.append(seen)
+    order, done_t, left = [], set(), set(range(len(outs)))
+    while left:
+        o = min(left, key=lambda i: (len(need[i] - done_t), i))  # cheapest next output given what is already live
+        left.remove(o)
+        order.append(o)
+        done_t |= need[o]
+    emitted = set()
+
+    def emit_temp(v):
+        if v < nin or v in emitted:
+            return
+        a, b = gate[v]
+        emit_temp(a)
+        emit_temp(b)
+        emitted.add(v)
+        lines.append("  const u32 t%d_ = %s ^ %s; \\" % (v, var(a), var(b)))
+
+    for o in order:
+        vs = outs[o]
+        for v in vs:
+            emit_temp(v)
         expr = " ^ ".join(var(v) for v in vs) if vs else "0u"
         lines.append("  %s = %s; \\" % (out_expr % o, expr))
     lines.append("} while (0)")
