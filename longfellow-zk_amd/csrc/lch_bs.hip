@@ -33,9 +33,9 @@ static u32 g_bs_rlog = 5;
 // writes of the four dwords of a column land on distinct banks.
 #define BS_PL(p, lc) ((p) * BS_COLS + ((lc) ^ ((((u32)(p)) >> 5) << 3)))
 
-template <int K>
-__global__ __launch_bounds__(256, 2) void bs_cin_kernel(const elt_t* __restrict__ src, size_t ld, u32 rows, u32 n,
-                                                        u32* __restrict__ dst) {
+template <int K, int WPC>
+__global__ __launch_bounds__(256, WPC) void bs_cin_kernel(const elt_t* __restrict__ src, size_t ld, u32 rows, u32 n,
+                                                          u32* __restrict__ dst) {
   constexpr int M = Tower<K>::M, D = Tower<K>::D;
   extern __shared__ u32 lds[];  // 32 rows x BS_COLS x 4 words, then 128 planes x BS_COLS words
   const u32 t = threadIdx.x, rg = blockIdx.y, c0 = blockIdx.x * BS_COLS;
@@ -68,16 +68,29 @@ __global__ __launch_bounds__(256, 2) void bs_cin_kernel(const elt_t* __restrict_
     const u32 lc = t & (BS_COLS - 1), q0 = t / BS_COLS;
 #define BS_IN(i) lds[BS_PL(i, lc)]
 #define BS_OUT(o) out[o]
-    for (u32 q = q0; q < (u32)D; q += 256 / BS_COLS) {
-      u32 out[M];
-      if (K == 5) {
-        switch (q) {
-          case 0: TOWER_K5_P2T_Q0(BS_IN, BS_OUT); break;
-          case 1: TOWER_K5_P2T_Q1(BS_IN, BS_OUT); break;
-          case 2: TOWER_K5_P2T_Q2(BS_IN, BS_OUT); break;
-          default: TOWER_K5_P2T_Q3(BS_IN, BS_OUT); break;
+    if (K == 5) {
+      // 16 outputs per program (half a coordinate): +4 % XORs over the 32-output programs, about half the live
+      // registers; a wave does both halves of its coordinate one after the other
+      const u32 q = q0;  // D == 4 == waves per workgroup
+      for (u32 hh = 0; hh < 2; ++hh) {
+        u32 out[16];
+        switch (2 * q + hh) {
+          case 0: TOWER_K5_P2T_Q0H0(BS_IN, BS_OUT); break;
+          case 1: TOWER_K5_P2T_Q0H1(BS_IN, BS_OUT); break;
+          case 2: TOWER_K5_P2T_Q1H0(BS_IN, BS_OUT); break;
+          case 3: TOWER_K5_P2T_Q1H1(BS_IN, BS_OUT); break;
+          case 4: TOWER_K5_P2T_Q2H0(BS_IN, BS_OUT); break;
+          case 5: TOWER_K5_P2T_Q2H1(BS_IN, BS_OUT); break;
+          case 6: TOWER_K5_P2T_Q3H0(BS_IN, BS_OUT); break;
+          default: TOWER_K5_P2T_Q3H1(BS_IN, BS_OUT); break;
         }
-      } else {
+        uint4* u = reinterpret_cast<uint4*>(dst + ((size_t)(rg * D + q) * n + c0 + lc) * M + 16 * hh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = make_uint4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
+      }
+    } else {
+      for (u32 q = q0; q < (u32)D; q += 256 / BS_COLS) {
+        u32 out[M];
         switch (q) {
           case 0: TOWER_K4_P2T_Q0(BS_IN, BS_OUT); break;
           case 1: TOWER_K4_P2T_Q1(BS_IN, BS_OUT); break;
@@ -88,10 +101,10 @@ __global__ __launch_bounds__(256, 2) void bs_cin_kernel(const elt_t* __restrict_
           case 6: TOWER_K4_P2T_Q6(BS_IN, BS_OUT); break;
           default: TOWER_K4_P2T_Q7(BS_IN, BS_OUT); break;
         }
-      }
-      uint4* u = reinterpret_cast<uint4*>(dst + ((size_t)(rg * D + q) * n + c0 + lc) * M);
+        uint4* u = reinterpret_cast<uint4*>(dst + ((size_t)(rg * D + q) * n + c0 + lc) * M);
 #pragma unroll
-      for (int j = 0; j < M / 4; ++j) u[j] = make_uint4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
+        for (int j = 0; j < M / 4; ++j) u[j] = make_uint4(out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]);
+      }
     }
 #undef BS_IN
 #undef BS_OUT
@@ -337,8 +350,13 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
   }
   if (combos > nrg * D)  // padded combos: define the bits (values are never read back)
     LF_HIP(c, hipMemsetAsync((u32*)internal + (size_t)nrg * D * n * M, 0, (size_t)(combos - nrg * D) * n * M * 4, c->stream));
-  hipLaunchKernelGGL(bs_cin_kernel<K>, dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
-                     (u32*)internal);
+  static const int cin_wpc = getenv("LFGPU_BS_CIN_WPC") ? atoi(getenv("LFGPU_BS_CIN_WPC")) : 2;
+  if (cin_wpc == 3)
+    hipLaunchKernelGGL((bs_cin_kernel<K, 3>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
+                       (u32*)internal);
+  else
+    hipLaunchKernelGGL((bs_cin_kernel<K, 2>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
+                       (u32*)internal);
   // bit groups of <= BS_NB_MAX index bits; FFT walks stages l-1..0, IFFT 0..l-1
   std::vector<std::pair<u32, u32>> groups;  // (lo_bit, nb), ascending
   for (u32 lo = 0; lo < l; lo += nbmax) groups.push_back({lo, std::min<u32>(nbmax, l - lo)});

@@ -378,6 +378,13 @@ def main():
                                     "poly planes -> tower coordinate %d" % q)
             out.append(prog)
             total += nx
+        if m == 32:  # half programs (16 outputs): lower register pressure, 2x the tasks
+            for q in range(d):
+                for hh in range(2):
+                    prog, nx = emit_program("TOWER_K%d_P2T_Q%dH%d" % (k, q, hh), to_tower[q * m + 16 * hh:q * m + 16 * hh + 16], 128,
+                                            "IN(%d)", "OUT(%d)", "poly planes -> tower coordinate %d, planes %d..%d" % (q, 16 * hh, 16 * hh + 15))
+                    out.append(prog)
+                    halves_total = nx
         # tower -> poly, output chunks of 32 poly planes (one dword of the element), inputs = 128 tower planes
         for w in range(4):
             prog, nx = emit_program("TOWER_K%d_T2P_W%d" % (k, w), to_poly[w * 32:(w + 1) * 32], 128, "IN(%d)", "OUT(%d)",
