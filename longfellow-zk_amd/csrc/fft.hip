@@ -386,7 +386,8 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     p.nbatch = (u32)n2;
     p.kfast_src = p.kfast_dst = 0;
     size_t lds = fp_lds_bytes(p);
-    if (!two_level && rows <= 65535)  // rows fastest: the tile's table slice is reused by every row while it is hot
+    static const bool row_fast_env = !(getenv("LFGPU_FP_ROWFAST") && atoi(getenv("LFGPU_FP_ROWFAST")) == 0);
+    if (!two_level && rows <= 65535 && row_fast_env)  // rows fastest: the tile's table slice is reused by every row while it is hot
       launch_fp(c, dim3((u32)rows, (u32)(n2 >> p.logC)), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi, 1u);
     else
       launch_fp(c, dim3((u32)(n2 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi, 0u);
