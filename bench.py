@@ -228,11 +228,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    launches_per_step = 1 if logn <= 13 else 2  # fp_fft_tile passes (fft.hip)
-    # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), collected
+    launches_per_step = 1 if logn <= 12 else 2  # fp_fft_tile passes (fft.hip: tiles of 2^12 elements)
+    # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE with the gfx950 correction + WRITE_SIZE), collected
     # with the same command and committed under profiles/ -- counters cannot be read in-process
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_fp_fft_tile.json")
+    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_fp_fft_tile_v7.json")
     if os.path.exists(pmc) and rows == 1024 and logn == 20:
         with open(pmc) as f:
             traffic = json.load(f)["hbm_bytes_per_launch"]
