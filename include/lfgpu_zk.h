@@ -54,7 +54,10 @@ void lfgpu_transcript_bytes(lfgpu_transcript* t, uint8_t* out, size_t n);
 /* primitives the transcript is built from (known-answer tested) */
 void lfgpu_sha256(const uint8_t* data, size_t n, uint8_t out[32]);
 void lfgpu_aes256_ecb_block(const uint8_t key[32], const uint8_t in[16], uint8_t out[16]);
-/* SHA-NI / AES-NI dispatch: force_portable = 1 / 0 switches the portable C++ paths on / off, < 0 only queries;
+/* host-side GF(2^128) product used by the driver's bookkeeping (GF2_128::mulf, lib/gf2k/gf2_128.h:233-246):
+ * PCLMULQDQ when available, portable otherwise */
+void lfgpu_host_gf2128_mul(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]);
+/* SHA-NI / AES-NI / PCLMULQDQ dispatch: force_portable = 1 / 0 switches the portable C++ paths on / off, < 0 only queries;
  * returns 1 when the hardware paths are active. */
 int lfgpu_crypto_hw(int force_portable);
 

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     # include/lfgpu_zk.h
     "lfgpu_transcript_new", "lfgpu_transcript_free", "lfgpu_transcript_get_ops", "lfgpu_transcript_write_bytes",
     "lfgpu_transcript_write_elt", "lfgpu_transcript_write_elt_array", "lfgpu_transcript_bytes", "lfgpu_sha256",
-    "lfgpu_aes256_ecb_block", "lfgpu_crypto_hw", "lfgpu_circuit_from_lfc1", "lfgpu_circuit_get_info", "lfgpu_circuit_layer_info",
+    "lfgpu_aes256_ecb_block", "lfgpu_host_gf2128_mul", "lfgpu_crypto_hw", "lfgpu_circuit_from_lfc1", "lfgpu_circuit_get_info", "lfgpu_circuit_layer_info",
     "lfgpu_circuit_free", "lfgpu_zk_prover_new", "lfgpu_zk_prover_param", "lfgpu_zk_commit", "lfgpu_zk_prove",
     "lfgpu_zk_proof_write", "lfgpu_zk_timings", "lfgpu_zk_prover_free",
 ]
@@ -138,7 +138,8 @@ def load_library():
     for name, args in (("lfgpu_transcript_free", [vp]), ("lfgpu_transcript_get_ops", [vp, C.POINTER(TranscriptOps)]),
                        ("lfgpu_transcript_write_bytes", [vp, vp, sz]), ("lfgpu_transcript_write_elt", [vp, vp]),
                        ("lfgpu_transcript_write_elt_array", [vp, vp, sz]), ("lfgpu_transcript_bytes", [vp, vp, sz]),
-                       ("lfgpu_sha256", [vp, sz, vp]), ("lfgpu_aes256_ecb_block", [vp, vp, vp])):
+                       ("lfgpu_sha256", [vp, sz, vp]), ("lfgpu_aes256_ecb_block", [vp, vp, vp]),
+                       ("lfgpu_host_gf2128_mul", [pu64, pu64, pu64])):
         fn = getattr(L, name)
         fn.restype, fn.argtypes = None, args
     _lib = L

@@ -20,13 +20,14 @@ const uint32_t kK256[64] = {
 
 int g_force_portable = 0;
 struct HwCaps {
-  bool sha = false, aes = false;
+  bool sha = false, aes = false, clmul = false;
   HwCaps() {
 #if FS_X86
     unsigned a, b, c, d;
     if (__get_cpuid(1, &a, &b, &c, &d)) {
       const bool ssse3 = c & (1u << 9), sse41 = c & (1u << 19);
       aes = (c & (1u << 25)) && sse41;
+      clmul = (c & (1u << 1)) && sse41;
       if (__get_cpuid_count(7, 0, &a, &b, &c, &d)) sha = (b & (1u << 29)) && ssse3 && sse41;
     }
 #endif
@@ -163,6 +164,36 @@ void aes256_encrypt_portable(const uint8_t rk[15][16], const uint8_t in[16], uin
   memcpy(out, s, 16);
 }
 }  // namespace
+
+#if FS_X86
+__attribute__((target("pclmul,sse4.1"))) static void gf128_mul_clmul(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]) {
+  const __m128i x = _mm_loadu_si128((const __m128i*)a), y = _mm_loadu_si128((const __m128i*)b);
+  const __m128i t0 = _mm_clmulepi64_si128(x, y, 0x00), t3 = _mm_clmulepi64_si128(x, y, 0x11);
+  const __m128i mid = _mm_xor_si128(_mm_clmulepi64_si128(x, y, 0x10), _mm_clmulepi64_si128(x, y, 0x01));
+  uint64_t p0 = (uint64_t)_mm_extract_epi64(t0, 0), p1 = (uint64_t)_mm_extract_epi64(t0, 1) ^ (uint64_t)_mm_extract_epi64(mid, 0);
+  uint64_t p2 = (uint64_t)_mm_extract_epi64(t3, 0) ^ (uint64_t)_mm_extract_epi64(mid, 1), p3 = (uint64_t)_mm_extract_epi64(t3, 1);
+  // x^128 = x^7 + x^2 + x + 1: fold the two high words down, top word first
+  const __m128i r = _mm_set_epi64x(0, 0x87);
+  __m128i f = _mm_clmulepi64_si128(_mm_set_epi64x(0, (long long)p3), r, 0x00);
+  p1 ^= (uint64_t)_mm_extract_epi64(f, 0);
+  p2 ^= (uint64_t)_mm_extract_epi64(f, 1);
+  f = _mm_clmulepi64_si128(_mm_set_epi64x(0, (long long)p2), r, 0x00);
+  p0 ^= (uint64_t)_mm_extract_epi64(f, 0);
+  p1 ^= (uint64_t)_mm_extract_epi64(f, 1);
+  out[0] = p0;
+  out[1] = p1;
+}
+#endif
+bool fs_gf128_mul(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]) {
+#if FS_X86
+  if (caps().clmul && !g_force_portable) {
+    gf128_mul_clmul(a, b, out);
+    return true;
+  }
+#endif
+  (void)a; (void)b; (void)out;
+  return false;
+}
 
 int fs_crypto_hw() { return (caps().sha && caps().aes && !g_force_portable) ? 1 : 0; }
 void fs_crypto_force_portable(int on) { g_force_portable = on; }

@@ -24,6 +24,11 @@ struct Aes256 {
   void ctr_blocks(uint64_t ctr0, size_t nblocks, uint8_t* out) const;
 };
 
+// GF(2^128) product mod x^128 + x^7 + x^2 + x + 1 (GF2_128::mulf, lib/gf2k/gf2_128.h:233-246) on the host with
+// PCLMULQDQ; returns false (out untouched) when the instruction is missing or the portable paths are forced, so
+// the caller falls back to the portable product of fields.h.  Operands: two little-endian u64 each.
+bool fs_gf128_mul(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]);
+
 // 1 when the SHA-NI / AES-NI paths are in use (for the tests; 0 = portable code)
 int fs_crypto_hw();
 // force the portable paths (tests compare both)

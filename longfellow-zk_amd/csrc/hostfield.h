@@ -1,13 +1,21 @@
 // hostfield.h -- host-side scalar field helpers shared by the C++ host loops (sumcheck layer, ZK prover).
 #pragma once
 #include "ctx.h"
+#include "fs_crypto.h"
+
+// host GF(2^128) product: PCLMULQDQ when the CPU has it (fs_crypto.cc), else the portable product of fields.h
+static inline elt_t h_gf_mul(elt_t a, elt_t b) {
+  uint64_t x[2] = {a.lo, a.hi}, y[2] = {b.lo, b.hi}, o[2];
+  if (fs_gf128_mul(x, y, o)) return elt_t{o[0], o[1]};
+  return gf_mul(a, b);
+}
 
 struct HostField {
   int field;
   elt_t one, pts[3], invden[3];
   elt_t add(elt_t a, elt_t b) const { return field == LFGPU_FIELD_GF2_128 ? gf_add(a, b) : fp_add(a, b); }
   elt_t sub(elt_t a, elt_t b) const { return field == LFGPU_FIELD_GF2_128 ? gf_add(a, b) : fp_sub(a, b); }
-  elt_t mul(elt_t a, elt_t b) const { return field == LFGPU_FIELD_GF2_128 ? gf_mul(a, b) : fp_mul(a, b); }
+  elt_t mul(elt_t a, elt_t b) const { return field == LFGPU_FIELD_GF2_128 ? h_gf_mul(a, b) : fp_mul(a, b); }
   elt_t inv(elt_t a) const { return field == LFGPU_FIELD_GF2_128 ? h_gf_inv(a) : h_fp_inv(a); }
   explicit HostField(lfgpu_ctx* c, int f) : field(f) {
     if (f == LFGPU_FIELD_GF2_128) {  // poly_evaluation_points_ = 0, 1, g (lib/gf2k/gf2_128.h:121-127)

@@ -102,6 +102,11 @@ void lfgpu_sha256(const uint8_t* data, size_t n, uint8_t out[32]) {
   s.update(data, n);
   s.digest(out);
 }
+void lfgpu_host_gf2128_mul(const uint64_t a[2], const uint64_t b[2], uint64_t out[2]) {
+  const elt_t r = h_gf_mul(elt_t{a[0], a[1]}, elt_t{b[0], b[1]});
+  out[0] = r.lo;
+  out[1] = r.hi;
+}
 int lfgpu_crypto_hw(int force_portable) {
   if (force_portable >= 0) fs_crypto_force_portable(force_portable);
   return fs_crypto_hw();
@@ -416,7 +421,7 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
     P.wc[1] = draw();
     Wv[w++] = P.wc[0];
     Wv[w++] = P.wc[1];
-    Wv[w++] = gf_mul(P.wc[0], P.wc[1]);
+    Wv[w++] = h_gf_mul(P.wc[0], P.wc[1]);
     const size_t cp = pi + 4 * logw;  // setup_lqc (zk_common.h:149-160): claim_pad(0..2)
     zk->lqc[3 * ly] = cp;
     zk->lqc[3 * ly + 1] = cp + 1;
@@ -629,13 +634,16 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
     std::vector<elt_t> u_ldt(p.nwqrow);
     for (auto& e : u_ldt) e = ts.elt();
     zk->y_ldt.assign(p.block, elt_t{0, 0});
+    static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
+    double tq[6] = {now_ms(), 0, 0, 0, 0, 0};
     LF_TRY(lfgpu_ligero_low_degree_proof(zk->lp, u_ldt.data(), zk->y_ldt.data()));
+    tq[1] = now_ms();
     std::vector<elt_t> alphal(nconstraints), alphaq(3 * p.nq);
     for (auto& e : alphal) e = ts.elt();
     for (auto& e : alphaq) e = ts.elt();
     // inner_product_vector (ligero_param.h:382-421)
-    for (size_t w = 0; w < zk->n_witness; ++w) A[w] = gf_mul(alphal[dense_c], bi[w]);
-    for (const Term& t : a) A[t.w] = gf_add(A[t.w], gf_mul(t.k, alphal[t.c]));
+    for (size_t w = 0; w < zk->n_witness; ++w) A[w] = h_gf_mul(alphal[dense_c], bi[w]);
+    for (const Term& t : a) A[t.w] = gf_add(A[t.w], h_gf_mul(t.k, alphal[t.c]));
     const size_t base = p.nwrow * p.w;
     const size_t Ax = base, Ay = base + p.nqtriples * p.w, Az = base + 2 * p.nqtriples * p.w;
     for (size_t iw = 0; iw < p.nq; ++iw) {
@@ -648,12 +656,15 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
       }
     }
     zk->y_dot.assign(p.dblock, elt_t{0, 0});
+    tq[2] = now_ms();
     LF_TRY(lfgpu_ligero_dot_proof(zk->lp, A.data(), zk->y_dot.data()));
+    tq[3] = now_ms();
     std::vector<elt_t> u_quad(p.nqtriples ? p.nqtriples : 1);
     for (size_t i = 0; i < p.nqtriples; ++i) u_quad[i] = ts.elt();
     zk->y_q0.assign(p.r, elt_t{0, 0});
     zk->y_q2.assign(p.dblock - p.block, elt_t{0, 0});
     LF_TRY(lfgpu_ligero_quadratic_proof(zk->lp, u_quad.data(), zk->y_q0.data(), zk->y_q2.data()));
+    tq[4] = now_ms();
     ts.write_array(zk->y_ldt.data(), zk->y_ldt.size());
     ts.write_array(zk->y_dot.data(), zk->y_dot.size());
     ts.write_array(zk->y_q0.data(), zk->y_q0.size());
@@ -665,6 +676,10 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
     const size_t cap = p.nreq * p.mc_pathlen + 1;
     zk->path.assign(cap * 32, 0);
     LF_TRY(lfgpu_ligero_open(zk->lp, idx.data(), zk->req.data(), zk->nonces.data(), zk->path.data(), cap, &zk->npath));
+    tq[5] = now_ms();
+    if (verbose)
+      fprintf(stderr, "lfgpu zk ligero_prove: ldt %.2f ms | host A vector %.2f | dot %.2f | quad %.2f | challenges+open %.2f\n", tq[1] - tq[0],
+              tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4]);
   }
   zk->ms[5] = now_ms() - t0;
   zk->ms[1] = now_ms() - t_start;

@@ -53,6 +53,31 @@ def _known_answers(pkg):
     assert pkg.aes256_ecb_block(key, bytes.fromhex("00112233445566778899aabbccddeeff")).hex() == "8ea2b7ca516745bfeafc49904b496089"
 
 
+@pytest.mark.parametrize("portable", [0, 1])
+def test_host_gf2128_product_matches_oracle(pkg, portable):
+    """the PCLMULQDQ product of the host bookkeeping (csrc/fs_crypto.cc) and its portable fallback vs the oracle"""
+    import ctypes as C
+    import oracle_lib as ol
+    L = pkg.load_library()
+    L.lfgpu_crypto_hw(portable)
+    try:
+        rng = np.random.default_rng(77)
+        vals = ol.rand_elts(rng, 400)
+        vals[0] = 0
+        vals[1] = (1, 0)
+        vals[2] = (0, 1 << 63)
+        vals[3] = (2**64 - 1, 2**64 - 1)
+        o = ol.oracle()
+        for i in range(0, 400, 2):
+            a, b = vals[i], vals[(i * 7 + 3) % 400]
+            out = (C.c_uint64 * 2)()
+            L.lfgpu_host_gf2128_mul((C.c_uint64 * 2)(int(a[0]), int(a[1])), (C.c_uint64 * 2)(int(b[0]), int(b[1])), out)
+            want = o.lfo_gf_mul(ol.elt(a), ol.elt(b))
+            assert (out[0], out[1]) == (want.l[0], want.l[1])
+    finally:
+        L.lfgpu_crypto_hw(0)
+
+
 def test_builtin_transcript_matches_harness_transcript(pkg):
     """same byte stream as tests/fs_transcript.py (which is pinned by the reference fixtures) under interleaved
     writes and reads, including the PRF reset on every write and reads that straddle AES blocks"""
