@@ -150,6 +150,13 @@ int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* 
 int lfgpu_raw_eq2(lfgpu_ctx* ctx, int field, size_t logn, size_t n, const void* h_G0, const void* h_G1,
                   const uint64_t alpha[2], void* d_eq);
 
+/* Quad::bind_gh_all (lib/sumcheck/quad.h:188-210), the verifier's combined bind_g + bind_h:
+ * out = sum over the corners of prep_v(v, beta) (EQ(G0,g) + alpha EQ(G1,g)) EQ(H0,h0) EQ(H1,h1).
+ * nw = number of input wires of the layer (hand indices are < nw <= 2^logw). */
+int lfgpu_quad_bind_gh_all(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                           const uint64_t beta[2], size_t logw, size_t nw, const void* h_H0, const void* h_H1,
+                           uint64_t out[2]);
+
 /* ---- one whole sumcheck layer with the transcript behind a callback -------------------
  * Replaces the body of ProverLayers::layer for logc = 0 (every ZK use, lib/zk/zk_common.h:72) together
  * with the bind_g that precedes it (lib/sumcheck/prover_layers.h:140-146,185-271): HQUAD = bind_g(...),

@@ -96,6 +96,16 @@ int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, size_t cap, si
 int lfgpu_zk_timings(const lfgpu_zk_prover* zk, double ms[6]);
 int lfgpu_zk_prover_free(lfgpu_zk_prover* zk);
 
+/* ---- ZkVerifier ----
+ * ZkVerifier::recv_commitment + verify (lib/zk/zk_verifier.h:68-94) on the wire bytes of ZkProof::write
+ * (parsed as ZkProof::read does, lib/zk/zk_proof.h:107-112,218-345).  h_pub: the npub_in public inputs.
+ * *ok = 1 iff the proof is accepted; *why (optional) names the failing check with the reference's strings
+ * (lib/ligero/ligero_verifier.h:90-130) or "proof does not parse".  The transcript must be in the same
+ * state the prover's was before its commit (e.g. a fresh Transcript over the same seed). */
+int lfgpu_zk_verify(lfgpu_ctx* ctx, const lfgpu_circuit* c, size_t rateinv, size_t nreq, size_t block_enc,
+                    const uint8_t* proof, size_t proof_len, const void* h_pub, const lfgpu_transcript_ops* ts, int* ok,
+                    const char** why);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,13 +30,13 @@ ABI_SYMBOLS = [
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
     "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
     "lfgpu_ligero_quadratic_proof", "lfgpu_ligero_open", "lfgpu_ligero_tableau", "lfgpu_ligero_free",
-    "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g", "lfgpu_sumcheck_layer", "lfgpu_raw_eq2",
+    "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g", "lfgpu_sumcheck_layer", "lfgpu_raw_eq2", "lfgpu_quad_bind_gh_all",
     # include/lfgpu_zk.h
     "lfgpu_transcript_new", "lfgpu_transcript_free", "lfgpu_transcript_get_ops", "lfgpu_transcript_write_bytes",
     "lfgpu_transcript_write_elt", "lfgpu_transcript_write_elt_array", "lfgpu_transcript_bytes", "lfgpu_sha256",
     "lfgpu_aes256_ecb_block", "lfgpu_host_gf2128_mul", "lfgpu_crypto_hw", "lfgpu_circuit_from_lfc1", "lfgpu_circuit_get_info", "lfgpu_circuit_layer_info",
     "lfgpu_circuit_free", "lfgpu_zk_prover_new", "lfgpu_zk_prover_param", "lfgpu_zk_commit", "lfgpu_zk_prove",
-    "lfgpu_zk_proof_write", "lfgpu_zk_timings", "lfgpu_zk_prover_free",
+    "lfgpu_zk_proof_write", "lfgpu_zk_timings", "lfgpu_zk_prover_free", "lfgpu_zk_verify",
 ]
 
 
@@ -117,6 +117,7 @@ def load_library():
         "lfgpu_quad_bind_g": [vp, sz, vp, vp, pu64, pu64, vp, vp, C.POINTER(sz)],
         "lfgpu_sumcheck_layer": [vp, sz, vp, vp, pu64, pu64, sz, sz, vp, pu64, SC_ROUND_FN, vp, pu64, pu64, pu64],
         "lfgpu_raw_eq2": [vp, ci, sz, sz, vp, vp, pu64, vp],
+        "lfgpu_quad_bind_gh_all": [vp, sz, vp, vp, pu64, pu64, sz, sz, vp, vp, pu64],
         "lfgpu_circuit_from_lfc1": [vp, vp, sz, C.POINTER(vp)],
         "lfgpu_circuit_get_info": [vp, C.POINTER(CircuitInfo)],
         "lfgpu_circuit_layer_info": [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)],
@@ -128,6 +129,7 @@ def load_library():
         "lfgpu_zk_proof_write": [vp, vp, sz, C.POINTER(sz)],
         "lfgpu_zk_timings": [vp, C.POINTER(C.c_double)],
         "lfgpu_zk_prover_free": [vp],
+        "lfgpu_zk_verify": [vp, vp, sz, sz, sz, vp, sz, vp, C.POINTER(TranscriptOps), C.POINTER(ci), C.POINTER(C.c_char_p)],
         "lfgpu_crypto_hw": [ci],
     }
     for name, args in sig.items():
@@ -411,6 +413,16 @@ class Quad:
                                                   C.byref(n_out)))
         return n_out.value
 
+    def bind_gh_all(self, logv, G0, G1, alpha, beta, logw, nw, H0, H1):
+        """Quad::bind_gh_all (the verifier's combined bind) -> (lo, hi)"""
+        import numpy as np
+        G0, G1, H0, H1 = (np.ascontiguousarray(a) for a in (G0, G1, H0, H1))
+        out = (C.c_uint64 * 2)()
+        self.gpu._ck(self.gpu.L.lfgpu_quad_bind_gh_all(self.h, logv, C.c_void_p(G0.ctypes.data), C.c_void_p(G1.ctypes.data),
+                                                       _u64x2(alpha), _u64x2(beta), logw, nw, C.c_void_p(H0.ctypes.data),
+                                                       C.c_void_p(H1.ctypes.data), out))
+        return (out[0], out[1])
+
     def sumcheck_layer(self, logv, G0, G1, alpha, beta, logw, nw, d_W, wc_in, round_cb):
         """ProverLayers::layer (logc = 0) incl. bind_g; round_cb(hand, round, evals[3]) -> challenge, evals and
         challenge as (lo, hi) pairs.  Returns (wc_out[2], challenges[2][logw], bound_quad)."""
@@ -560,3 +572,15 @@ class ZkProver:
         if self.h:
             self.gpu.L.lfgpu_zk_prover_free(self.h)
             self.h = None
+
+
+def zk_verify(gpu, circuit, proof, pub, transcript, rate=7, nreq=132, block_enc=0):
+    """ZkVerifier::recv_commitment + verify over the wire bytes -> (accepted, reason)"""
+    import numpy as np
+    pub = np.ascontiguousarray(pub)
+    ok, why = C.c_int(), C.c_char_p()
+    ops = transcript.ops()
+    raw = bytes(proof)
+    gpu._ck(gpu.L.lfgpu_zk_verify(gpu.h, circuit.h, rate, nreq, block_enc, raw, len(raw), C.c_void_p(pub.ctypes.data) if pub.size else None,
+                                  C.byref(ops), C.byref(ok), C.byref(why)))
+    return bool(ok.value), (why.value or b"").decode()

@@ -364,6 +364,94 @@ extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, c
 }
 
 
+// ---- Quad::bind_gh_all (lib/sumcheck/quad.h:188-210): the verifier's combined bind, no expansion:
+//   sum over the corners of prep_v(v, beta) * (EQ(G0,g) + alpha EQ(G1,g)) * EQ(H0,h0) * EQ(H1,h1)
+// Three EQ tables by raw_eq2_kernel, then one pass over the corners with a block-reduced sum; the device-wide fold
+// of the block sums uses XOR words (GF2_128) / 32-bit-limb integer accumulators (Fp128), so it is exact and
+// independent of arrival order.
+template <int F>
+__global__ __launch_bounds__(QD_THREADS) void bind_gh_all_kernel(size_t n, const corner4* __restrict__ t, const elt_t* __restrict__ kvec,
+                                                                 const elt_t* __restrict__ eqg, const elt_t* __restrict__ eqh0,
+                                                                 const elt_t* __restrict__ eqh1, elt_t beta, u64* __restrict__ acc) {
+  __shared__ elt_t sh[QD_THREADS / 64];
+  elt_t s = elt_zero();
+  for (size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * QD_THREADS) {
+    const corner4 cr = t[i];
+    elt_t v = ld16(&kvec[cr.vi]);
+    if ((v.lo | v.hi) == 0) v = beta;  // prep_v: assert-zero terms carry beta (quad.h:213-220)
+    elt_t qv = Fld<F>::mul(v, ld16(&eqg[cr.g]));
+    qv = Fld<F>::mul(qv, ld16(&eqh0[cr.h0]));
+    s = Fld<F>::add(s, Fld<F>::mul(qv, ld16(&eqh1[cr.h1])));
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    elt_t o;
+    o.lo = __shfl_down(s.lo, off, 64);
+    o.hi = __shfl_down(s.hi, off, 64);
+    s = Fld<F>::add(s, o);
+  }
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (u32 w = 1; w < QD_THREADS / 64; ++w) s = Fld<F>::add(s, sh[w]);
+    if (F == FIELD_GF2_128) {
+      atomicXor(&acc[0], s.lo);
+      atomicXor(&acc[1], s.hi);
+    } else {
+      atomicAdd(&acc[0], (u64)(u32)s.lo);
+      atomicAdd(&acc[1], s.lo >> 32);
+      atomicAdd(&acc[2], (u64)(u32)s.hi);
+      atomicAdd(&acc[3], s.hi >> 32);
+    }
+  }
+}
+
+extern "C" int lfgpu_quad_bind_gh_all(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                                      const uint64_t beta[2], size_t logw, size_t nw, const void* h_H0, const void* h_H1,
+                                      uint64_t out[2]) {
+  if (!q || !alpha || !beta || !out || (logv && (!h_G0 || !h_G1)) || (logw && (!h_H0 || !h_H1))) return LFGPU_ERR_ARG;
+  lfgpu_ctx* c = q->c;
+  if (logv > 40 || logw > 40 || ((size_t)1 << logv) < q->nv || nw == 0 || ((size_t)1 << logw) < nw)
+    return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_gh_all: table sizes");
+  LF_HIP(c, hipSetDevice(c->device));
+  const int field = q->field;
+  void* sc = nullptr;
+  LF_TRY(lf_scratch3(c, (q->nv + 2 * nw) * 16 + 64, &sc));
+  elt_t* d_eqg = (elt_t*)sc;
+  elt_t* d_eqh0 = d_eqg + q->nv;
+  elt_t* d_eqh1 = d_eqh0 + nw;
+  u64* d_acc = (u64*)(d_eqh1 + nw);
+  const uint64_t zero[2] = {0, 0};
+  LF_TRY(lfgpu_raw_eq2(c, field, logv, q->nv, h_G0, h_G1, alpha, d_eqg));
+  LF_TRY(lfgpu_raw_eq2(c, field, logw, nw, h_H0, h_H0, zero, d_eqh0));  // EQ(H0, i) + 0 * (...)
+  LF_TRY(lfgpu_raw_eq2(c, field, logw, nw, h_H1, h_H1, zero, d_eqh1));
+  LF_HIP(c, hipMemsetAsync(d_acc, 0, 32, c->stream));
+  const elt_t be{beta[0], beta[1]};
+  u32 nb = (u32)((q->n + QD_THREADS - 1) / QD_THREADS);
+  if (nb > 2048) nb = 2048;
+  if (nb == 0) nb = 1;
+  QD_DISPATCH(field, bind_gh_all_kernel, dim3(nb), dim3(QD_THREADS), q->n, (const corner4*)q->d_morton, (const elt_t*)q->d_kvec,
+              (const elt_t*)d_eqg, (const elt_t*)d_eqh0, (const elt_t*)d_eqh1, be, d_acc);
+  LF_HIP(c, hipGetLastError());
+  u64 w[4];
+  LF_HIP(c, hipMemcpyAsync(w, d_acc, 32, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  if (field == LFGPU_FIELD_GF2_128) {
+    out[0] = w[0];
+    out[1] = w[1];
+  } else {  // recombine the limbs: sum_k w[k] 2^(32k) mod p on Montgomery images
+    elt_t pw = h_fp_of_scalar(1), sum{0, 0};
+    const elt_t two32 = h_fp_of_scalar(1ull << 32);
+    for (int k = 0; k < 4; ++k) {
+      sum = fp_add(sum, fp_add(fp_mul(elt_t{(u64)(u32)w[k], 0}, pw), fp_mul(fp_mul(elt_t{w[k] >> 32, 0}, pw), two32)));
+      pw = fp_mul(pw, two32);
+    }
+    out[0] = sum.lo;
+    out[1] = sum.hi;
+  }
+  return LFGPU_OK;
+}
+
 // ------------------------------------------------------------------ one sumcheck layer (host loop)
 extern "C" int lfgpu_sumcheck_partials(lfgpu_ctx*, int, size_t, const void*, const void*, uint64_t*, uint64_t*);
 extern "C" int lfgpu_qw_scatter(lfgpu_ctx*, int, size_t, const void*, const void*, int, const void*, size_t, void*);

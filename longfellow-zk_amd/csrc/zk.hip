@@ -759,3 +759,390 @@ extern "C" int lfgpu_zk_prover_free(lfgpu_zk_prover* zk) {
   delete zk;
   return LFGPU_OK;
 }
+
+// ------------------------------------------------------------------ ZkVerifier
+// ZkVerifier::recv_commitment + verify (lib/zk/zk_verifier.h:68-94) over the wire bytes of ZkProof::write:
+//   ZkProof::read                           lib/zk/zk_proof.h:107-112,218-345
+//   ZkCommon::verifier_constraints, aux == nullptr (bind_quad -> Quad::bind_gh_all)   lib/zk/zk_common.h:49-136,441-450
+//   LigeroVerifier::verify                  lib/ligero/ligero_verifier.h:42-270
+//   MerkleCommitmentVerifier::verify        lib/merkle/merkle_commitment.h:85-99, merkle_tree.h:160-209
+// Device work: bind_gh_all of every layer (the bulk: one pass over all corners of the circuit), the Reed-Solomon
+// extension of the nwqrow rows of A and of the three y vectors, the gather at the opened columns.  Host: transcript
+// replay, symbolic constraints, the nreq column hashes and the Merkle recomputation.
+namespace {
+struct ParsedProof {
+  uint8_t root[32];
+  std::vector<lfgpu_zk_prover::LayerPad> sc;
+  std::vector<elt_t> y_ldt, y_dot, y_q0, y_q2, req;
+  std::vector<uint8_t> nonces, path;
+  size_t npath = 0;
+};
+
+struct Reader {
+  const uint8_t* p;
+  size_t left;
+  bool have(size_t n) const { return left >= n; }
+  const uint8_t* next(size_t n) {
+    const uint8_t* r = p;
+    p += n;
+    left -= n;
+    return r;
+  }
+  elt_t elt() {
+    elt_t e;
+    memcpy(&e, next(16), 16);  // GF2_128::of_bytes_field: every 16-byte string is an element
+    return e;
+  }
+  size_t size4() {
+    const uint8_t* b = next(4);
+    return (size_t)b[0] | (size_t)b[1] << 8 | (size_t)b[2] << 16 | (size_t)b[3] << 24;
+  }
+};
+
+// ZkProof::read; false on underflow or inconsistent sizes (the reference returns false as well)
+bool parse_proof(const lfgpu_circuit* C, const lfgpu_ligero_param& p, const GfHostCtx* g, const uint8_t* buf, size_t len, ParsedProof& pr) {
+  Reader rd{buf, len};
+  if (!rd.have(32)) return false;
+  memcpy(pr.root, rd.next(32), 32);
+  pr.sc.assign(C->layers.size(), {});
+  for (size_t ly = 0; ly < C->layers.size(); ++ly) {
+    const size_t logw = C->layers[ly].logw;
+    if (!rd.have((logw * 4 + 2) * 16)) return false;
+    auto& P = pr.sc[ly];
+    P.hp[0].resize(2 * logw);
+    P.hp[1].resize(2 * logw);
+    for (size_t wi = 0; wi < logw; ++wi)
+      for (int k = 0; k < 2; ++k) {
+        P.hp[0][2 * wi + k] = rd.elt();
+        P.hp[1][2 * wi + k] = rd.elt();
+      }
+    P.wc[0] = rd.elt();
+    P.wc[1] = rd.elt();
+  }
+  auto vec = [&](std::vector<elt_t>& v, size_t n) {
+    if (!rd.have(n * 16)) return false;
+    v.resize(n);
+    for (auto& e : v) e = rd.elt();
+    return true;
+  };
+  if (!vec(pr.y_ldt, p.block) || !vec(pr.y_dot, p.dblock) || !vec(pr.y_q0, p.r) || !vec(pr.y_q2, p.dblock - p.block)) return false;
+  if (!rd.have(p.nreq * 32)) return false;
+  pr.nonces.assign(rd.p, rd.p + p.nreq * 32);
+  rd.next(p.nreq * 32);
+  const size_t total = p.nreq * p.nrow;
+  constexpr size_t kMaxRunLen = (size_t)1 << 25, kMaxNumDigests = (size_t)1 << 25;
+  pr.req.assign(total, elt_t{0, 0});
+  size_t ci = 0;
+  bool subfield_run = false;
+  while (ci < total) {
+    if (!rd.have(4)) return false;
+    const size_t runlen = rd.size4();
+    if (runlen >= kMaxRunLen || ci + runlen > total) return false;
+    if (subfield_run) {
+      if (!rd.have(runlen * 2)) return false;
+      for (size_t i = ci; i < ci + runlen; ++i) {  // of_bytes_subfield: of_scalar(u) = sum_i bit_i(u) beta_i
+        const uint8_t* b = rd.next(2);
+        const u32 u = (u32)b[0] | (u32)b[1] << 8;
+        elt_t e{0, 0};
+        for (unsigned k = 0; k < g->sub_bits; ++k)
+          if ((u >> k) & 1) e = gf_add(e, g->beta[k]);
+        pr.req[i] = e;
+      }
+    } else {
+      if (!rd.have(runlen * 16)) return false;
+      for (size_t i = ci; i < ci + runlen; ++i) pr.req[i] = rd.elt();
+    }
+    ci += runlen;
+    subfield_run = !subfield_run;
+  }
+  if (!rd.have(4)) return false;
+  const size_t sz = rd.size4();
+  if (sz < p.nreq || sz >= kMaxNumDigests || sz > p.nreq * p.mc_pathlen || !rd.have(sz * 32)) return false;
+  pr.npath = sz;
+  pr.path.assign(rd.p, rd.p + sz * 32);
+  rd.next(sz * 32);
+  return true;
+}
+
+void hash2(const uint8_t* a, const uint8_t* b, uint8_t out[32]) {  // Digest::hash2: SHA-256(left || right)
+  Sha256 s;
+  s.update(a, 32);
+  s.update(b, 32);
+  s.digest(out);
+}
+
+// MerkleTreeVerifier::verify_compressed_proof (merkle_tree.h:160-209)
+bool merkle_verify(size_t n, const uint8_t root[32], const uint8_t* path, size_t npath, const uint8_t* leaves, const size_t* pos, size_t np) {
+  std::vector<uint8_t> layers(2 * n * 32, 0);
+  std::vector<bool> defined(2 * n, false), tree(2 * n, false);
+  for (size_t ip = 0; ip < np; ++ip) {
+    if (pos[ip] >= n) return false;
+    tree[pos[ip] + n] = true;
+  }
+  for (size_t i = n; i-- > 1;) tree[i] = tree[2 * i] || tree[2 * i + 1];
+  size_t sz = 0;
+  for (size_t i = n; i-- > 1;) {
+    if (tree[i]) {
+      size_t child = 2 * i;
+      if (tree[child]) child = 2 * i + 1;
+      if (!tree[child]) {
+        if (sz >= npath) return false;
+        memcpy(&layers[child * 32], path + 32 * sz++, 32);
+        defined[child] = true;
+      }
+    }
+  }
+  if (sz != npath) return false;  // the whole proof must be consumed
+  for (size_t ip = 0; ip < np; ++ip) {
+    memcpy(&layers[(pos[ip] + n) * 32], leaves + 32 * ip, 32);
+    defined[pos[ip] + n] = true;
+  }
+  for (size_t i = n; i-- > 1;)
+    if (defined[2 * i] && defined[2 * i + 1]) {
+      hash2(&layers[2 * i * 32], &layers[(2 * i + 1) * 32], &layers[i * 32]);
+      defined[i] = true;
+    }
+  return defined[1] && memcmp(root, &layers[32], 32) == 0;
+}
+}  // namespace
+
+extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc, const uint8_t* proof,
+                               size_t proof_len, const void* h_pub, const lfgpu_transcript_ops* tso, int* ok, const char** why_out) {
+  static const char* kWhy[] = {"ok", "proof does not parse", "merkle_check failed", "low_degree_check failed", "dot_check failed",
+                               "wrong dot product", "quadratic_check failed"};
+  if (!c || !C || C->c != c || !proof || !tso || !ok || (C->info.npub_in && !h_pub)) return LFGPU_ERR_ARG;
+  *ok = 0;
+  auto fail = [&](int w) {
+    if (why_out) *why_out = kWhy[w];
+    return LFGPU_OK;
+  };
+  const lfgpu_circuit_info& I = C->info;
+  const size_t nl = C->layers.size(), npub = I.npub_in, n_witness = I.ninputs - npub;
+  size_t pad_size = 0;
+  for (const auto& l : C->layers) pad_size += layer_size(l.logw);
+  lfgpu_ligero_param p{};
+  LF_TRY(lfgpu_ligero_param_init(&p, LFGPU_FIELD_GF2_128, 4, n_witness + pad_size, nl, rateinv, nreq, block_enc));
+  const GfHostCtx* g = lf_gf_ctx(c, 4);
+  if (!g) return LFGPU_ERR_ARG;
+  ParsedProof pr;
+  if (!parse_proof(C, p, g, proof, proof_len, pr)) return fail(1);
+  LF_HIP(c, hipSetDevice(c->device));
+  const HostField F(c, LFGPU_FIELD_GF2_128);
+  const Ts ts{tso, tso->user};
+  const elt_t* pub = (const elt_t*)h_pub;
+
+  // recv_commitment, initialize_sumcheck_fiat_shamir
+  ts.write_bytes(pr.root, 32);
+  ts.write_bytes(I.id, 32);
+  for (size_t i = 0; i < npub; ++i) ts.write_elt(pub[i]);
+  ts.write_elt(elt_t{0, 0});
+  {
+    std::vector<uint8_t> z(I.nterms, 0);
+    ts.write_bytes(z.data(), z.size());
+  }
+
+  // verifier_constraints with aux == nullptr: the bound quad of every layer comes from bind_gh_all
+  struct Term {
+    size_t c, w;
+    elt_t k;
+  };
+  std::vector<Term> a;
+  std::vector<elt_t> b;
+  std::vector<size_t> lqc(3 * nl);
+  size_t ci = 0;
+  std::vector<elt_t> G[2], gh[2];
+  elt_t alpha_in;
+  {
+    for (size_t i = 0; i < kMaxBindings; ++i) (void)ts.elt();  // Q
+    G[0].resize(kMaxBindings);
+    for (size_t i = 0; i < kMaxBindings; ++i) G[0][i] = ts.elt();
+    G[1] = G[0];
+    size_t logv = I.logv;
+    elt_t claims[2] = {elt_t{0, 0}, elt_t{0, 0}};
+    size_t pi = n_witness;
+    std::vector<elt_t> sym;
+    for (size_t ly = 0; ly < nl; ++ly) {
+      const auto& L = C->layers[ly];
+      const size_t logw = L.logw;
+      const elt_t alpha = ts.elt(), beta = ts.elt();
+      const size_t n = 3 + layer_size(logw);
+      elt_t known{0, 0};
+      sym.assign(n, elt_t{0, 0});
+      auto axpy = [&](size_t var, elt_t kv, elt_t k) {
+        known = F.add(known, F.mul(k, kv));
+        sym[var] = F.add(sym[var], k);
+      };
+      axpy(0, claims[0], F.one);
+      axpy(1, claims[1], alpha);
+      gh[0].assign(logw ? logw : 1, elt_t{0, 0});
+      gh[1].assign(logw ? logw : 1, elt_t{0, 0});
+      const auto& P = pr.sc[ly];
+      for (size_t rnd = 0; rnd < logw; ++rnd)
+        for (int hand = 0; hand < 2; ++hand) {
+          const size_t r = 2 * rnd + hand;
+          const elt_t t0e = P.hp[hand][2 * rnd], t2e = P.hp[hand][2 * rnd + 1];
+          ts.write_elt(t0e);
+          ts.write_elt(t2e);
+          const elt_t chal = ts.elt();
+          gh[hand][rnd] = chal;
+          elt_t lag[3];
+          for (int i = 0; i < 3; ++i) {
+            elt_t num = F.one;
+            for (int j = 0; j < 3; ++j)
+              if (j != i) num = F.mul(num, F.sub(chal, F.pts[j]));
+            lag[i] = F.mul(num, F.invden[i]);
+          }
+          axpy(3 + 2 * r, t0e, F.one);
+          known = F.mul(known, lag[1]);
+          for (auto& s : sym)
+            if (s.lo | s.hi) s = F.mul(s, lag[1]);
+          axpy(3 + 2 * r, t0e, lag[0]);
+          axpy(3 + 2 * r + 1, t2e, lag[2]);
+        }
+      uint64_t bq[2];
+      const uint64_t al[2] = {alpha.lo, alpha.hi}, be[2] = {beta.lo, beta.hi};
+      LF_TRY(lfgpu_quad_bind_gh_all(L.q, logv, G[0].data(), G[1].data(), al, be, logw, L.nw, gh[0].data(), gh[1].data(), bq));
+      const elt_t eqq{bq[0], bq[1]};  // Eq::eval with logc = 0 is 1
+      const size_t cp = 3 + 4 * logw;
+      b.push_back(F.sub(F.mul(eqq, F.mul(P.wc[0], P.wc[1])), known));  // ConstraintBuilder::finalize
+      sym[cp] = F.sub(sym[cp], F.mul(eqq, P.wc[1]));
+      sym[cp + 1] = F.sub(sym[cp + 1], F.mul(eqq, P.wc[0]));
+      sym[cp + 2] = F.sub(sym[cp + 2], eqq);
+      for (size_t i = ly == 0 ? 3 : 0; i < n; ++i) a.push_back({ci, pi + i - 3, sym[i]});
+      ++ci;
+      ts.write_array(P.wc, 2);
+      claims[0] = P.wc[0];
+      claims[1] = P.wc[1];
+      lqc[3 * ly] = pi + 4 * logw;  // setup_lqc
+      lqc[3 * ly + 1] = pi + 4 * logw + 1;
+      lqc[3 * ly + 2] = pi + 4 * logw + 2;
+      for (int h = 0; h < 2; ++h) {
+        G[h].assign(kMaxBindings, elt_t{0, 0});
+        for (size_t r = 0; r < logw; ++r) G[h][r] = gh[h][r];
+      }
+      logv = logw;
+      pi += layer_size(logw);
+    }
+    alpha_in = ts.elt();
+    a.push_back({ci, pi - 3, F.one});
+    a.push_back({ci, pi - 2, alpha_in});
+    ++ci;
+  }
+  const size_t nconstraints = ci, dense_c = ci - 1;
+  // input_constraint: EQ table over the inputs; public part folded into b, private part is the dense block of A
+  std::vector<elt_t> bi(I.ninputs);
+  {
+    const size_t logn = C->layers[nl - 1].logw;
+    void* d_eq = nullptr;
+    LF_TRY(lf_scratch3(c, I.ninputs * 16, &d_eq));
+    const uint64_t al[2] = {alpha_in.lo, alpha_in.hi};
+    LF_TRY(lfgpu_raw_eq2(c, LFGPU_FIELD_GF2_128, logn, I.ninputs, gh[0].data(), gh[1].data(), al, d_eq));
+    LF_HIP(c, hipMemcpyAsync(bi.data(), d_eq, I.ninputs * 16, hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(c, hipStreamSynchronize(c->stream));
+    const auto& P = pr.sc[nl - 1];
+    elt_t pub_binding{0, 0};
+    for (size_t i = 0; i < npub; ++i) pub_binding = F.add(pub_binding, F.mul(bi[i], pub[i]));
+    const elt_t got = F.add(P.wc[0], F.mul(alpha_in, P.wc[1]));
+    b.push_back(F.sub(got, pub_binding));
+  }
+
+  // LigeroVerifier::verify: replay the challenges
+  uint8_t hash_of_A[32] = {0xde, 0xad, 0xbe, 0xef};
+  ts.write_bytes(hash_of_A, 32);
+  std::vector<elt_t> u_ldt(p.nwqrow), alphal(nconstraints), alphaq(3 * p.nq), u_quad(p.nqtriples ? p.nqtriples : 1);
+  for (auto& e : u_ldt) e = ts.elt();
+  for (auto& e : alphal) e = ts.elt();
+  for (auto& e : alphaq) e = ts.elt();
+  for (size_t i = 0; i < p.nqtriples; ++i) u_quad[i] = ts.elt();
+  ts.write_array(pr.y_ldt.data(), pr.y_ldt.size());
+  ts.write_array(pr.y_dot.data(), pr.y_dot.size());
+  ts.write_array(pr.y_q0.data(), pr.y_q0.size());
+  ts.write_array(pr.y_q2.data(), pr.y_q2.size());
+  std::vector<size_t> idx(p.nreq);
+  ts.choose(p.block_ext, p.nreq, idx.data());
+  auto req_at = [&](size_t i, size_t j) -> elt_t { return pr.req[i * p.nreq + j]; };
+
+  {  // merkle_check: leaf r = SHA-256(nonce_r || column r of the opening)
+    std::vector<uint8_t> leaves(p.nreq * 32);
+    for (size_t r = 0; r < p.nreq; ++r) {
+      Sha256 s;
+      s.update(&pr.nonces[32 * r], 32);
+      for (size_t i = 0; i < p.nrow; ++i) {
+        const elt_t e = req_at(i, r);
+        s.update((const uint8_t*)&e, 16);
+      }
+      s.digest(&leaves[32 * r]);
+    }
+    if (!merkle_verify(p.block_ext, pr.root, pr.path.data(), pr.npath, leaves.data(), idx.data(), p.nreq)) return fail(2);
+  }
+
+  // device: rows [0, nwqrow) = [0^r | A_i] extended block -> block_enc, rows nwqrow.. = y_ldt, y_dot, y_quad
+  std::vector<elt_t> A(p.nwqrow * p.w, elt_t{0, 0});
+  for (size_t w = 0; w < n_witness; ++w) A[w] = h_gf_mul(alphal[dense_c], bi[npub + w]);  // inner_product_vector
+  for (const Term& t : a) A[t.w] = gf_add(A[t.w], h_gf_mul(t.k, alphal[t.c]));
+  {
+    const size_t base = p.nwrow * p.w;
+    const size_t Ax = base, Ay = base + p.nqtriples * p.w, Az = base + 2 * p.nqtriples * p.w;
+    for (size_t iw = 0; iw < p.nq; ++iw) {
+      const size_t off[3] = {Ax + iw, Ay + iw, Az + iw};
+      for (int j = 0; j < 3; ++j) {
+        const elt_t aq = alphaq[3 * iw + j];
+        A[off[j]] = gf_add(A[off[j]], aq);
+        A[lqc[3 * iw + j]] = gf_add(A[lqc[3 * iw + j]], aq);
+      }
+    }
+  }
+  const size_t nrows_dev = p.nwqrow + 3, ld = p.block_enc;
+  void* dT = nullptr;
+  LF_TRY(lf_scratch(c, (nrows_dev * ld + (size_t)nrows_dev * p.nreq) * 16 + 256, &dT));
+  elt_t* d_T = (elt_t*)dT;
+  elt_t* d_req = d_T + nrows_dev * ld;
+  {
+    std::vector<elt_t> hostT(nrows_dev * ld, elt_t{0, 0});
+    for (size_t i = 0; i < p.nwqrow; ++i) memcpy(&hostT[i * ld + p.r], &A[i * p.w], p.w * 16);  // layout_Aext
+    memcpy(&hostT[(p.nwqrow + 0) * ld], pr.y_ldt.data(), p.block * 16);
+    memcpy(&hostT[(p.nwqrow + 1) * ld], pr.y_dot.data(), p.dblock * 16);
+    elt_t* yq = &hostT[(p.nwqrow + 2) * ld];  // y_quad = y_quad_0 | 0^w | y_quad_2
+    memcpy(yq, pr.y_q0.data(), p.r * 16);
+    memcpy(yq + p.block, pr.y_q2.data(), (p.dblock - p.block) * 16);
+    LF_HIP(c, hipMemcpyAsync(d_T, hostT.data(), hostT.size() * 16, hipMemcpyHostToDevice, c->stream));
+    LF_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  LF_TRY(lfgpu_gf2128_rs_encode_rows(c, 4, p.nwqrow + 1, p.block, p.block_enc, d_T, ld));                       // A rows and y_ldt
+  LF_TRY(lfgpu_gf2128_rs_encode_rows(c, 4, 2, p.dblock, p.block_enc, d_T + (p.nwqrow + 1) * ld, ld));            // y_dot, y_quad
+  LF_TRY(lfgpu_gather_columns(c, nrows_dev, ld, p.dblock, d_T, idx.data(), p.nreq, d_req));
+  std::vector<elt_t> ext(nrows_dev * p.nreq);
+  LF_HIP(c, hipMemcpyAsync(ext.data(), d_req, ext.size() * 16, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  auto ext_at = [&](size_t row, size_t j) -> elt_t { return ext[row * p.nreq + j]; };
+
+  for (size_t j = 0; j < p.nreq; ++j) {  // low_degree_check
+    elt_t yc = req_at(p.ildt, j);
+    for (size_t i = 0; i < p.nwqrow; ++i) yc = gf_add(yc, h_gf_mul(u_ldt[i], req_at(i + p.iw, j)));
+    if (!elt_eq(yc, ext_at(p.nwqrow, j))) return fail(3);
+  }
+  for (size_t j = 0; j < p.nreq; ++j) {  // dot_check
+    elt_t yc = req_at(p.idot, j);
+    for (size_t i = 0; i < p.nwqrow; ++i) yc = gf_add(yc, h_gf_mul(ext_at(i, j), req_at(i + p.iw, j)));
+    if (!elt_eq(yc, ext_at(p.nwqrow + 1, j))) return fail(4);
+  }
+  {  // the putative value of the inner product
+    elt_t want{0, 0}, got{0, 0};
+    for (size_t k = 0; k < nconstraints; ++k) want = gf_add(want, h_gf_mul(b[k], alphal[k]));
+    for (size_t j = 0; j < p.w; ++j) got = gf_add(got, pr.y_dot[p.r + j]);
+    if (!elt_eq(want, got)) return fail(5);
+  }
+  {  // quadratic_check
+    const size_t iqx = p.iq, iqy = iqx + p.nqtriples, iqz = iqy + p.nqtriples;
+    for (size_t j = 0; j < p.nreq; ++j) {
+      elt_t yc = req_at(p.iquad, j);
+      for (size_t i = 0; i < p.nqtriples; ++i) {
+        const elt_t tmp = gf_add(req_at(iqz + i, j), h_gf_mul(req_at(iqx + i, j), req_at(iqy + i, j)));
+        yc = gf_add(yc, h_gf_mul(u_quad[i], tmp));
+      }
+      if (!elt_eq(yc, ext_at(p.nwqrow + 2, j))) return fail(6);
+    }
+  }
+  *ok = 1;
+  return fail(0);
+}

@@ -785,6 +785,31 @@ size_t lfo_quad_bind_g(int f, size_t nterms, const uint32_t* g, const uint32_t* 
   return wr;
 }
 
+/* Quad::bind_gh_all (lib/sumcheck/quad.h:188-210) */
+lfo_elt lfo_quad_bind_gh_all(int f, size_t nterms, const uint32_t* g, const uint32_t* h0, const uint32_t* h1,
+                             const uint32_t* vi, const lfo_elt* kvec, size_t logv, size_t nv, const lfo_elt* G0,
+                             const lfo_elt* G1, lfo_elt alpha, lfo_elt beta, size_t logw, size_t nw, const lfo_elt* H0,
+                             const lfo_elt* H1) {
+  lfo_elt zero = {{0, 0}};
+  lfo_elt* eqg = (lfo_elt*)malloc((nv ? nv : 1) * sizeof(lfo_elt));
+  lfo_elt* eqh0 = (lfo_elt*)malloc((nw ? nw : 1) * sizeof(lfo_elt));
+  lfo_elt* eqh1 = (lfo_elt*)malloc((nw ? nw : 1) * sizeof(lfo_elt));
+  lfo_raw_eq2(f, logv, nv, G0, G1, alpha, eqg);
+  lfo_raw_eq2(f, logw, nw, H0, H0, zero, eqh0); /* Eqs(logw, nw, H0): EQ(H0, i) */
+  lfo_raw_eq2(f, logw, nw, H1, H1, zero, eqh1);
+  lfo_elt s = zero;
+  for (size_t i = 0; i < nterms; ++i) {
+    lfo_elt v = kvec[vi[i]];
+    lfo_elt q = lfo_mul(f, elt_is_zero(v) ? beta : v, eqg[g[i]]);
+    q = lfo_mul(f, q, eqh0[h0[i]]);
+    s = lfo_add(f, s, lfo_mul(f, q, eqh1[h1[i]]));
+  }
+  free(eqg);
+  free(eqh0);
+  free(eqh1);
+  return s;
+}
+
 /* Blas::axpy / vaxpy (lib/algebra/blas.h:62-78) */
 void lfo_axpy(int f, size_t n, lfo_elt* y, lfo_elt a, const lfo_elt* x) {
   for (size_t i = 0; i < n; ++i) y[i] = lfo_add(f, y[i], lfo_mul(f, x[i], a));

@@ -127,6 +127,13 @@ size_t lfo_quad_bind_g(int field, size_t nterms, const uint32_t* g, const uint32
                        const uint32_t* vi, const lfo_elt* kvec, size_t logv, const lfo_elt* G0, const lfo_elt* G1,
                        lfo_elt alpha, lfo_elt beta, uint32_t* hc_out, lfo_elt* vc_out);
 
+/* Quad::bind_gh_all (lib/sumcheck/quad.h:188-210): sum_t prep_v(v_t, beta) eqg[g_t] EQ(H0,h0_t) EQ(H1,h1_t),
+ * eqg = raw_eq2(G0, G1, alpha) */
+lfo_elt lfo_quad_bind_gh_all(int field, size_t nterms, const uint32_t* g, const uint32_t* h0, const uint32_t* h1,
+                             const uint32_t* vi, const lfo_elt* kvec, size_t logv, size_t nv, const lfo_elt* G0,
+                             const lfo_elt* G1, lfo_elt alpha, lfo_elt beta, size_t logw, size_t nw, const lfo_elt* H0,
+                             const lfo_elt* H1);
+
 /* ------------------------------------------------------------------ Ligero row combos (Blas) */
 /* y[j] += a * x[j] */
 void lfo_axpy(int field, size_t n, lfo_elt* y, lfo_elt a, const lfo_elt* x);

@@ -86,6 +86,7 @@ def oracle():
         "lfo_raw_eq2": (None, [ci, sz, sz, vp, vp, Elt, vp]),
         "lfo_eval_quad": (ci, [ci, sz, vp, vp, vp, vp, vp, sz, vp, vp]),
         "lfo_quad_bind_g": (sz, [ci, sz, vp, vp, vp, vp, vp, sz, vp, vp, Elt, Elt, vp, vp]),
+        "lfo_quad_bind_gh_all": (Elt, [ci, sz, vp, vp, vp, vp, vp, sz, sz, vp, vp, Elt, Elt, sz, sz, vp, vp]),
         "lfo_axpy": (None, [ci, sz, vp, Elt, vp]), "lfo_vaxpy": (None, [ci, sz, vp, vp, vp]),
         "lfo_fp_bogorng_fill": (None, [u64, sz, vp]), "lfo_gf_fill": (None, [u64, sz, vp]),
     }

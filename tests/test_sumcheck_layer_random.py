@@ -131,3 +131,43 @@ def test_sumcheck_layer_matches_oracle_replay(field, case):
     assert [tuple(int(x) for x in w) for w in wc] == want_wc
     assert tuple(int(x) for x in bq) == want_bq
     assert [[tuple(int(x) for x in c) for c in ch[h]] for h in (0, 1)] == [[chal[2 * r + h] for r in range(logw)] for h in (0, 1)]
+
+
+def _bind_gh_all_oracle(field, L, logv, G0, G1, alpha, beta, H0, H1):
+    r = ol.oracle().lfo_quad_bind_gh_all(field, L["n"], P(L["g"]), P(L["h0"]), P(L["h1"]), P(L["vi"]), P(L["kvec"]), logv, L["nv"],
+                                         P(G0), P(G1), elt(alpha), elt(beta), L["logw"], L["nw"], P(H0), P(H1))
+    return (r.l[0], r.l[1])
+
+
+@pytest.mark.parametrize("field", [GF, FP])
+def test_oracle_bind_gh_all_equals_bind_g_then_bind_h(field):
+    """Quad::bind_gh_all (lib/sumcheck/quad.h:188-210) is by definition the scalar left after bind_g and binding every
+    hand variable (what the prover reports as ProofAux::bound_quad): pins the oracle's restatement of the verifier's
+    shortcut against the already pinned bind_g / bind_h path, no reference needed."""
+    rng = np.random.default_rng(31 + field)
+    logv, logw = 6, 7
+    L = make_layer_vec(rng, field, logv, logw, 900)
+    G0, G1 = ol.rand_elts(rng, logv, field), ol.rand_elts(rng, logv, field)
+    alpha, beta = (tuple(int(x) for x in ol.rand_elts(rng, 1, field)[0]) for _ in range(2))
+    chal = [tuple(int(x) for x in e) for e in ol.rand_elts(rng, 2 * logw, field)]
+    _, _, bq = oracle_layer(field, L, logv, G0, G1, alpha, beta, [(0, 0), (0, 0)], chal)
+    H0 = np.array([chal[2 * r] for r in range(logw)], dtype=np.uint64)
+    H1 = np.array([chal[2 * r + 1] for r in range(logw)], dtype=np.uint64)
+    assert _bind_gh_all_oracle(field, L, logv, G0, G1, alpha, beta, H0, H1) == bq
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field", [GF, FP])
+@pytest.mark.parametrize("case", CASES[:2] + [("big", 12, 16, 400000)], ids=["small", "mid", "big"])
+def test_quad_bind_gh_all_matches_oracle(field, case):
+    import gpu_util as G
+    _, logv, logw, nterms = case
+    rng = np.random.default_rng(7000 + field + logw)
+    L = make_layer_vec(rng, field, logv, logw, nterms)
+    G0, G1 = ol.rand_elts(rng, logv, field), ol.rand_elts(rng, logv, field)
+    H0, H1 = ol.rand_elts(rng, logw, field), ol.rand_elts(rng, logw, field)
+    alpha, beta = (tuple(int(x) for x in ol.rand_elts(rng, 1, field)[0]) for _ in range(2))
+    q = G.pkg.Quad(G.gpu(), field, L["g"], L["h0"], L["h1"], L["vi"], L["kvec"], L["nv"])
+    got = q.bind_gh_all(logv, G0, G1, alpha, beta, logw, L["nw"], H0, H1)
+    q.close()
+    assert got == _bind_gh_all_oracle(field, L, logv, G0, G1, alpha, beta, H0, H1)

@@ -158,3 +158,130 @@ def test_zk_cxx_driver_rejects_bad_witness_and_bad_circuits():
     ts.close()
     zk.close()
     circ.close()
+
+
+def _subfield_solver():
+    """GF2_128<4>::solve (lib/gf2k/gf2_128.h:496-508) in Python: coordinates of e in the basis beta, or None"""
+    import ctypes as C
+    import oracle_lib as ol
+    ctx = ol.gf_ctx(4)
+    rows = []  # (vector as int, combination mask, pivot bit)
+    for i in range(16):
+        v = ctx.beta[i].l[0] | (ctx.beta[i].l[1] << 64)
+        comb = 1 << i
+        for (rv, rc, pb) in rows:
+            if (v >> pb) & 1:
+                v ^= rv
+                comb ^= rc
+        rows.append((v, comb, v.bit_length() - 1))
+
+    def solve(e):
+        u = 0
+        for (rv, rc, pb) in rows:
+            if (e >> pb) & 1:
+                e ^= rv
+                u ^= rc
+        return u if e == 0 else None
+
+    return solve
+
+
+def wire_from_components(comp, layers_logw, p):
+    """ZkProof::write (lib/zk/zk_proof.h:90-185) from the component dump of oracle/ref_flatsha.cc (.zkproof)"""
+    solve = _subfield_solver()
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        b = comp[pos:pos + n]
+        pos += n
+        return b
+
+    out = bytearray(take(32))
+    for logw in layers_logw:
+        for _ in range(logw):
+            h0t0, h0t2, h1t0, h1t2 = take(16), take(16), take(16), take(16)
+            out += h0t0 + h1t0 + h0t2 + h1t2
+        out += take(32)
+    out += take(16 * (p.block + p.dblock + p.r + (p.dblock - p.block)))
+    req = take(16 * p.nrow * p.nreq)
+    out += take(32 * p.nreq)  # nonces precede the opened columns on the wire
+    elts = [int.from_bytes(req[16 * i:16 * i + 16], "little") for i in range(p.nrow * p.nreq)]
+    ci, sub = 0, False
+    while ci < len(elts):
+        run = 0
+        while ci + run < len(elts) and (solve(elts[ci + run]) is not None) == sub:
+            run += 1
+        out += run.to_bytes(4, "little")
+        for e in elts[ci:ci + run]:
+            out += solve(e).to_bytes(2, "little") if sub else e.to_bytes(16, "little")
+        ci += run
+        sub = not sub
+    npath = int.from_bytes(take(8), "little")
+    out += npath.to_bytes(4, "little") + take(32 * npath)
+    assert pos == len(comp)
+    return bytes(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb", [1, 32])
+def test_zk_verifier_accepts_reference_and_own_proofs_rejects_tampering(nb):
+    """lfgpu_zk_verify = ZkVerifier::recv_commitment + verify (lib/zk/zk_verifier.h:68-94).  The REFERENCE prover's
+    proof (component fixture re-serialised to the wire format; the re-serialisation is pinned by the recorded SHA-256
+    of the reference's own ZkProof::write output) and this library's proof are accepted; single-byte corruptions
+    in every section of the proof are rejected."""
+    import gpu_util as G
+    import ligero_fixture as lf
+    raw, W, info = _load(nb)
+    comp = lzma.decompress(open(os.path.join(GOLD, "flatsha_nb%d.zkproof.xz" % nb), "rb").read())
+    gpu = G.gpu()
+    circ = G.pkg.Circuit(gpu, raw)
+    p = G.pkg.ligero_param(G.pkg.FIELD_GF2_128, info["zk_nw"], circ.info.nl, 7, 132, 0)
+    logws = [circ.layer(i)["logw"] for i in range(circ.info.nl)]
+    ref_wire = wire_from_components(comp, logws, p)
+    assert len(ref_wire) == info["zk_wire_bytes"] and hashlib.sha256(ref_wire).hexdigest() == info["zk_wire_sha256"]
+    pub = W[:circ.info.npub_in]
+
+    def verify(wire):
+        ts = G.pkg.FsTranscript(b"test")
+        r = G.pkg.zk_verify(gpu, circ, wire, pub, ts)
+        ts.close()
+        return r
+
+    assert verify(ref_wire) == (True, "ok")
+    # our own proof under a different RandomEngine (different pads, blinding rows and nonces)
+    zk = G.pkg.ZkProver(gpu, circ, 7, 132)
+    ts = G.pkg.FsTranscript(b"test")
+    zk.commit(W, lf.LcgRng(4242).bytes, ts)
+    assert zk.prove(W, ts)
+    own = zk.wire()
+    ts.close()
+    zk.close()
+    assert own != ref_wire
+    assert verify(own) == (True, "ok")
+    # tampering: one flipped bit per section
+    sc_bytes = sum((4 * l + 2) * 16 for l in logws)
+    off_y = 32 + sc_bytes
+    sections = {
+        "root": 5,
+        "sumcheck": 32 + 16 * 3 + 1,
+        "y_ldt": off_y + 7,
+        "y_dot": off_y + 16 * p.block + 16 * (p.r + 3) + 2,
+        "y_quad": off_y + 16 * (p.block + p.dblock) + 9,
+        "nonce": off_y + 16 * (p.block + p.dblock + p.r + p.dblock - p.block) + 40,
+        "req": off_y + 16 * (p.block + p.dblock + p.r + p.dblock - p.block) + 32 * p.nreq + 4 + 16 * 1000 + 3,
+        "path": len(own) - 11,
+    }
+    for name, off in sections.items():
+        bad = bytearray(own)
+        bad[off] ^= 0x10
+        okb, why = verify(bytes(bad))
+        assert not okb, name
+        assert why != "ok", name
+    assert verify(own[:-1]) == (False, "proof does not parse")
+    assert verify(own + b"\x00")[0] in (True, False)  # trailing bytes are the caller's business (ReadBuffer is not checked for exhaustion)
+    # wrong transcript seed: every challenge differs
+    ts = G.pkg.FsTranscript(b"tesu")
+    assert G.pkg.zk_verify(gpu, circ, own, pub, ts)[0] is False
+    ts.close()
+    circ.close()
