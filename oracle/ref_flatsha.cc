@@ -36,6 +36,7 @@
 #include "util/log.h"
 #include "zk/zk_proof.h"
 #include "zk/zk_prover.h"
+#include "zk/zk_verifier.h"
 
 using namespace proofs;
 
@@ -165,7 +166,7 @@ int main(int argc, char** argv) {
   }
   // ---- full ZK proof (BM_ShaZK_fp2_128 body, flatsha256_circuit_test.cc:510-536) under a deterministic RNG:
   // rate 7, 132 queries, transcript "test", LCG seed 100.  Dumps every component of the proof.
-  double zk_commit_ms = 0, zk_prove_ms = 0;
+  double zk_commit_ms = 0, zk_prove_ms = 0, zk_verify_ms = 0;
   size_t z_block_enc = 0, z_nrow = 0, z_block = 0, z_dblock = 0, z_nw = 0;
   {
     using RSFactory = LCH14ReedSolomonFactory<F128>;
@@ -213,11 +214,22 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> wire;  // the reference's own serialization (ZkProof::write, zk_proof.h:90-185)
     zk.write(wire, Fs);
     dump(prefix + ".zkwire", wire.data(), wire.size());
+    // the reference verifier on its own proof (timing baseline for lfgpu_zk_verify)
+    {
+      ZkVerifier<F128, RSFactory> zv(*C, rsf, 7, 132, Fs);
+      Transcript tv((const uint8_t*)"test", 4);
+      auto v0 = std::chrono::steady_clock::now();
+      zv.recv_commitment(zk, tv);
+      bool vok = zv.verify(zk, W, tv);
+      auto v1 = std::chrono::steady_clock::now();
+      check(vok, "reference verifier rejected the reference proof");
+      zk_verify_ms = ms(v0, v1);
+    }
   }
   printf("{\"nb\": %zu, \"nl\": %zu, \"ninputs\": %zu, \"npub_in\": %zu, \"nterms\": %zu, \"round_hands\": %zu, \"lfc1_bytes\": %zu, "
          "\"ref_eval_circuit_ms\": %.2f, \"ref_sumcheck_ms\": %.2f, \"zk_nw\": %zu, \"zk_block_enc\": %zu, \"zk_block\": %zu, "
-         "\"zk_dblock\": %zu, \"zk_nrow\": %zu, \"ref_zk_commit_ms\": %.2f, \"ref_zk_prove_ms\": %.2f}\n",
+         "\"zk_dblock\": %zu, \"zk_nrow\": %zu, \"ref_zk_commit_ms\": %.2f, \"ref_zk_prove_ms\": %.2f, \"ref_zk_verify_ms\": %.2f}\n",
          nb, (size_t)C->nl, (size_t)C->ninputs, (size_t)C->npub_in, nterms, 2 * rounds, bytes.size(), ms(t0, t1), ms(t1, t2),
-         z_nw, z_block_enc, z_block, z_dblock, z_nrow, zk_commit_ms, zk_prove_ms);
+         z_nw, z_block_enc, z_block, z_dblock, z_nrow, zk_commit_ms, zk_prove_ms, zk_verify_ms);
   return 0;
 }

@@ -63,6 +63,19 @@ best = min(runs, key=lambda d: d["wall_total"])
 res["gpu_cxx_driver_ms"] = {k: round(v, 3) for k, v in best.items()}
 res["gpu_cxx_driver_total_ms_all_reps"] = [round(d["wall_total"], 3) for d in runs]
 
+# 3. verifier (lfgpu_zk_verify) on the proof of the last timed repetition
+wire = zk.wire()
+pub = W[:circ.info.npub_in]
+vruns = []
+for rep in range(reps):
+    ts = pkg.FsTranscript(b"test")
+    t0 = time.perf_counter()
+    okv, why = pkg.zk_verify(gpu, circ, wire, pub, ts)
+    vruns.append((time.perf_counter() - t0) * 1e3)
+    ts.close()
+    assert okv, why
+res["gpu_verify_ms"] = round(min(vruns), 3)
+
 if "--harness" in sys.argv:
     import sumcheck_driver as sd
     import zk_driver as zd
@@ -81,5 +94,8 @@ if os.path.exists(gen):
         r = json.loads(subprocess.check_output([gen, str(nb), os.path.join(td_, "x")]).decode())
     res["cpu_reference_ms"] = {"commit": r["ref_zk_commit_ms"], "prove": r["ref_zk_prove_ms"], "total": r["ref_zk_commit_ms"] + r["ref_zk_prove_ms"],
                                "cores": 1}
+    res["cpu_reference_ms"]["verify"] = r.get("ref_zk_verify_ms")
     res["speedup_vs_cpu_reference"] = round(res["cpu_reference_ms"]["total"] / best["wall_total"], 2)
+    if r.get("ref_zk_verify_ms"):
+        res["verify_speedup_vs_cpu_reference"] = round(r["ref_zk_verify_ms"] / res["gpu_verify_ms"], 2)
 print(json.dumps(res))
