@@ -924,8 +924,11 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   LF_TRY(lfgpu_ligero_param_init(&p, LFGPU_FIELD_GF2_128, 4, n_witness + pad_size, nl, rateinv, nreq, block_enc));
   const GfHostCtx* g = lf_gf_ctx(c, 4);
   if (!g) return LFGPU_ERR_ARG;
+  static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
+  double tv[6] = {now_ms(), 0, 0, 0, 0, 0};
   ParsedProof pr;
   if (!parse_proof(C, p, g, proof, proof_len, pr)) return fail(1);
+  tv[1] = now_ms();
   LF_HIP(c, hipSetDevice(c->device));
   const HostField F(c, LFGPU_FIELD_GF2_128);
   const Ts ts{tso, tso->user};
@@ -1046,6 +1049,7 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
     b.push_back(F.sub(got, pub_binding));
   }
 
+  tv[2] = now_ms();
   // LigeroVerifier::verify: replay the challenges
   uint8_t hash_of_A[32] = {0xde, 0xad, 0xbe, 0xef};
   ts.write_bytes(hash_of_A, 32);
@@ -1076,6 +1080,7 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
     if (!merkle_verify(p.block_ext, pr.root, pr.path.data(), pr.npath, leaves.data(), idx.data(), p.nreq)) return fail(2);
   }
 
+  tv[3] = now_ms();
   // device: rows [0, nwqrow) = [0^r | A_i] extended block -> block_enc, rows nwqrow.. = y_ldt, y_dot, y_quad
   std::vector<elt_t> A(p.nwqrow * p.w, elt_t{0, 0});
   for (size_t w = 0; w < n_witness; ++w) A[w] = h_gf_mul(alphal[dense_c], bi[npub + w]);  // inner_product_vector
@@ -1097,15 +1102,14 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   LF_TRY(lf_scratch(c, (nrows_dev * ld + (size_t)nrows_dev * p.nreq) * 16 + 256, &dT));
   elt_t* d_T = (elt_t*)dT;
   elt_t* d_req = d_T + nrows_dev * ld;
-  {
-    std::vector<elt_t> hostT(nrows_dev * ld, elt_t{0, 0});
-    for (size_t i = 0; i < p.nwqrow; ++i) memcpy(&hostT[i * ld + p.r], &A[i * p.w], p.w * 16);  // layout_Aext
-    memcpy(&hostT[(p.nwqrow + 0) * ld], pr.y_ldt.data(), p.block * 16);
-    memcpy(&hostT[(p.nwqrow + 1) * ld], pr.y_dot.data(), p.dblock * 16);
-    elt_t* yq = &hostT[(p.nwqrow + 2) * ld];  // y_quad = y_quad_0 | 0^w | y_quad_2
-    memcpy(yq, pr.y_q0.data(), p.r * 16);
-    memcpy(yq + p.block, pr.y_q2.data(), (p.dblock - p.block) * 16);
-    LF_HIP(c, hipMemcpyAsync(d_T, hostT.data(), hostT.size() * 16, hipMemcpyHostToDevice, c->stream));
+  {  // only the first dblock columns of a row are inputs: clear them on the device, then strided copies
+    LF_HIP(c, hipMemset2DAsync(d_T, ld * 16, 0, p.dblock * 16, nrows_dev, c->stream));
+    LF_HIP(c, hipMemcpy2DAsync(d_T + p.r, ld * 16, A.data(), p.w * 16, p.w * 16, p.nwqrow, hipMemcpyHostToDevice, c->stream));  // layout_Aext
+    LF_HIP(c, hipMemcpyAsync(d_T + (p.nwqrow + 0) * ld, pr.y_ldt.data(), p.block * 16, hipMemcpyHostToDevice, c->stream));
+    LF_HIP(c, hipMemcpyAsync(d_T + (p.nwqrow + 1) * ld, pr.y_dot.data(), p.dblock * 16, hipMemcpyHostToDevice, c->stream));
+    elt_t* yq = d_T + (p.nwqrow + 2) * ld;  // y_quad = y_quad_0 | 0^w | y_quad_2
+    LF_HIP(c, hipMemcpyAsync(yq, pr.y_q0.data(), p.r * 16, hipMemcpyHostToDevice, c->stream));
+    LF_HIP(c, hipMemcpyAsync(yq + p.block, pr.y_q2.data(), (p.dblock - p.block) * 16, hipMemcpyHostToDevice, c->stream));
     LF_HIP(c, hipStreamSynchronize(c->stream));
   }
   LF_TRY(lfgpu_gf2128_rs_encode_rows(c, 4, p.nwqrow + 1, p.block, p.block_enc, d_T, ld));                       // A rows and y_ldt
@@ -1115,6 +1119,7 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   LF_HIP(c, hipMemcpyAsync(ext.data(), d_req, ext.size() * 16, hipMemcpyDeviceToHost, c->stream));
   LF_HIP(c, hipStreamSynchronize(c->stream));
   auto ext_at = [&](size_t row, size_t j) -> elt_t { return ext[row * p.nreq + j]; };
+  tv[4] = now_ms();
 
   for (size_t j = 0; j < p.nreq; ++j) {  // low_degree_check
     elt_t yc = req_at(p.ildt, j);
@@ -1143,6 +1148,9 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
       if (!elt_eq(yc, ext_at(p.nwqrow + 2, j))) return fail(6);
     }
   }
+  if (verbose)
+    fprintf(stderr, "lfgpu zk_verify: parse %.2f ms | FS init + constraints (bind_gh_all) %.2f | challenges + merkle %.2f | A + RS extension %.2f | checks %.2f\n",
+            tv[1] - tv[0], tv[2] - tv[1], tv[3] - tv[2], tv[4] - tv[3], now_ms() - tv[4]);
   *ok = 1;
   return fail(0);
 }
