@@ -520,7 +520,15 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   // Larger rounds always take the multi-kernel path (whole-GPU kernels, 2 stream synchronisations per round-hand).
   static const int sc_mode = [] {
     const char* e = getenv("LFGPU_SC_MODE");
-    return !e ? 3 : !strcmp(e, "off") ? 0 : !strcmp(e, "launch") ? 1 : !strcmp(e, "resident") ? 2 : 3;
+    if (!e) {
+      // rocprofv3 (ROCm 7.2) crashes in its own finalisation when the traced process ran kernels that stay resident
+      // across host round trips (results and stats are written first, the proofs are correct): under the profiler
+      // default to one fused launch per round-hand, which it handles.  LFGPU_SC_MODE overrides.
+      const char* pre = getenv("LD_PRELOAD");
+      const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || (pre && strstr(pre, "rocprofiler"));
+      return profiled ? 1 : 3;
+    }
+    return !strcmp(e, "off") ? 0 : !strcmp(e, "launch") ? 1 : !strcmp(e, "resident") ? 2 : 3;
   }();
   const bool no_fuse = sc_mode == 0;
   const bool use_resident = sc_mode >= 2 && lf_sc_resident_ok(c);

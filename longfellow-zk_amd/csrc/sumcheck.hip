@@ -1025,6 +1025,7 @@ int lf_sc_small_step(lfgpu_ctx* c, const ScSmall& a, u64 out[8]) {
 // whether coherent pinned memory lets a RUNNING kernel see host writes on this system (otherwise the per-step
 // launches are used)
 __global__ void sc_handshake_test_kernel(u64 seq, u64 timeout_ticks, volatile u64* post, const volatile u64* cmd) {
+  if (threadIdx.x != 0) return;
   post[8] = 0;
   __threadfence_system();
   __hip_atomic_store((u64*)&post[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1048,8 +1049,18 @@ bool lf_sc_resident_ok(lfgpu_ctx* c) {
   const u64 seq = c->poll_seq + 1;
   c->poll_seq += 2;
   volatile u64* cmd = c->poll_h + 64;
-  hipLaunchKernelGGL(sc_handshake_test_kernel, dim3(1), dim3(1), 0, c->stream, seq, 200ull * c->wall_khz /*0.2 s*/, c->poll_h, cmd);
-  if (hipGetLastError() != hipSuccess) return false;
+  // launched the way the layer kernel is (cooperative): tools that hold such a dispatch back until it has finished
+  // (rocprofv3 --kernel-trace does) make the first post invisible while the kernel runs, and the test fails cleanly
+  {
+    u64 a_seq = seq, a_to = 200ull * c->wall_khz /*0.2 s*/;
+    volatile u64* a_post = c->poll_h;
+    const volatile u64* a_cmd = cmd;
+    void* args[] = {&a_seq, &a_to, &a_post, &a_cmd};
+    if (hipLaunchCooperativeKernel((const void*)sc_handshake_test_kernel, dim3(1), dim3(64), args, 0, c->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+  }
   bool seen = false;  // the first post must arrive while the kernel is still waiting for us
   for (u64 spins = 0; spins < (1ull << 34); ++spins) {
     if (__atomic_load_n((const u64*)&c->poll_h[5], __ATOMIC_ACQUIRE) == seq) {
