@@ -30,6 +30,22 @@ int lf_scratch(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scra
 int lf_scratch2(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch2, &c->scratch2_bytes, bytes, out); }
 int lf_scratch3(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch3, &c->scratch3_bytes, bytes, out); }
 
+int lf_stage_upload(lfgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+  const unsigned slot = c->stage_next & 3;
+  if (!c->stage_h || !c->stage_ev[slot] || bytes > LF_STAGE_SLOT) {  // no ring: plain copy, the source must outlive it
+    LF_HIP(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    LF_HIP(c, hipStreamSynchronize(c->stream));
+    return LFGPU_OK;
+  }
+  ++c->stage_next;
+  LF_HIP(c, hipEventSynchronize(c->stage_ev[slot]));  // the copy that last used this slot (normally long done)
+  void* h = (uint8_t*)c->stage_h + (size_t)slot * LF_STAGE_SLOT;
+  memcpy(h, h_src, bytes);
+  LF_HIP(c, hipMemcpyAsync(d_dst, h, bytes, hipMemcpyHostToDevice, c->stream));
+  LF_HIP(c, hipEventRecord(c->stage_ev[slot], c->stream));
+  return LFGPU_OK;
+}
+
 bool lf_table_lookup(lfgpu_ctx* c, const std::string& key, void** out) {
   auto it = c->tables.find(key);
   if (it == c->tables.end()) return false;
@@ -145,6 +161,9 @@ int lfgpu_init(int device, lfgpu_ctx** out) {
   }
   memset(ph, 0, 4096);
   c->poll_h = (volatile u64*)ph;
+  if (hipHostMalloc(&c->stage_h, 4 * LF_STAGE_SLOT) != hipSuccess) c->stage_h = nullptr;  // optional: uploads then synchronise
+  for (int i = 0; i < 4 && c->stage_h; ++i)
+    if (hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess) c->stage_ev[i] = nullptr;
   *out = c;
   return LFGPU_OK;
 }
@@ -159,6 +178,9 @@ int lfgpu_shutdown(lfgpu_ctx* c) {
   if (c->scratch3) hipFree(c->scratch3);
   if (c->mailbox_h) hipHostFree(c->mailbox_h);
   if (c->poll_h) hipHostFree((void*)c->poll_h);
+  for (int i = 0; i < 4; ++i)
+    if (c->stage_ev[i]) hipEventDestroy(c->stage_ev[i]);
+  if (c->stage_h) hipHostFree(c->stage_h);
   if (c->mailbox_d) hipFree(c->mailbox_d);
   delete c;
   return LFGPU_OK;

@@ -40,6 +40,11 @@ struct lfgpu_ctx {
   // small pinned host mailbox for results read back every call (roots, partial sums)
   void* mailbox_h = nullptr;
   void* mailbox_d = nullptr;
+  // pinned staging ring for small host tables that are uploaded without a stream synchronisation: slot i may be
+  // rewritten once stage_ev[i] (recorded after its copy) has completed
+  void* stage_h = nullptr;
+  hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned stage_next = 0;
   // coherent (fine-grained) pinned words a running kernel writes and the host polls: results of the fused
   // sumcheck steps come back without a stream synchronisation
   volatile u64* poll_h = nullptr;
@@ -69,6 +74,9 @@ int lf_scratch3(lfgpu_ctx* c, size_t bytes, void** out);
 // upload (and cache under `key`) a host table; returns device pointer
 int lf_table(lfgpu_ctx* c, const std::string& key, const void* host, size_t bytes, void** out);
 bool lf_table_lookup(lfgpu_ctx* c, const std::string& key, void** out);
+// asynchronous upload of <= LF_STAGE_SLOT bytes through the pinned staging ring (no stream synchronisation)
+#define LF_STAGE_SLOT 4096
+int lf_stage_upload(lfgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes);
 
 // host-side field helpers (use the LF_HD arithmetic of fields.h compiled for the host)
 elt_t h_gf_inv(elt_t a);

@@ -306,8 +306,7 @@ extern "C" int lfgpu_raw_eq2(lfgpu_ctx* c, int field, size_t logn, size_t n, con
   }
   void* d_G = nullptr;
   LF_TRY(lf_scratch2(c, Gt.size() * 16, &d_G));
-  LF_HIP(c, hipMemcpyAsync(d_G, Gt.data(), Gt.size() * 16, hipMemcpyHostToDevice, c->stream));
-  LF_HIP(c, hipStreamSynchronize(c->stream));  // Gt is a stack-lifetime host buffer
+  LF_TRY(lf_stage_upload(c, d_G, Gt.data(), Gt.size() * 16));  // 4*logn+1 <= 161 elements: through the pinned ring
   const elt_t al{alpha[0], alpha[1]};
   QD_DISPATCH(field, raw_eq2_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, (u32)n,
               (const elt_t*)d_G, al, one, (elt_t*)d_eq);
