@@ -356,6 +356,142 @@ void zk_round_cb(void* user, size_t hand, size_t rnd, const uint64_t ev[3][2], u
 }
 }  // namespace
 
+namespace {
+// ---- ZkCommon::verifier_constraints (lib/zk/zk_common.h:49-136) + input_constraint (:406-439), shared by the prover
+// (aux = the bound quads the sumcheck prover recorded) and the verifier (aux = nullptr: Quad::bind_gh_all on the device).
+// Replays the verifier's side of the sumcheck on the transcript and returns the sparse rows of A (all but the dense
+// private-input block of the last constraint), b, and the EQ vector of the input constraint over all inputs.
+struct LinTerm {
+  size_t c, w;
+  elt_t k;
+};
+struct ConstraintSet {
+  std::vector<LinTerm> a;
+  std::vector<elt_t> b;       // one entry per constraint
+  std::vector<elt_t> eq_in;   // EQ(g0, i) + alpha EQ(g1, i), i < ninputs: dense coefficients of the last constraint
+  size_t n = 0;               // number of constraints; the dense one is n - 1
+};
+int build_constraints(lfgpu_ctx* c, const lfgpu_circuit* C, const HostField& F, const Ts& ts, const std::vector<lfgpu_zk_prover::LayerPad>& proof,
+                      const std::vector<elt_t>* aux, const elt_t* pub, ConstraintSet& out) {
+  const lfgpu_circuit_info& I = C->info;
+  const size_t nl = C->layers.size(), npub = I.npub_in;
+  std::vector<elt_t> G[2], gh[2];
+  for (size_t i = 0; i < kMaxBindings; ++i) (void)ts.elt();  // begin_circuit: Q (unused for logc = 0), then G
+  G[0].resize(kMaxBindings);
+  for (size_t i = 0; i < kMaxBindings; ++i) G[0][i] = ts.elt();
+  G[1] = G[0];
+  size_t logv = I.logv, ci = 0, pi = I.ninputs - npub;
+  elt_t claims[2] = {elt_t{0, 0}, elt_t{0, 0}};
+  std::vector<elt_t> sym;
+  for (size_t ly = 0; ly < nl; ++ly) {
+    const auto& L = C->layers[ly];
+    const size_t logw = L.logw;
+    const elt_t alpha = ts.elt(), beta = ts.elt();
+    const size_t n = 3 + layer_size(logw);  // ovp_layer_size
+    elt_t known{0, 0};
+    sym.assign(n, elt_t{0, 0});
+    auto axpy = [&](size_t var, elt_t kv, elt_t k) {  // Expression::axpy
+      known = F.add(known, F.mul(k, kv));
+      sym[var] = F.add(sym[var], k);
+    };
+    auto axmy = [&](size_t var, elt_t kv, elt_t k) {  // Expression::axmy
+      known = F.sub(known, F.mul(k, kv));
+      sym[var] = F.sub(sym[var], k);
+    };
+    axpy(0, claims[0], F.one);  // ConstraintBuilder::first
+    axpy(1, claims[1], alpha);
+    gh[0].assign(logw ? logw : 1, elt_t{0, 0});
+    gh[1].assign(logw ? logw : 1, elt_t{0, 0});
+    const auto& P = proof[ly];
+    for (size_t rnd = 0; rnd < logw; ++rnd)
+      for (int hand = 0; hand < 2; ++hand) {
+        const size_t r = 2 * rnd + hand;
+        const elt_t t0e = P.hp[hand][2 * rnd], t2e = P.hp[hand][2 * rnd + 1];
+        ts.write_elt(t0e);
+        ts.write_elt(t2e);
+        const elt_t chal = ts.elt();
+        gh[hand][rnd] = chal;
+        elt_t lag[3];  // dot_interpolation coefficients: p(chal) = sum_i lag[i] p(P_i)
+        for (int i = 0; i < 3; ++i) {
+          elt_t num = F.one;
+          for (int j = 0; j < 3; ++j)
+            if (j != i) num = F.mul(num, F.sub(chal, F.pts[j]));
+          lag[i] = F.mul(num, F.invden[i]);
+        }
+        axmy(3 + 2 * r, t0e, F.one);   // ConstraintBuilder::next: p(1) = claim - p(0)
+        known = F.mul(known, lag[1]);  // scale
+        for (auto& s : sym)
+          if (s.lo | s.hi) s = F.mul(s, lag[1]);
+        axpy(3 + 2 * r, t0e, lag[0]);
+        axpy(3 + 2 * r + 1, t2e, lag[2]);
+      }
+    elt_t eqq;  // EQ[Q,C] QUAD[R,L]; Eq::eval with logc = 0 is 1
+    if (aux) {
+      eqq = (*aux)[ly];
+    } else {
+      uint64_t bq[2];
+      const uint64_t al[2] = {alpha.lo, alpha.hi}, be[2] = {beta.lo, beta.hi};
+      LF_TRY(lfgpu_quad_bind_gh_all(L.q, logv, G[0].data(), G[1].data(), al, be, logw, L.nw, gh[0].data(), gh[1].data(), bq));
+      eqq = elt_t{bq[0], bq[1]};
+    }
+    const size_t cp = 3 + 4 * logw;  // ConstraintBuilder::finalize
+    out.b.push_back(F.sub(F.mul(eqq, F.mul(P.wc[0], P.wc[1])), known));
+    sym[cp] = F.sub(sym[cp], F.mul(eqq, P.wc[1]));
+    sym[cp + 1] = F.sub(sym[cp + 1], F.mul(eqq, P.wc[0]));
+    sym[cp + 2] = F.sub(sym[cp + 2], eqq);
+    for (size_t i = ly == 0 ? 3 : 0; i < n; ++i) out.a.push_back({ci, pi + i - 3, sym[i]});
+    ++ci;
+    ts.write_array(P.wc, 2);
+    claims[0] = P.wc[0];
+    claims[1] = P.wc[1];
+    for (int h = 0; h < 2; ++h) {
+      G[h].assign(kMaxBindings, elt_t{0, 0});
+      for (size_t r = 0; r < logw; ++r) G[h][r] = gh[h][r];
+    }
+    logv = logw;
+    pi += layer_size(logw);
+  }
+  const elt_t alpha = ts.elt();
+  out.a.push_back({ci, pi - 3, F.one});  // input_constraint: the claims of the input layer
+  out.a.push_back({ci, pi - 2, alpha});
+  out.n = ci + 1;
+  // EQ table over the inputs on the device: public part folded into b, private part = dense block of A
+  out.eq_in.assign(I.ninputs, elt_t{0, 0});
+  const size_t logn = C->layers[nl - 1].logw;
+  void* d_eq = nullptr;
+  LF_TRY(lf_scratch3(c, I.ninputs * 16, &d_eq));
+  const uint64_t al[2] = {alpha.lo, alpha.hi};
+  LF_TRY(lfgpu_raw_eq2(c, LFGPU_FIELD_GF2_128, logn, I.ninputs, gh[0].data(), gh[1].data(), al, d_eq));
+  LF_HIP(c, hipMemcpyAsync(out.eq_in.data(), d_eq, I.ninputs * 16, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  const auto& P = proof[nl - 1];
+  elt_t pub_binding{0, 0};
+  for (size_t i = 0; i < npub; ++i) pub_binding = F.add(pub_binding, F.mul(out.eq_in[i], pub[i]));
+  out.b.push_back(F.sub(F.add(P.wc[0], F.mul(alpha, P.wc[1])), pub_binding));
+  return LFGPU_OK;
+}
+
+// LigeroCommon::inner_product_vector (lib/ligero/ligero_param.h:382-421): A[nwqrow][w] from the linear constraints
+// (sparse terms + the dense private-input block), alphal, the quadratic constraints and alphaq
+void inner_product_vector(std::vector<elt_t>& A, const lfgpu_ligero_param& p, const ConstraintSet& cs, size_t npub, size_t n_witness,
+                          const std::vector<elt_t>& alphal, const std::vector<size_t>& lqc, const std::vector<elt_t>& alphaq) {
+  A.assign(p.nwqrow * p.w, elt_t{0, 0});
+  const elt_t ad = alphal[cs.n - 1];
+  for (size_t w = 0; w < n_witness; ++w) A[w] = h_gf_mul(ad, cs.eq_in[npub + w]);
+  for (const LinTerm& t : cs.a) A[t.w] = gf_add(A[t.w], h_gf_mul(t.k, alphal[t.c]));
+  const size_t base = p.nwrow * p.w;
+  const size_t Ax = base, Ay = base + p.nqtriples * p.w, Az = base + 2 * p.nqtriples * p.w;
+  for (size_t iw = 0; iw < p.nq; ++iw) {
+    const size_t off[3] = {Ax + iw, Ay + iw, Az + iw};
+    for (int j = 0; j < 3; ++j) {
+      const elt_t aq = alphaq[3 * iw + j];
+      A[off[j]] = gf_add(A[off[j]], aq);
+      A[lqc[3 * iw + j]] = gf_add(A[lqc[3 * iw + j]], aq);
+    }
+  }
+}
+}  // namespace
+
 extern "C" int lfgpu_zk_prover_new(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc,
                                    lfgpu_zk_prover** out) {
   if (!c || !C || !out || C->c != c) return LFGPU_ERR_ARG;
@@ -534,96 +670,10 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
 
   // verifier_constraints with aux (zk_common.h:49-136): replay the verifier symbolically on the ORIGINAL transcript
   t0 = now_ms();
-  struct Term {
-    size_t c, w;
-    elt_t k;
-  };
-  std::vector<Term> a;
-  size_t ci = 0;
-  elt_t alpha_in;
-  std::vector<elt_t> gh[2];
-  {
-    for (size_t i = 0; i < kMaxBindings; ++i) (void)ts.elt();
-    for (size_t i = 0; i < kMaxBindings; ++i) (void)ts.elt();  // G: only the hand bindings of the last layer are used below
-    elt_t claims[2] = {elt_t{0, 0}, elt_t{0, 0}};
-    size_t pi = zk->n_witness;
-    std::vector<elt_t> sym;
-    for (size_t ly = 0; ly < nl; ++ly) {
-      const size_t logw = C->layers[ly].logw;
-      const elt_t alpha = ts.elt();
-      (void)ts.elt();  // beta
-      const size_t n = 3 + layer_size(logw);  // ovp_layer_size
-      elt_t known{0, 0};
-      sym.assign(n, elt_t{0, 0});
-      auto axpy = [&](size_t var, elt_t kv, elt_t k) {
-        known = F.add(known, F.mul(k, kv));
-        sym[var] = F.add(sym[var], k);
-      };
-      axpy(0, claims[0], F.one);  // ConstraintBuilder::first
-      axpy(1, claims[1], alpha);
-      gh[0].assign(logw, elt_t{0, 0});
-      gh[1].assign(logw, elt_t{0, 0});
-      const auto& P = zk->proof[ly];
-      for (size_t rnd = 0; rnd < logw; ++rnd)
-        for (int hand = 0; hand < 2; ++hand) {
-          const size_t r = 2 * rnd + hand;
-          const elt_t t0e = P.hp[hand][2 * rnd], t2e = P.hp[hand][2 * rnd + 1];
-          ts.write_elt(t0e);
-          ts.write_elt(t2e);
-          const elt_t chal = ts.elt();
-          gh[hand][rnd] = chal;
-          elt_t lag[3];  // dot_interpolation coefficients: p(chal) = sum_i lag[i] p(P_i)
-          for (int i = 0; i < 3; ++i) {
-            elt_t num = F.one;
-            for (int j = 0; j < 3; ++j)
-              if (j != i) num = F.mul(num, F.sub(chal, F.pts[j]));
-            lag[i] = F.mul(num, F.invden[i]);
-          }
-          axpy(3 + 2 * r, t0e, F.one);  // p(1) = claim - p(0)  (axmy == axpy in characteristic 2)
-          known = F.mul(known, lag[1]);  // scale
-          for (auto& s : sym)
-            if (s.lo | s.hi) s = F.mul(s, lag[1]);
-          axpy(3 + 2 * r, t0e, lag[0]);
-          axpy(3 + 2 * r + 1, t2e, lag[2]);
-        }
-      const elt_t eqq = zk->aux[ly];  // Eq::eval with logc = 0 is 1
-      const size_t cp = 3 + 4 * logw;  // finalize
-      sym[cp] = F.add(sym[cp], F.mul(eqq, P.wc[1]));
-      sym[cp + 1] = F.add(sym[cp + 1], F.mul(eqq, P.wc[0]));
-      sym[cp + 2] = F.add(sym[cp + 2], eqq);
-      for (size_t i = ly == 0 ? 3 : 0; i < n; ++i) a.push_back({ci, pi + i - 3, sym[i]});
-      ++ci;
-      ts.write_array(P.wc, 2);
-      claims[0] = P.wc[0];
-      claims[1] = P.wc[1];
-      pi += layer_size(logw);
-    }
-    alpha_in = ts.elt();
-    a.push_back({ci, pi - 3, F.one});  // input_constraint (zk_common.h:406-439): claims of the input layer
-    a.push_back({ci, pi - 2, alpha_in});
-    ++ci;
-  }
-  const size_t nconstraints = ci, dense_c = ci - 1;
-  // dense part of the input constraint: EQ(g0, i) + alpha EQ(g1, i) over the inputs, on the device
+  ConstraintSet cs;
+  LF_TRY(build_constraints(c, C, F, ts, zk->proof, &zk->aux, W, cs));
+  const size_t nconstraints = cs.n;
   const lfgpu_ligero_param& p = zk->param;
-  std::vector<elt_t> A(p.nwqrow * p.w, elt_t{0, 0});
-  std::vector<elt_t> bi(zk->n_witness);
-  {
-    const size_t logn = C->layers[nl - 1].logw;
-    void* d_eq = nullptr;
-    LF_TRY(lf_scratch3(c, I.ninputs * 16, &d_eq));
-    std::vector<elt_t> g0(logn ? logn : 1, elt_t{0, 0}), g1(logn ? logn : 1, elt_t{0, 0});
-    for (size_t i = 0; i < logn; ++i) {
-      g0[i] = gh[0][i];
-      g1[i] = gh[1][i];
-    }
-    const uint64_t al[2] = {alpha_in.lo, alpha_in.hi};
-    LF_TRY(lfgpu_raw_eq2(c, LFGPU_FIELD_GF2_128, logn, I.ninputs, g0.data(), g1.data(), al, d_eq));
-    if (zk->n_witness) {
-      LF_HIP(c, hipMemcpyAsync(bi.data(), (const elt_t*)d_eq + zk->npub, zk->n_witness * 16, hipMemcpyDeviceToHost, c->stream));
-      LF_HIP(c, hipStreamSynchronize(c->stream));
-    }
-  }
   zk->ms[4] = now_ms() - t0;
 
   // LigeroProver::prove (ligero_prover.h:84-146)
@@ -641,20 +691,8 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
     std::vector<elt_t> alphal(nconstraints), alphaq(3 * p.nq);
     for (auto& e : alphal) e = ts.elt();
     for (auto& e : alphaq) e = ts.elt();
-    // inner_product_vector (ligero_param.h:382-421)
-    for (size_t w = 0; w < zk->n_witness; ++w) A[w] = h_gf_mul(alphal[dense_c], bi[w]);
-    for (const Term& t : a) A[t.w] = gf_add(A[t.w], h_gf_mul(t.k, alphal[t.c]));
-    const size_t base = p.nwrow * p.w;
-    const size_t Ax = base, Ay = base + p.nqtriples * p.w, Az = base + 2 * p.nqtriples * p.w;
-    for (size_t iw = 0; iw < p.nq; ++iw) {
-      const size_t off[3] = {Ax + iw, Ay + iw, Az + iw};
-      for (int j = 0; j < 3; ++j) {
-        const elt_t aq = alphaq[3 * iw + j];
-        A[off[j]] = gf_add(A[off[j]], aq);
-        const size_t tgt = zk->lqc[3 * iw + j];
-        A[tgt] = gf_add(A[tgt], aq);
-      }
-    }
+    std::vector<elt_t> A;
+    inner_product_vector(A, p, cs, zk->npub, zk->n_witness, alphal, zk->lqc, alphaq);
     zk->y_dot.assign(p.dblock, elt_t{0, 0});
     tq[2] = now_ms();
     LF_TRY(lfgpu_ligero_dot_proof(zk->lp, A.data(), zk->y_dot.data()));
@@ -945,110 +983,20 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   }
 
   // verifier_constraints with aux == nullptr: the bound quad of every layer comes from bind_gh_all
-  struct Term {
-    size_t c, w;
-    elt_t k;
-  };
-  std::vector<Term> a;
-  std::vector<elt_t> b;
+  ConstraintSet cs;
+  LF_TRY(build_constraints(c, C, F, ts, pr.sc, nullptr, pub, cs));
+  const size_t nconstraints = cs.n;
   std::vector<size_t> lqc(3 * nl);
-  size_t ci = 0;
-  std::vector<elt_t> G[2], gh[2];
-  elt_t alpha_in;
   {
-    for (size_t i = 0; i < kMaxBindings; ++i) (void)ts.elt();  // Q
-    G[0].resize(kMaxBindings);
-    for (size_t i = 0; i < kMaxBindings; ++i) G[0][i] = ts.elt();
-    G[1] = G[0];
-    size_t logv = I.logv;
-    elt_t claims[2] = {elt_t{0, 0}, elt_t{0, 0}};
     size_t pi = n_witness;
-    std::vector<elt_t> sym;
-    for (size_t ly = 0; ly < nl; ++ly) {
-      const auto& L = C->layers[ly];
-      const size_t logw = L.logw;
-      const elt_t alpha = ts.elt(), beta = ts.elt();
-      const size_t n = 3 + layer_size(logw);
-      elt_t known{0, 0};
-      sym.assign(n, elt_t{0, 0});
-      auto axpy = [&](size_t var, elt_t kv, elt_t k) {
-        known = F.add(known, F.mul(k, kv));
-        sym[var] = F.add(sym[var], k);
-      };
-      axpy(0, claims[0], F.one);
-      axpy(1, claims[1], alpha);
-      gh[0].assign(logw ? logw : 1, elt_t{0, 0});
-      gh[1].assign(logw ? logw : 1, elt_t{0, 0});
-      const auto& P = pr.sc[ly];
-      for (size_t rnd = 0; rnd < logw; ++rnd)
-        for (int hand = 0; hand < 2; ++hand) {
-          const size_t r = 2 * rnd + hand;
-          const elt_t t0e = P.hp[hand][2 * rnd], t2e = P.hp[hand][2 * rnd + 1];
-          ts.write_elt(t0e);
-          ts.write_elt(t2e);
-          const elt_t chal = ts.elt();
-          gh[hand][rnd] = chal;
-          elt_t lag[3];
-          for (int i = 0; i < 3; ++i) {
-            elt_t num = F.one;
-            for (int j = 0; j < 3; ++j)
-              if (j != i) num = F.mul(num, F.sub(chal, F.pts[j]));
-            lag[i] = F.mul(num, F.invden[i]);
-          }
-          axpy(3 + 2 * r, t0e, F.one);
-          known = F.mul(known, lag[1]);
-          for (auto& s : sym)
-            if (s.lo | s.hi) s = F.mul(s, lag[1]);
-          axpy(3 + 2 * r, t0e, lag[0]);
-          axpy(3 + 2 * r + 1, t2e, lag[2]);
-        }
-      uint64_t bq[2];
-      const uint64_t al[2] = {alpha.lo, alpha.hi}, be[2] = {beta.lo, beta.hi};
-      LF_TRY(lfgpu_quad_bind_gh_all(L.q, logv, G[0].data(), G[1].data(), al, be, logw, L.nw, gh[0].data(), gh[1].data(), bq));
-      const elt_t eqq{bq[0], bq[1]};  // Eq::eval with logc = 0 is 1
-      const size_t cp = 3 + 4 * logw;
-      b.push_back(F.sub(F.mul(eqq, F.mul(P.wc[0], P.wc[1])), known));  // ConstraintBuilder::finalize
-      sym[cp] = F.sub(sym[cp], F.mul(eqq, P.wc[1]));
-      sym[cp + 1] = F.sub(sym[cp + 1], F.mul(eqq, P.wc[0]));
-      sym[cp + 2] = F.sub(sym[cp + 2], eqq);
-      for (size_t i = ly == 0 ? 3 : 0; i < n; ++i) a.push_back({ci, pi + i - 3, sym[i]});
-      ++ci;
-      ts.write_array(P.wc, 2);
-      claims[0] = P.wc[0];
-      claims[1] = P.wc[1];
-      lqc[3 * ly] = pi + 4 * logw;  // setup_lqc
-      lqc[3 * ly + 1] = pi + 4 * logw + 1;
-      lqc[3 * ly + 2] = pi + 4 * logw + 2;
-      for (int h = 0; h < 2; ++h) {
-        G[h].assign(kMaxBindings, elt_t{0, 0});
-        for (size_t r = 0; r < logw; ++r) G[h][r] = gh[h][r];
-      }
-      logv = logw;
-      pi += layer_size(logw);
+    for (size_t ly = 0; ly < nl; ++ly) {  // setup_lqc (zk_common.h:149-160)
+      const size_t cp = pi + 4 * C->layers[ly].logw;
+      lqc[3 * ly] = cp;
+      lqc[3 * ly + 1] = cp + 1;
+      lqc[3 * ly + 2] = cp + 2;
+      pi += layer_size(C->layers[ly].logw);
     }
-    alpha_in = ts.elt();
-    a.push_back({ci, pi - 3, F.one});
-    a.push_back({ci, pi - 2, alpha_in});
-    ++ci;
   }
-  const size_t nconstraints = ci, dense_c = ci - 1;
-  // input_constraint: EQ table over the inputs; public part folded into b, private part is the dense block of A
-  std::vector<elt_t> bi(I.ninputs);
-  {
-    const size_t logn = C->layers[nl - 1].logw;
-    void* d_eq = nullptr;
-    LF_TRY(lf_scratch3(c, I.ninputs * 16, &d_eq));
-    const uint64_t al[2] = {alpha_in.lo, alpha_in.hi};
-    LF_TRY(lfgpu_raw_eq2(c, LFGPU_FIELD_GF2_128, logn, I.ninputs, gh[0].data(), gh[1].data(), al, d_eq));
-    LF_HIP(c, hipMemcpyAsync(bi.data(), d_eq, I.ninputs * 16, hipMemcpyDeviceToHost, c->stream));
-    LF_HIP(c, hipStreamSynchronize(c->stream));
-    const auto& P = pr.sc[nl - 1];
-    elt_t pub_binding{0, 0};
-    for (size_t i = 0; i < npub; ++i) pub_binding = F.add(pub_binding, F.mul(bi[i], pub[i]));
-    const elt_t got = F.add(P.wc[0], F.mul(alpha_in, P.wc[1]));
-    b.push_back(F.sub(got, pub_binding));
-  }
-
   tv[2] = now_ms();
   // LigeroVerifier::verify: replay the challenges
   uint8_t hash_of_A[32] = {0xde, 0xad, 0xbe, 0xef};
@@ -1082,21 +1030,8 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
 
   tv[3] = now_ms();
   // device: rows [0, nwqrow) = [0^r | A_i] extended block -> block_enc, rows nwqrow.. = y_ldt, y_dot, y_quad
-  std::vector<elt_t> A(p.nwqrow * p.w, elt_t{0, 0});
-  for (size_t w = 0; w < n_witness; ++w) A[w] = h_gf_mul(alphal[dense_c], bi[npub + w]);  // inner_product_vector
-  for (const Term& t : a) A[t.w] = gf_add(A[t.w], h_gf_mul(t.k, alphal[t.c]));
-  {
-    const size_t base = p.nwrow * p.w;
-    const size_t Ax = base, Ay = base + p.nqtriples * p.w, Az = base + 2 * p.nqtriples * p.w;
-    for (size_t iw = 0; iw < p.nq; ++iw) {
-      const size_t off[3] = {Ax + iw, Ay + iw, Az + iw};
-      for (int j = 0; j < 3; ++j) {
-        const elt_t aq = alphaq[3 * iw + j];
-        A[off[j]] = gf_add(A[off[j]], aq);
-        A[lqc[3 * iw + j]] = gf_add(A[lqc[3 * iw + j]], aq);
-      }
-    }
-  }
+  std::vector<elt_t> A;
+  inner_product_vector(A, p, cs, npub, n_witness, alphal, lqc, alphaq);
   const size_t nrows_dev = p.nwqrow + 3, ld = p.block_enc;
   void* dT = nullptr;
   LF_TRY(lf_scratch(c, (nrows_dev * ld + (size_t)nrows_dev * p.nreq) * 16 + 256, &dT));
@@ -1133,7 +1068,7 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   }
   {  // the putative value of the inner product
     elt_t want{0, 0}, got{0, 0};
-    for (size_t k = 0; k < nconstraints; ++k) want = gf_add(want, h_gf_mul(b[k], alphal[k]));
+    for (size_t k = 0; k < nconstraints; ++k) want = gf_add(want, h_gf_mul(cs.b[k], alphal[k]));
     for (size_t j = 0; j < p.w; ++j) got = gf_add(got, pr.y_dot[p.r + j]);
     if (!elt_eq(want, got)) return fail(5);
   }
