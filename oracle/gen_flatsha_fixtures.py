@@ -44,5 +44,25 @@ def main():
             print(info)
 
 
+def variant(nb=1, npub=9, sfb=777):
+    """same circuit with the first `npub` inputs declared public and inputs below `sfb` declared subfield (what the
+    mdoc hash circuit does): only sizes and hashes are stored -- the LFC1 bytes are the nb fixture with two header
+    fields patched (pinned by lfc1_sha256), the witness is the nb fixture's"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/gen_flatsha"])
+    with tempfile.TemporaryDirectory() as td:
+        pre = os.path.join(td, "x")
+        info = json.loads(subprocess.check_output([GEN, str(nb), pre, str(npub), str(sfb)]).decode())
+        wire = open(pre + ".zkwire", "rb").read()
+        info.update(npub_in=npub, subfield_boundary=sfb, zk_wire_bytes=len(wire), zk_wire_sha256=hashlib.sha256(wire).hexdigest(),
+                    lfc1_sha256=hashlib.sha256(open(pre + ".lfc1", "rb").read()).hexdigest())
+        dst = os.path.join(OUT, "flatsha_nb%d_pub%d_sfb%d.json" % (nb, npub, sfb))
+        with open(dst, "w") as f:
+            json.dump(info, f)
+        print(dst, info)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:2] == ["variant"]:
+        variant()
+    else:
+        main()

@@ -89,6 +89,12 @@ int main(int argc, char** argv) {
   for (auto& b : bw) b.input(lc);
   sha.assert_message_hash(nb, nbv, in.data(), target, bw.data());
   std::unique_ptr<Circuit<F128>> C = Q.mkcircuit(1);
+  // optional: declare the first argv[3] inputs public and inputs below argv[4] known to lie in the subfield (the SHA
+  // circuit's first 1 + 8 + 512*nb + 256 inputs are the constant one and bits), as the mdoc hash circuit does; the
+  // gates are unchanged.  Exercises the public-input binding, subfield sampling and the run-length wire encoding.
+  if (argc > 3) C->npub_in = strtoul(argv[3], nullptr, 10);
+  if (argc > 4) C->subfield_boundary = strtoul(argv[4], nullptr, 10);
+  check(C->npub_in <= C->ninputs && C->subfield_boundary <= 1 + 8 + 512 * nb + 256, "override out of range");
 
   // ---- witness for the message 'a' x len
   const size_t nbench = sizeof(kSha_benchmark_) / sizeof(kSha_benchmark_[0]);

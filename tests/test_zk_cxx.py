@@ -285,3 +285,42 @@ def test_zk_verifier_accepts_reference_and_own_proofs_rejects_tampering(nb):
     assert G.pkg.zk_verify(gpu, circ, own, pub, ts)[0] is False
     ts.close()
     circ.close()
+
+
+@pytest.mark.gpu
+def test_zk_public_inputs_and_subfield_boundary_match_reference():
+    """The mdoc hash circuit's two features the flatsha benchmark circuit lacks: public inputs (bound through
+    input_constraint, written to the transcript) and a subfield boundary (witness rows below it are padded with
+    subfield randomness, and opened subfield elements travel as 2 bytes in runs).  Fixture: the reference run on the
+    1-block circuit with npub_in = 9, subfield_boundary = 777 (oracle/gen_flatsha_fixtures.py variant)."""
+    import gpu_util as G
+    import ligero_fixture as lf
+    raw, W, _ = _load(1)
+    info = json.load(open(os.path.join(GOLD, "flatsha_nb1_pub9_sfb777.json")))
+    b = bytearray(raw)
+    b[1 + 9:1 + 12] = info["npub_in"].to_bytes(3, "little")          # header: version, fid, nv, nc, NPUB, SFB, ...
+    b[1 + 12:1 + 15] = info["subfield_boundary"].to_bytes(3, "little")
+    raw2 = bytes(b)
+    assert hashlib.sha256(raw2).hexdigest() == info["lfc1_sha256"]  # exactly the bytes the reference serialised
+    gpu = G.gpu()
+    circ = G.pkg.Circuit(gpu, raw2)
+    assert (circ.info.npub_in, circ.info.subfield_boundary) == (9, 777)
+    zk = G.pkg.ZkProver(gpu, circ, 7, 132)
+    assert zk.param.nw == info["zk_nw"]
+    ts = G.pkg.FsTranscript(b"test")
+    zk.commit(W, lf.LcgRng(100).bytes, ts)
+    assert zk.prove(W, ts)
+    wire = zk.wire()
+    ts.close()
+    assert len(wire) == info["zk_wire_bytes"]
+    assert hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"]
+    tv = G.pkg.FsTranscript(b"test")
+    assert G.pkg.zk_verify(gpu, circ, wire, W[:9], tv) == (True, "ok")
+    tv.close()
+    pub_bad = W[:9].copy()
+    pub_bad[3, 0] ^= np.uint64(1)  # a different public input: rejected
+    tv = G.pkg.FsTranscript(b"test")
+    assert G.pkg.zk_verify(gpu, circ, wire, pub_bad, tv)[0] is False
+    tv.close()
+    zk.close()
+    circ.close()
