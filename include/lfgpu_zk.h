@@ -7,8 +7,11 @@
  *   ZkProof::write                            lib/zk/zk_proof.h:90-185
  *   CircuitRep::from_bytes (LFC1)             lib/proto/circuit.h, lib/proto/circuit_reader.h:55-233
  * written in C++ inside the library, with every data-parallel step on the device through the lfgpu.h kernels.
- * Field: GF2_128<4> (the field of BM_ShaZK_fp2_128, lib/circuits/sha/flatsha256_circuit_test.cc:510-536); other
- * field ids in the circuit header return LFGPU_ERR_UNSUPPORTED.
+ * Fields: GF2_128<4> (the field of BM_ShaZK_fp2_128, lib/circuits/sha/flatsha256_circuit_test.cc:510-536; LCH14
+ * Reed-Solomon) and Fp128 (field id 6; ReedSolomonFactory over FFTConvolutionFactory with the 2^32-order root, as
+ * lib/zk/zk_test.cc:252-330 sets it up); other field ids in the circuit header return LFGPU_ERR_UNSUPPORTED.
+ * Elements cross the ABI as the reference's in-memory Elt images (Fp128: Montgomery form) and the wire as
+ * to_bytes_field images.
  *
  * The Fiat-Shamir transcript and the RandomEngine are the CALLER's: they are reached through the hooks below, so
  * an integration passes thin wrappers over proofs::Transcript / proofs::RandomEngine.  A built-in

@@ -85,6 +85,8 @@ static elt_t h_fp_rsq() {
   return rsq;
 }
 elt_t h_fp_of_scalar(u64 u) { return fp_mul(elt_t{u, 0}, h_fp_rsq()); }
+elt_t h_fp_to_mont(elt_t raw) { return fp_mul(raw, h_fp_rsq()); }
+bool h_fp_fits(elt_t raw) { return raw.hi < FP_P_HI || (raw.hi == FP_P_HI && raw.lo < FP_P_LO); }
 elt_t h_fp_inv(elt_t x) {  // x^(p-2)
   unsigned __int128 e = (((unsigned __int128)FP_P_HI) << 64 | FP_P_LO) - 2;
   elt_t r = h_fp_of_scalar(1), b = x;

@@ -82,6 +82,10 @@ int lf_stage_upload(lfgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes);
 elt_t h_gf_inv(elt_t a);
 elt_t h_fp_inv(elt_t a);
 elt_t h_fp_of_scalar(u64 u);
+elt_t h_fp_to_mont(elt_t raw);  // raw < p -> Montgomery image
+bool h_fp_fits(elt_t raw);      // raw < p
+// Reed-Solomon row extension for either field (GF2_128<k>: LCH14; Fp128: convolution with the 2^32-order root)
+int lf_rs_rows(lfgpu_ctx* c, int field, int k, size_t nrow, size_t n, size_t m, elt_t* d, size_t ld);
 const GfHostCtx* lf_gf_ctx(lfgpu_ctx* c, int k);
 elt_t h_lch14_twiddle(const GfHostCtx* g, unsigned i, u64 u);
 

@@ -161,7 +161,7 @@ static inline elt_t h_add(int field, elt_t a, elt_t b) { return field == LFGPU_F
 static inline elt_t h_sub(int field, elt_t a, elt_t b) { return field == LFGPU_FIELD_GF2_128 ? gf_add(a, b) : fp_sub(a, b); }
 static inline elt_t h_mul(int field, elt_t a, elt_t b) { return field == LFGPU_FIELD_GF2_128 ? gf_mul(a, b) : fp_mul(a, b); }
 
-static int rs_rows(lfgpu_ctx* c, int field, int k, size_t nrow, size_t n, size_t m, elt_t* d, size_t ld) {
+int lf_rs_rows(lfgpu_ctx* c, int field, int k, size_t nrow, size_t n, size_t m, elt_t* d, size_t ld) {
   if (nrow == 0) return LFGPU_OK;
   if (field == LFGPU_FIELD_GF2_128) return lfgpu_gf2128_rs_encode_rows(c, k, nrow, n, m, d, ld);
   // Fp128: the 2^32-order root of lib/algebra/fp_p128.h:48-56
@@ -260,9 +260,9 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
       hipMemcpyAsync(d_non, pr->nonces.data(), p.block_ext * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess)
     return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit: upload failed"));
   // rows 0 (ILDT) and all witness/quadratic rows: block -> block_enc; rows 1,2: dblock -> block_enc
-  if ((rc = rs_rows(c, field, k, 1, p.block, p.block_enc, pr->d_T + p.ildt * ld, ld))) return fail(rc);
-  if ((rc = rs_rows(c, field, k, 2, p.dblock, p.block_enc, pr->d_T + p.idot * ld, ld))) return fail(rc);
-  if ((rc = rs_rows(c, field, k, p.nwqrow, p.block, p.block_enc, pr->d_T + p.iw * ld, ld))) return fail(rc);
+  if ((rc = lf_rs_rows(c, field, k, 1, p.block, p.block_enc, pr->d_T + p.ildt * ld, ld))) return fail(rc);
+  if ((rc = lf_rs_rows(c, field, k, 2, p.dblock, p.block_enc, pr->d_T + p.idot * ld, ld))) return fail(rc);
+  if ((rc = lf_rs_rows(c, field, k, p.nwqrow, p.block, p.block_enc, pr->d_T + p.iw * ld, ld))) return fail(rc);
   if ((rc = lfgpu_column_commit(c, field, p.nrow, ld, p.dblock, p.block_ext, pr->d_T, d_non, pr->d_layers, root_out)))
     return fail(rc);
   *out = pr;
@@ -350,7 +350,7 @@ extern "C" int lfgpu_ligero_dot_proof(lfgpu_ligero_prover* pr, const void* h_A, 
   LF_HIP(c, hipMemsetAsync(dAext, 0, p.nwqrow * lda * 16, c->stream));
   hipLaunchKernelGGL(layout_aext_kernel, dim3((u32)((p.block + 255) / 256), (u32)p.nwqrow), dim3(256), 0, c->stream,
                      (u32)p.r, (u32)p.w, lda, (const elt_t*)dA, dAext);
-  LF_TRY(rs_rows(c, pr->field, pr->k, p.nwqrow, p.block, p.dblock, dAext, lda));
+  LF_TRY(lf_rs_rows(c, pr->field, pr->k, p.nwqrow, p.block, p.dblock, dAext, lda));
   LIG_DISPATCH(pr->field, rows_vaxpy_kernel, dim3((u32)((p.dblock + 255) / 256)), dim3(256), (u32)p.nwqrow, p.dblock,
                (const elt_t*)(pr->d_T + p.idot * p.block_enc), (const elt_t*)dAext, lda,
                (const elt_t*)(pr->d_T + p.iw * p.block_enc), p.block_enc, dy);

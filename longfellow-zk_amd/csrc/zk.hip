@@ -139,16 +139,49 @@ void lfgpu_transcript_get_ops(lfgpu_transcript* t, lfgpu_transcript_ops* ops) {
 
 namespace {
 // the caller's transcript seen through the hooks, plus the samplers built on RandomEngine::bytes
+// to_bytes_field / of_bytes_field / sample of the two fields (lib/gf2k/gf2_128.h:168-190, lib/algebra/fp_generic.h:344-383)
+inline void elt_to_bytes(int field, elt_t e, uint8_t out[16]) {
+  if (field != LFGPU_FIELD_GF2_128) e = fp_from_mont(e);
+  memcpy(out, &e, 16);
+}
+inline bool elt_of_bytes(int field, const uint8_t in[16], elt_t& e) {
+  memcpy(&e, in, 16);
+  if (field == LFGPU_FIELD_GF2_128) return true;  // every 128-bit string is an element
+  if (!h_fp_fits(e)) return false;
+  e = h_fp_to_mont(e);
+  return true;
+}
+template <class Fill>
+inline elt_t elt_sample(int field, Fill fill) {  // rejection sampling for Fp128 (exact_bits = 128: no masking)
+  for (;;) {
+    uint8_t b[16];
+    fill(b, 16);
+    elt_t e;
+    if (elt_of_bytes(field, b, e)) return e;
+  }
+}
+
 struct Ts {
   const lfgpu_transcript_ops* o;
   void* u;
+  int field = LFGPU_FIELD_GF2_128;
   void write_bytes(const uint8_t* d, size_t n) const { o->write_bytes(u, d, n); }
-  void write_elt(elt_t e) const { o->write_elt(u, (const uint8_t*)&e); }  // GF2_128 image = the 16 LE bytes
-  void write_array(const elt_t* e, size_t n) const { o->write_elt_array(u, (const uint8_t*)e, n); }
-  elt_t elt() const {  // GF2_128::sample (lib/gf2k/gf2_128.h:182-190)
-    elt_t e;
-    o->gen_bytes(u, (uint8_t*)&e, 16);
-    return e;
+  void write_elt(elt_t e) const {
+    uint8_t b[16];
+    elt_to_bytes(field, e, b);
+    o->write_elt(u, b);
+  }
+  void write_array(const elt_t* e, size_t n) const {
+    if (field == LFGPU_FIELD_GF2_128) {
+      o->write_elt_array(u, (const uint8_t*)e, n);
+      return;
+    }
+    std::vector<uint8_t> b(16 * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i) elt_to_bytes(field, e[i], &b[16 * i]);
+    o->write_elt_array(u, b.data(), n);
+  }
+  elt_t elt() const {
+    return elt_sample(field, [&](uint8_t* b, size_t n) { o->gen_bytes(u, b, n); });
   }
   size_t nat(size_t n) const {  // RandomEngine::nat (lib/random/random.h:57-87): rejection sampling under a bit mask
     size_t l = 0, mask = 0;
@@ -208,12 +241,15 @@ extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t le
   size_t fid, nv, nc, npub, sfb, nin, nl, nk;
   if (!num(&fid) || !num(&nv) || !num(&nc) || !num(&npub) || !num(&sfb) || !num(&nin) || !num(&nl) || !num(&nk))
     return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated header");
-  if (fid != 4) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "LFC1: field id %zu (only GF2_128 = 4 is supported by the ZK driver)", fid);
+  if (fid != LFGPU_FIELD_GF2_128 && fid != LFGPU_FIELD_FP128)
+    return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "LFC1: field id %zu (the ZK driver handles GF2_128 = 4 and Fp128 = 6)", fid);
+  const int field = (int)fid;
   if (nc != 1) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "LFC1: nc = %zu copies (logc must be 0)", nc);
   if (npub > nin || nv == 0 || nl == 0) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: inconsistent header");
   if (!need(16 * nk)) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated constant table");
   std::vector<elt_t> kvec(nk ? nk : 1);
-  memcpy(kvec.data(), b + pos, 16 * nk);  // GF2_128 of_bytes_field image: 16 little-endian bytes
+  for (size_t i = 0; i < nk; ++i)  // of_bytes_field: 16 little-endian bytes (Fp128: canonical value -> Montgomery)
+    if (!elt_of_bytes(field, b + pos + 16 * i, kvec[i])) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: constant %zu is not a field element", i);
   pos += 16 * nk;
   std::unique_ptr<lfgpu_circuit> C(new lfgpu_circuit());
   C->c = c;
@@ -238,7 +274,7 @@ extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t le
       g[t] = (u32)acc[0]; h0[t] = (u32)acc[1]; h1[t] = (u32)acc[2]; vi[t] = (u32)v[3];
     }
     lfgpu_circuit::Layer L{logw, nw, nq, nullptr};
-    LF_TRY(lfgpu_quad_upload(c, LFGPU_FIELD_GF2_128, nq, g.data(), h0.data(), h1.data(), vi.data(), nk, kvec.data(), nout, &L.q));
+    LF_TRY(lfgpu_quad_upload(c, field, nq, g.data(), h0.data(), h1.data(), vi.data(), nk, kvec.data(), nout, &L.q));
     C->layers.push_back(L);
     nterms += nq;
     nout = nw;
@@ -246,7 +282,7 @@ extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t le
   if (!need(32) || pos + 32 != len) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: bad trailer");
   if (nout != nin) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: input layer width %zu != ninputs %zu", nout, nin);
   lfgpu_circuit_info& I = C->info;
-  I.field = LFGPU_FIELD_GF2_128;
+  I.field = field;
   I.nv = nv; I.nc = nc; I.npub_in = npub; I.subfield_boundary = sfb; I.ninputs = nin; I.nl = nl; I.nterms = nterms;
   I.logv = lf_log2(nv);
   memcpy(I.id, b + pos, 32);
@@ -452,8 +488,8 @@ int build_constraints(lfgpu_ctx* c, const lfgpu_circuit* C, const HostField& F, 
     pi += layer_size(logw);
   }
   const elt_t alpha = ts.elt();
-  out.a.push_back({ci, pi - 3, F.one});  // input_constraint: the claims of the input layer
-  out.a.push_back({ci, pi - 2, alpha});
+  out.a.push_back({ci, pi - 3, F.sub(elt_t{0, 0}, F.one)});  // input_constraint: -1, -alpha on the input layer's claim pads
+  out.a.push_back({ci, pi - 2, F.sub(elt_t{0, 0}, alpha)});
   out.n = ci + 1;
   // EQ table over the inputs on the device: public part folded into b, private part = dense block of A
   out.eq_in.assign(I.ninputs, elt_t{0, 0});
@@ -461,7 +497,7 @@ int build_constraints(lfgpu_ctx* c, const lfgpu_circuit* C, const HostField& F, 
   void* d_eq = nullptr;
   LF_TRY(lf_scratch3(c, I.ninputs * 16, &d_eq));
   const uint64_t al[2] = {alpha.lo, alpha.hi};
-  LF_TRY(lfgpu_raw_eq2(c, LFGPU_FIELD_GF2_128, logn, I.ninputs, gh[0].data(), gh[1].data(), al, d_eq));
+  LF_TRY(lfgpu_raw_eq2(c, I.field, logn, I.ninputs, gh[0].data(), gh[1].data(), al, d_eq));
   LF_HIP(c, hipMemcpyAsync(out.eq_in.data(), d_eq, I.ninputs * 16, hipMemcpyDeviceToHost, c->stream));
   LF_HIP(c, hipStreamSynchronize(c->stream));
   const auto& P = proof[nl - 1];
@@ -473,20 +509,22 @@ int build_constraints(lfgpu_ctx* c, const lfgpu_circuit* C, const HostField& F, 
 
 // LigeroCommon::inner_product_vector (lib/ligero/ligero_param.h:382-421): A[nwqrow][w] from the linear constraints
 // (sparse terms + the dense private-input block), alphal, the quadratic constraints and alphaq
-void inner_product_vector(std::vector<elt_t>& A, const lfgpu_ligero_param& p, const ConstraintSet& cs, size_t npub, size_t n_witness,
-                          const std::vector<elt_t>& alphal, const std::vector<size_t>& lqc, const std::vector<elt_t>& alphaq) {
+void inner_product_vector(const HostField& F, std::vector<elt_t>& A, const lfgpu_ligero_param& p, const ConstraintSet& cs, size_t npub,
+                          size_t n_witness, const std::vector<elt_t>& alphal, const std::vector<size_t>& lqc, const std::vector<elt_t>& alphaq) {
   A.assign(p.nwqrow * p.w, elt_t{0, 0});
   const elt_t ad = alphal[cs.n - 1];
-  for (size_t w = 0; w < n_witness; ++w) A[w] = h_gf_mul(ad, cs.eq_in[npub + w]);
-  for (const LinTerm& t : cs.a) A[t.w] = gf_add(A[t.w], h_gf_mul(t.k, alphal[t.c]));
+  for (size_t w = 0; w < n_witness; ++w) A[w] = F.mul(ad, cs.eq_in[npub + w]);
+  for (const LinTerm& t : cs.a) A[t.w] = F.add(A[t.w], F.mul(t.k, alphal[t.c]));
+  // quadratic constraints W[x] * W[y] = W[z] live in their own rows: copy constraints tie them to the witness rows
+  // (A[copy] += aq, A[original] -= aq)
   const size_t base = p.nwrow * p.w;
   const size_t Ax = base, Ay = base + p.nqtriples * p.w, Az = base + 2 * p.nqtriples * p.w;
   for (size_t iw = 0; iw < p.nq; ++iw) {
     const size_t off[3] = {Ax + iw, Ay + iw, Az + iw};
     for (int j = 0; j < 3; ++j) {
       const elt_t aq = alphaq[3 * iw + j];
-      A[off[j]] = gf_add(A[off[j]], aq);
-      A[lqc[3 * iw + j]] = gf_add(A[lqc[3 * iw + j]], aq);
+      A[off[j]] = F.add(A[off[j]], aq);
+      A[lqc[3 * iw + j]] = F.sub(A[lqc[3 * iw + j]], aq);
     }
   }
 }
@@ -502,10 +540,12 @@ extern "C" int lfgpu_zk_prover_new(lfgpu_ctx* c, const lfgpu_circuit* C, size_t 
   zk->n_witness = C->info.ninputs - C->info.npub_in;
   for (const auto& l : C->layers) zk->pad_size += layer_size(l.logw);
   // ZkProof: LigeroParam(n_witness + pad_size, nl quadratic constraints, rate, nreq[, block_enc]) (zk_proof.h:63-76)
-  LF_TRY(lfgpu_ligero_param_init(&zk->param, LFGPU_FIELD_GF2_128, 4, zk->n_witness + zk->pad_size, C->info.nl, rateinv, nreq, block_enc));
-  const GfHostCtx* g = lf_gf_ctx(c, 4);
-  if (!g) return LFGPU_ERR_ARG;
-  build_subfield_solver(zk.get(), g);
+  LF_TRY(lfgpu_ligero_param_init(&zk->param, C->info.field, 4, zk->n_witness + zk->pad_size, C->info.nl, rateinv, nreq, block_enc));
+  if (C->info.field == LFGPU_FIELD_GF2_128) {
+    const GfHostCtx* g = lf_gf_ctx(c, 4);
+    if (!g) return LFGPU_ERR_ARG;
+    build_subfield_solver(zk.get(), g);
+  }
   LF_HIP(c, hipSetDevice(c->device));
   zk->d_in.assign(C->layers.size(), nullptr);
   for (size_t l = 0; l < C->layers.size(); ++l)
@@ -528,10 +568,10 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
   lfgpu_ctx* c = zk->c;
   const lfgpu_circuit* C = zk->C;
   const size_t nl = C->layers.size();
-  auto draw = [&]() {
-    elt_t e;
-    rng(rng_user, (uint8_t*)&e, 16);
-    return e;
+  const int field = C->info.field;
+  const HostField F(c, field);
+  auto draw = [&]() {  // RandomEngine::elt = Field::sample
+    return elt_sample(field, [&](uint8_t* b, size_t n) { rng(rng_user, b, n); });
   };
   // witness = private inputs || pad; fill_pad draws, per layer: (t0, t2) for hand 0 then hand 1 of every round,
   // then wc0, wc1 and stores wc0*wc1 (zk_prover.h:152-188, logc = 0)
@@ -557,7 +597,7 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
     P.wc[1] = draw();
     Wv[w++] = P.wc[0];
     Wv[w++] = P.wc[1];
-    Wv[w++] = h_gf_mul(P.wc[0], P.wc[1]);
+    Wv[w++] = F.mul(P.wc[0], P.wc[1]);
     const size_t cp = pi + 4 * logw;  // setup_lqc (zk_common.h:149-160): claim_pad(0..2)
     zk->lqc[3 * ly] = cp;
     zk->lqc[3 * ly + 1] = cp + 1;
@@ -571,7 +611,7 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
     zk->lp = nullptr;
   }
   zk->have_proof = false;
-  LF_TRY(lfgpu_ligero_commit(c, LFGPU_FIELD_GF2_128, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), rng, rng_user, zk->root, &zk->lp));
+  LF_TRY(lfgpu_ligero_commit(c, field, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), rng, rng_user, zk->root, &zk->lp));
   ts->write_bytes(ts->user, zk->root, 32);  // LigeroTranscript::write_commitment
   if (root_out) memcpy(root_out, zk->root, 32);
   zk->ms[0] = now_ms() - t0;
@@ -587,8 +627,8 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
   const lfgpu_circuit_info& I = C->info;
   const size_t nl = C->layers.size();
   const elt_t* W = (const elt_t*)h_W;
-  const HostField F(c, LFGPU_FIELD_GF2_128);
-  const Ts ts{tso, tso->user};
+  const HostField F(c, I.field);
+  const Ts ts{tso, tso->user, I.field};
   *ok = 0;
   zk->have_proof = false;
   LF_HIP(c, hipSetDevice(c->device));
@@ -608,7 +648,7 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
     void* u;
     ~CloneGuard() { o->free_clone(u); }
   } cg{tso, cl};
-  const Ts tst{tso, cl};
+  const Ts tst{tso, cl, I.field};
 
   // eval_circuit (prover_layers.h:52-104): layer inputs stay resident for the sumcheck
   double t0 = now_ms();
@@ -692,7 +732,7 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
     for (auto& e : alphal) e = ts.elt();
     for (auto& e : alphaq) e = ts.elt();
     std::vector<elt_t> A;
-    inner_product_vector(A, p, cs, zk->npub, zk->n_witness, alphal, zk->lqc, alphaq);
+    inner_product_vector(F, A, p, cs, zk->npub, zk->n_witness, alphal, zk->lqc, alphaq);
     zk->y_dot.assign(p.dblock, elt_t{0, 0});
     tq[2] = now_ms();
     LF_TRY(lfgpu_ligero_dot_proof(zk->lp, A.data(), zk->y_dot.data()));
@@ -730,7 +770,17 @@ extern "C" int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, siz
   if (!zk || !nbytes) return LFGPU_ERR_ARG;
   if (!zk->have_proof) return lf_fail(zk->c, LFGPU_ERR_ARG, "zk_proof_write: no proof");
   std::vector<uint8_t> o;
-  auto pute = [&](elt_t e) { o.insert(o.end(), (const uint8_t*)&e, (const uint8_t*)&e + 16); };
+  const int field = zk->C->info.field;
+  auto pute = [&](elt_t e) {
+    uint8_t b[16];
+    elt_to_bytes(field, e, b);
+    o.insert(o.end(), b, b + 16);
+  };
+  auto in_subfield = [&](elt_t e) {  // Fp128: the subfield is the field (fp_generic.h:284)
+    if (field != LFGPU_FIELD_GF2_128) return true;
+    const elt_t res = solve_subfield(zk, e).first;
+    return (res.lo | res.hi) == 0;
+  };
   auto putsz = [&](size_t g) {  // write_size: 4 bytes LE (zk_proof.h:211-216)
     for (int i = 0; i < 4; ++i) o.push_back((uint8_t)(g >> (8 * i)));
   };
@@ -759,17 +809,16 @@ extern "C" int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, siz
   while (ci < nreq_elts) {
     size_t runlen = 0;
     while (ci + runlen < nreq_elts && runlen < kMaxRunLen) {
-      const elt_t res = solve_subfield(zk, zk->req[ci + runlen]).first;
-      if (((res.lo | res.hi) == 0) != subfield_run) break;
+      if (in_subfield(zk->req[ci + runlen]) != subfield_run) break;
       ++runlen;
     }
     putsz(runlen);
     for (size_t i = ci; i < ci + runlen; ++i) {
-      if (subfield_run) {
+      if (subfield_run && field == LFGPU_FIELD_GF2_128) {
         const u32 u = solve_subfield(zk, zk->req[i]).second;  // to_bytes_subfield: 2 bytes LE
         o.push_back((uint8_t)u);
         o.push_back((uint8_t)(u >> 8));
-      } else {
+      } else {  // full-field run, or Fp128 where to_bytes_subfield == to_bytes_field
         pute(zk->req[i]);
       }
     }
@@ -826,9 +875,11 @@ struct Reader {
     left -= n;
     return r;
   }
+  int field = LFGPU_FIELD_GF2_128;
+  bool bad = false;  // an of_bytes_field failed (Fp128: value >= p)
   elt_t elt() {
     elt_t e;
-    memcpy(&e, next(16), 16);  // GF2_128::of_bytes_field: every 16-byte string is an element
+    if (!elt_of_bytes(field, next(16), e)) bad = true;
     return e;
   }
   size_t size4() {
@@ -839,7 +890,9 @@ struct Reader {
 
 // ZkProof::read; false on underflow or inconsistent sizes (the reference returns false as well)
 bool parse_proof(const lfgpu_circuit* C, const lfgpu_ligero_param& p, const GfHostCtx* g, const uint8_t* buf, size_t len, ParsedProof& pr) {
-  Reader rd{buf, len};
+  const int field = C->info.field;
+  const size_t sub_bytes = field == LFGPU_FIELD_GF2_128 ? 2 : 16;
+  Reader rd{buf, len, field};
   if (!rd.have(32)) return false;
   memcpy(pr.root, rd.next(32), 32);
   pr.sc.assign(C->layers.size(), {});
@@ -877,8 +930,12 @@ bool parse_proof(const lfgpu_circuit* C, const lfgpu_ligero_param& p, const GfHo
     const size_t runlen = rd.size4();
     if (runlen >= kMaxRunLen || ci + runlen > total) return false;
     if (subfield_run) {
-      if (!rd.have(runlen * 2)) return false;
+      if (!rd.have(runlen * sub_bytes)) return false;
       for (size_t i = ci; i < ci + runlen; ++i) {  // of_bytes_subfield: of_scalar(u) = sum_i bit_i(u) beta_i
+        if (field != LFGPU_FIELD_GF2_128) {  // Fp128: of_bytes_subfield == of_bytes_field
+          pr.req[i] = rd.elt();
+          continue;
+        }
         const uint8_t* b = rd.next(2);
         const u32 u = (u32)b[0] | (u32)b[1] << 8;
         elt_t e{0, 0};
@@ -899,7 +956,7 @@ bool parse_proof(const lfgpu_circuit* C, const lfgpu_ligero_param& p, const GfHo
   pr.npath = sz;
   pr.path.assign(rd.p, rd.p + sz * 32);
   rd.next(sz * 32);
-  return true;
+  return !rd.bad;
 }
 
 void hash2(const uint8_t* a, const uint8_t* b, uint8_t out[32]) {  // Digest::hash2: SHA-256(left || right)
@@ -959,7 +1016,8 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   size_t pad_size = 0;
   for (const auto& l : C->layers) pad_size += layer_size(l.logw);
   lfgpu_ligero_param p{};
-  LF_TRY(lfgpu_ligero_param_init(&p, LFGPU_FIELD_GF2_128, 4, n_witness + pad_size, nl, rateinv, nreq, block_enc));
+  const int field = I.field;
+  LF_TRY(lfgpu_ligero_param_init(&p, field, 4, n_witness + pad_size, nl, rateinv, nreq, block_enc));
   const GfHostCtx* g = lf_gf_ctx(c, 4);
   if (!g) return LFGPU_ERR_ARG;
   static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
@@ -968,8 +1026,8 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   if (!parse_proof(C, p, g, proof, proof_len, pr)) return fail(1);
   tv[1] = now_ms();
   LF_HIP(c, hipSetDevice(c->device));
-  const HostField F(c, LFGPU_FIELD_GF2_128);
-  const Ts ts{tso, tso->user};
+  const HostField F(c, field);
+  const Ts ts{tso, tso->user, field};
   const elt_t* pub = (const elt_t*)h_pub;
 
   // recv_commitment, initialize_sumcheck_fiat_shamir
@@ -1020,8 +1078,9 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
       Sha256 s;
       s.update(&pr.nonces[32 * r], 32);
       for (size_t i = 0; i < p.nrow; ++i) {
-        const elt_t e = req_at(i, r);
-        s.update((const uint8_t*)&e, 16);
+        uint8_t eb[16];
+        elt_to_bytes(field, req_at(i, r), eb);
+        s.update(eb, 16);
       }
       s.digest(&leaves[32 * r]);
     }
@@ -1031,7 +1090,7 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   tv[3] = now_ms();
   // device: rows [0, nwqrow) = [0^r | A_i] extended block -> block_enc, rows nwqrow.. = y_ldt, y_dot, y_quad
   std::vector<elt_t> A;
-  inner_product_vector(A, p, cs, npub, n_witness, alphal, lqc, alphaq);
+  inner_product_vector(F, A, p, cs, npub, n_witness, alphal, lqc, alphaq);
   const size_t nrows_dev = p.nwqrow + 3, ld = p.block_enc;
   void* dT = nullptr;
   LF_TRY(lf_scratch(c, (nrows_dev * ld + (size_t)nrows_dev * p.nreq) * 16 + 256, &dT));
@@ -1047,8 +1106,8 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
     LF_HIP(c, hipMemcpyAsync(yq + p.block, pr.y_q2.data(), (p.dblock - p.block) * 16, hipMemcpyHostToDevice, c->stream));
     LF_HIP(c, hipStreamSynchronize(c->stream));
   }
-  LF_TRY(lfgpu_gf2128_rs_encode_rows(c, 4, p.nwqrow + 1, p.block, p.block_enc, d_T, ld));                       // A rows and y_ldt
-  LF_TRY(lfgpu_gf2128_rs_encode_rows(c, 4, 2, p.dblock, p.block_enc, d_T + (p.nwqrow + 1) * ld, ld));            // y_dot, y_quad
+  LF_TRY(lf_rs_rows(c, field, 4, p.nwqrow + 1, p.block, p.block_enc, d_T, ld));                       // A rows and y_ldt
+  LF_TRY(lf_rs_rows(c, field, 4, 2, p.dblock, p.block_enc, d_T + (p.nwqrow + 1) * ld, ld));            // y_dot, y_quad
   LF_TRY(lfgpu_gather_columns(c, nrows_dev, ld, p.dblock, d_T, idx.data(), p.nreq, d_req));
   std::vector<elt_t> ext(nrows_dev * p.nreq);
   LF_HIP(c, hipMemcpyAsync(ext.data(), d_req, ext.size() * 16, hipMemcpyDeviceToHost, c->stream));
@@ -1058,18 +1117,18 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
 
   for (size_t j = 0; j < p.nreq; ++j) {  // low_degree_check
     elt_t yc = req_at(p.ildt, j);
-    for (size_t i = 0; i < p.nwqrow; ++i) yc = gf_add(yc, h_gf_mul(u_ldt[i], req_at(i + p.iw, j)));
+    for (size_t i = 0; i < p.nwqrow; ++i) yc = F.add(yc, F.mul(u_ldt[i], req_at(i + p.iw, j)));
     if (!elt_eq(yc, ext_at(p.nwqrow, j))) return fail(3);
   }
   for (size_t j = 0; j < p.nreq; ++j) {  // dot_check
     elt_t yc = req_at(p.idot, j);
-    for (size_t i = 0; i < p.nwqrow; ++i) yc = gf_add(yc, h_gf_mul(ext_at(i, j), req_at(i + p.iw, j)));
+    for (size_t i = 0; i < p.nwqrow; ++i) yc = F.add(yc, F.mul(ext_at(i, j), req_at(i + p.iw, j)));
     if (!elt_eq(yc, ext_at(p.nwqrow + 1, j))) return fail(4);
   }
   {  // the putative value of the inner product
     elt_t want{0, 0}, got{0, 0};
-    for (size_t k = 0; k < nconstraints; ++k) want = gf_add(want, h_gf_mul(cs.b[k], alphal[k]));
-    for (size_t j = 0; j < p.w; ++j) got = gf_add(got, pr.y_dot[p.r + j]);
+    for (size_t k = 0; k < nconstraints; ++k) want = F.add(want, F.mul(cs.b[k], alphal[k]));
+    for (size_t j = 0; j < p.w; ++j) got = F.add(got, pr.y_dot[p.r + j]);
     if (!elt_eq(want, got)) return fail(5);
   }
   {  // quadratic_check
@@ -1077,8 +1136,8 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
     for (size_t j = 0; j < p.nreq; ++j) {
       elt_t yc = req_at(p.iquad, j);
       for (size_t i = 0; i < p.nqtriples; ++i) {
-        const elt_t tmp = gf_add(req_at(iqz + i, j), h_gf_mul(req_at(iqx + i, j), req_at(iqy + i, j)));
-        yc = gf_add(yc, h_gf_mul(u_quad[i], tmp));
+        const elt_t tmp = F.sub(req_at(iqz + i, j), F.mul(req_at(iqx + i, j), req_at(iqy + i, j)));  // z - x*y
+        yc = F.add(yc, F.mul(u_quad[i], tmp));
       }
       if (!elt_eq(yc, ext_at(p.nwqrow + 2, j))) return fail(6);
     }

@@ -61,8 +61,29 @@ def variant(nb=1, npub=9, sfb=777):
         print(dst, info)
 
 
+def fp128(nb=1):
+    """the same generator compiled over Fp128 (oracle/_ref/gen_flatsha_fp): ZK over the prime field"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/gen_flatsha_fp"])
+    with tempfile.TemporaryDirectory() as td:
+        pre = os.path.join(td, "x")
+        info = json.loads(subprocess.check_output([GEN + "_fp", str(nb), pre]).decode())
+        for ext in (".lfc1", ".w", ".zkproof"):
+            data = open(pre + ext, "rb").read()
+            dst = os.path.join(OUT, "flatsha_fp_nb%d%s.xz" % (nb, ext))
+            with open(dst, "wb") as f:
+                f.write(lzma.compress(data, preset=9 | lzma.PRESET_EXTREME))
+            print(dst, os.path.getsize(dst))
+        wire = open(pre + ".zkwire", "rb").read()
+        info.update(field="Fp128", zk_wire_bytes=len(wire), zk_wire_sha256=hashlib.sha256(wire).hexdigest())
+        with open(os.path.join(OUT, "flatsha_fp_nb%d.json" % nb), "w") as f:
+            json.dump(info, f)
+        print(info)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:2] == ["variant"]:
+    if sys.argv[1:2] == ["fp128"]:
+        fp128()
+    elif sys.argv[1:2] == ["variant"]:
         variant()
     else:
         main()

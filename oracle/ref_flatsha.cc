@@ -26,6 +26,9 @@
 #include "circuits/sha/flatsha256_witness.h"
 #include "circuits/sha/sha256_test_values.h"
 #include "gf2k/gf2_128.h"
+#include "algebra/convolution.h"
+#include "algebra/fp_p128.h"
+#include "algebra/reed_solomon.h"
 #include "proto/circuit_io.h"
 #include "proto/circuit_writer.h"
 #include "random/transcript.h"
@@ -54,7 +57,16 @@ class LcgRng : public RandomEngine {
  private:
   uint64_t s_;
 };
+#ifdef REF_FP128  // same generator over the prime field Fp128 (lib/algebra/fp_p128.h), as lib/zk/zk_test.cc:252-330 sets it up
+using F128 = Fp128<>;
+static const FieldID kFieldId = FP128_ID;
+using FftConv = FFTConvolutionFactory<F128>;
+using RSFactory = ReedSolomonFactory<F128, FftConv>;
+#else
 using F128 = GF2_128<>;
+static const FieldID kFieldId = GF2_128_ID;
+using RSFactory = LCH14ReedSolomonFactory<F128>;
+#endif
 constexpr size_t kPlucker = 2;
 
 static void dump(const std::string& path, const void* p, size_t n) {
@@ -131,7 +143,7 @@ int main(int argc, char** argv) {
 
   // ---- serialize
   std::vector<uint8_t> bytes;
-  CircuitWriter<F128> cw(Fs, GF2_128_ID);
+  CircuitWriter<F128> cw(Fs, kFieldId);
   cw.to_bytes(*C, bytes);
   dump(prefix + ".lfc1", bytes.data(), bytes.size());
   dump(prefix + ".w", W.v_.data(), 16 * C->ninputs);
@@ -175,8 +187,12 @@ int main(int argc, char** argv) {
   double zk_commit_ms = 0, zk_prove_ms = 0, zk_verify_ms = 0;
   size_t z_block_enc = 0, z_nrow = 0, z_block = 0, z_dblock = 0, z_nw = 0;
   {
-    using RSFactory = LCH14ReedSolomonFactory<F128>;
+#ifdef REF_FP128
+    const FftConv fft(Fs, Fs.of_string("164956748514267535023998284330560247862"), 1ull << 32);
+    const RSFactory rsf(fft, Fs);
+#else
     const RSFactory rsf(Fs);
+#endif
     Transcript tp((const uint8_t*)"test", 4);
     LcgRng rng(100);
     ZkProof<F128> zk(*C, 7, 132);

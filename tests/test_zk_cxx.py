@@ -186,9 +186,15 @@ def _subfield_solver():
     return solve
 
 
-def wire_from_components(comp, layers_logw, p):
+def wire_from_components(comp, layers_logw, p, fp128=False):
     """ZkProof::write (lib/zk/zk_proof.h:90-185) from the component dump of oracle/ref_flatsha.cc (.zkproof)"""
-    solve = _subfield_solver()
+    if fp128:  # Fp128: every element is "in the subfield" and to_bytes_subfield is the full 16-byte image
+        def solve(e):
+            return e
+        sub_bytes = 16
+    else:
+        solve = _subfield_solver()
+        sub_bytes = 2
     pos = 0
 
     def take(n):
@@ -214,7 +220,7 @@ def wire_from_components(comp, layers_logw, p):
             run += 1
         out += run.to_bytes(4, "little")
         for e in elts[ci:ci + run]:
-            out += solve(e).to_bytes(2, "little") if sub else e.to_bytes(16, "little")
+            out += solve(e).to_bytes(sub_bytes, "little") if sub else e.to_bytes(16, "little")
         ci += run
         sub = not sub
     npath = int.from_bytes(take(8), "little")
@@ -321,6 +327,46 @@ def test_zk_public_inputs_and_subfield_boundary_match_reference():
     pub_bad[3, 0] ^= np.uint64(1)  # a different public input: rejected
     tv = G.pkg.FsTranscript(b"test")
     assert G.pkg.zk_verify(gpu, circ, wire, pub_bad, tv)[0] is False
+    tv.close()
+    zk.close()
+    circ.close()
+
+
+@pytest.mark.gpu
+def test_zk_over_fp128_matches_reference():
+    """The same driver over the prime field Fp128 (field id 6): the flatsha256 circuit compiled by the reference over
+    Fp128<> with ReedSolomonFactory<Fp128, FFTConvolutionFactory> (as lib/zk/zk_test.cc:252-330 sets ZK up for that
+    field), LCG RandomEngine, transcript "test".  Exercises rejection sampling, Montgomery <-> wire conversions, the
+    signed constraint algebra, the Fp128 sumcheck / Ligero kernels end to end, and the verifier."""
+    import gpu_util as G
+    import ligero_fixture as lf
+    raw = lzma.decompress(open(os.path.join(GOLD, "flatsha_fp_nb1.lfc1.xz"), "rb").read())
+    W = np.frombuffer(lzma.decompress(open(os.path.join(GOLD, "flatsha_fp_nb1.w.xz"), "rb").read()), dtype=np.uint64).reshape(-1, 2).copy()
+    comp = lzma.decompress(open(os.path.join(GOLD, "flatsha_fp_nb1.zkproof.xz"), "rb").read())
+    info = json.load(open(os.path.join(GOLD, "flatsha_fp_nb1.json")))
+    gpu = G.gpu()
+    circ = G.pkg.Circuit(gpu, raw)
+    assert (circ.info.field, circ.info.nl, circ.info.nterms) == (G.pkg.FIELD_FP128, info["nl"], info["nterms"])
+    zk = G.pkg.ZkProver(gpu, circ, 7, 132)
+    assert (zk.param.nw, zk.param.block_enc, zk.param.nrow) == (info["zk_nw"], info["zk_block_enc"], info["zk_nrow"])
+    logws = [circ.layer(i)["logw"] for i in range(circ.info.nl)]
+    ref_wire = wire_from_components(comp, logws, zk.param, fp128=True)
+    assert len(ref_wire) == info["zk_wire_bytes"] and hashlib.sha256(ref_wire).hexdigest() == info["zk_wire_sha256"]
+    ts = G.pkg.FsTranscript(b"test")
+    root = zk.commit(W, lf.LcgRng(100).bytes, ts)
+    assert root == comp[:32]
+    assert zk.prove(W, ts)
+    wire = zk.wire()
+    ts.close()
+    assert wire == ref_wire
+    for w in (ref_wire, wire):
+        tv = G.pkg.FsTranscript(b"test")
+        assert G.pkg.zk_verify(gpu, circ, w, W[:0], tv) == (True, "ok")
+        tv.close()
+    bad = bytearray(wire)
+    bad[32 + 16 * 5 + 3] ^= 1
+    tv = G.pkg.FsTranscript(b"test")
+    assert G.pkg.zk_verify(gpu, circ, bytes(bad), W[:0], tv)[0] is False
     tv.close()
     zk.close()
     circ.close()
