@@ -16,16 +16,18 @@ import ligero_fixture as lf
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 nb = int(args[0]) if args else 32
 reps = int(args[1]) if len(args) > 1 else 5
+FP = "--fp128" in sys.argv  # the circuit compiled over Fp128 (fixture for 1 block only)
+stem = "flatsha_fp_nb%d" % nb if FP else "flatsha_nb%d" % nb
 gold = os.path.join(ROOT, "tests", "golden")
-raw = lzma.decompress(open(os.path.join(gold, "flatsha_nb%d.lfc1.xz" % nb), "rb").read())
-W = np.frombuffer(lzma.decompress(open(os.path.join(gold, "flatsha_nb%d.w.xz" % nb), "rb").read()), dtype=np.uint64).reshape(-1, 2).copy()
-info = json.load(open(os.path.join(gold, "flatsha_nb%d.json" % nb)))
+raw = lzma.decompress(open(os.path.join(gold, stem + ".lfc1.xz"), "rb").read())
+W = np.frombuffer(lzma.decompress(open(os.path.join(gold, stem + ".w.xz"), "rb").read()), dtype=np.uint64).reshape(-1, 2).copy()
+info = json.load(open(os.path.join(gold, stem + ".json")))
 pkg, gpu = G.pkg, G.gpu()
 t0 = time.perf_counter()
 circ = pkg.Circuit(gpu, raw)
 t_load = (time.perf_counter() - t0) * 1e3
 zk = pkg.ZkProver(gpu, circ, 7, 132)
-res = {"nb": nb, "shape": {k: info[k] for k in ("zk_nw", "zk_block_enc", "zk_nrow", "nterms", "round_hands")},
+res = {"nb": nb, "field": "Fp128" if FP else "GF2_128", "shape": {k: info[k] for k in ("zk_nw", "zk_block_enc", "zk_nrow", "nterms", "round_hands")},
        "circuit_parse_upload_ms": t_load}
 
 # 1. parity: same RandomEngine and transcript seed as the reference run that made the fixtures
@@ -88,7 +90,7 @@ if "--harness" in sys.argv:
         zp.lp.close()
     res["gpu_python_harness_total_ms"] = (t1 - t0) * 1e3
 
-gen = os.path.join(ROOT, "oracle", "_ref", "gen_flatsha")
+gen = os.path.join(ROOT, "oracle", "_ref", "gen_flatsha_fp" if FP else "gen_flatsha")
 if os.path.exists(gen):
     with tempfile.TemporaryDirectory() as td_:
         r = json.loads(subprocess.check_output([gen, str(nb), os.path.join(td_, "x")]).decode())
