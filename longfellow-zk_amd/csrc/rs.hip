@@ -115,6 +115,57 @@ __global__ __launch_bounds__(RS_THREADS) void gf_rs_rows_kernel(RsPlan p, elt_t*
   }
 }
 
+// ---- rows larger than LDS (2^l > 4096): the same op list, one launch per op over all rows, coefficients in a
+// device work buffer Cc[row][2^l]; the further cosets go through the batched LCH14 FFT (bit-sliced for >= 32 rows).
+__global__ __launch_bounds__(256) void gf_rs_big_load_kernel(u32 n, u32 fftn, const elt_t* __restrict__ T, size_t ld, elt_t* __restrict__ Cc) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= fftn) return;
+  const size_t r = blockIdx.y;
+  st16(&Cc[r * fftn + i], i < n ? ld16(&T[r * ld + i]) : elt_zero());
+}
+__global__ __launch_bounds__(256) void gf_rs_big_op_kernel(RsOp op, const elt_t* __restrict__ twp, u32 fftn, elt_t* __restrict__ Cc) {
+  elt_t* B = Cc + (size_t)blockIdx.y * fftn;
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  const u32 s = 1u << op.i;
+  u32 i0, i1;
+  elt_t tw;
+  if (op.kind <= OP_DIAG) {
+    const u32 uv = op.lo + t;
+    if (uv >= op.hi) return;
+    i0 = op.base + uv;
+    i1 = i0 + s;
+    tw = ld16(&twp[op.tw]);
+  } else {
+    if (t >= (1u << (op.lo - 1))) return;
+    const u32 v = t & (s - 1), u = t >> op.i;
+    i0 = op.base + (u << (op.i + 1)) + v;
+    i1 = i0 + s;
+    tw = ld16(&twp[op.tw + u]);
+  }
+  elt_t b0 = ld16(&B[i0]), b1 = ld16(&B[i1]);
+  if (op.kind == OP_FWD || op.kind == OP_FFT_STAGE) {  // lch14.h:219-223
+    b0 = gf_add(b0, gf_mul(tw, b1));
+    b1 = gf_add(b1, b0);
+  } else if (op.kind == OP_BWD || op.kind == OP_IFFT_STAGE) {  // :225-229
+    b1 = gf_add(b1, b0);
+    b0 = gf_add(b0, gf_mul(tw, b1));
+  } else {  // diag :232-237
+    const elt_t x = b1;
+    b1 = gf_add(b1, b0);
+    b0 = gf_add(b0, gf_mul(tw, x));
+  }
+  st16(&B[i0], b0);
+  st16(&B[i1], b1);
+}
+// evaluations n..top of the first coset out to the rows; coefficients n..fftn back to zero
+__global__ __launch_bounds__(256) void gf_rs_big_store_kernel(u32 n, u32 top, u32 fftn, elt_t* __restrict__ T, size_t ld, elt_t* __restrict__ Cc) {
+  const u32 i = n + blockIdx.x * 256 + threadIdx.x;
+  if (i >= fftn) return;
+  const size_t r = blockIdx.y;
+  if (i < top) st16(&T[r * ld + i], ld16(&Cc[r * fftn + i]));
+  st16(&Cc[r * fftn + i], elt_zero());
+}
+
 // ---- host: unroll bidir_recur (lch14.h:185-217) into ops
 struct PlanBuilder {
   const GfHostCtx* g;
@@ -156,6 +207,56 @@ struct PlanBuilder {
 };
 
 
+extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx*, int, int, size_t, unsigned, uint64_t, void*, size_t);
+
+static int gf_rs_rows_big(lfgpu_ctx* c, const GfHostCtx* g, int k, size_t nrow, size_t n, size_t m, elt_t* T, size_t ld, unsigned l) {
+  if ((size_t)1 << g->sub_bits < ((size_t)1 << l)) return lf_fail(c, LFGPU_ERR_ARG, "gf2128_rs_encode_rows: 2^l exceeds the subfield of GF2_128<%d>", k);
+  const u32 fftn = 1u << l;
+  // op list + twiddles of the bidirectional transform (host copy: one launch per op)
+  char kb[96];
+  snprintf(kb, sizeof(kb), "rsbig:%d:%zu", k, n);
+  const std::string key(kb);
+  void* dtw = nullptr;
+  auto it = c->blobs.find(key);
+  if (it == c->blobs.end()) {
+    PlanBuilder pb{g, {}, {}};
+    pb.bidir(l, 0, (u32)n, 0);
+    if (pb.tw.empty()) pb.tw.push_back(elt_t{0, 0});
+    LF_TRY(lf_table(c, key + ":tw", pb.tw.data(), pb.tw.size() * 16, &dtw));
+    c->blobs[key] = std::string((const char*)pb.ops.data(), pb.ops.size() * sizeof(RsOp));
+    it = c->blobs.find(key);
+  } else if (!lf_table_lookup(c, key + ":tw", &dtw)) {
+    return lf_fail(c, LFGPU_ERR_ASSERT, "gf2128_rs_encode_rows: plan cache");
+  }
+  const RsOp* ops = (const RsOp*)it->second.data();
+  const size_t nops = it->second.size() / sizeof(RsOp);
+  u32 ncoset = 1;
+  while (((size_t)ncoset << l) < m) ++ncoset;
+  void* sc = nullptr;
+  LF_TRY(lf_scratch2(c, (ncoset > 1 ? 2 : 1) * nrow * fftn * 16, &sc));  // scratch2: the batched FFT below takes `scratch`
+  elt_t* Cc = (elt_t*)sc;
+  elt_t* Wk = Cc + nrow * fftn;
+  const dim3 gfull((fftn + 255) / 256, (u32)nrow);
+  hipLaunchKernelGGL(gf_rs_big_load_kernel, gfull, dim3(256), 0, c->stream, (u32)n, fftn, (const elt_t*)T, ld, Cc);
+  for (size_t o = 0; o < nops; ++o) {
+    const RsOp op = ops[o];
+    const u32 work = op.kind <= OP_DIAG ? (op.hi > op.lo ? op.hi - op.lo : 0) : (1u << (op.lo - 1));
+    if (!work) continue;
+    hipLaunchKernelGGL(gf_rs_big_op_kernel, dim3((work + 255) / 256, (u32)nrow), dim3(256), 0, c->stream, op, (const elt_t*)dtw, fftn, Cc);
+  }
+  const u32 top = m < fftn ? (u32)m : fftn;
+  if (n < fftn)
+    hipLaunchKernelGGL(gf_rs_big_store_kernel, dim3((fftn - (u32)n + 255) / 256, (u32)nrow), dim3(256), 0, c->stream, (u32)n, top, fftn, T, ld, Cc);
+  LF_HIP(c, hipGetLastError());
+  for (u32 cs = 1; cs < ncoset; ++cs) {  // further cosets: FFT of the coefficients with coset offset cs * 2^l
+    LF_HIP(c, hipMemcpyAsync(Wk, Cc, nrow * fftn * 16, hipMemcpyDeviceToDevice, c->stream));
+    LF_TRY(lfgpu_gf2128_lch14_fft(c, k, 0, nrow, l, (uint64_t)cs << l, Wk, fftn));
+    const size_t base = (size_t)cs << l, width = (m - base < fftn ? m - base : fftn);
+    LF_HIP(c, hipMemcpy2DAsync(T + base, ld * 16, Wk, (size_t)fftn * 16, width * 16, nrow, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return LFGPU_OK;
+}
+
 extern "C" int lfgpu_gf2128_rs_encode_rows(lfgpu_ctx* c, int k, size_t nrow, size_t n, size_t m, void* d_T,
                                            size_t ld) {
   if (!c || (!d_T && nrow)) return lf_fail(c, LFGPU_ERR_ARG, "gf2128_rs_encode_rows: null argument");
@@ -167,8 +268,9 @@ extern "C" int lfgpu_gf2128_rs_encode_rows(lfgpu_ctx* c, int k, size_t nrow, siz
   // evaluation points of_scalar(j), j < m, must exist in the subfield (ligero_param.h:197-202)
   if (k < 6 && g->sub_bits < 64 && m > ((size_t)1 << g->sub_bits))
     return lf_fail(c, LFGPU_ERR_ARG, "gf2128_rs_encode_rows: m exceeds the subfield domain");
-  if (l > 12) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "gf2128_rs_encode_rows: n > 4096 (LDS-resident rows) not covered yet");
+  if (l > 20) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "gf2128_rs_encode_rows: n > 2^20");
   LF_HIP(c, hipSetDevice(c->device));
+  if (l > 12) return gf_rs_rows_big(c, g, k, nrow, n, m, (elt_t*)d_T, ld, l);
 
   char kb[96];
   snprintf(kb, sizeof(kb), "rsplan:%d:%zu:%zu", k, n, m);

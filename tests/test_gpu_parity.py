@@ -167,7 +167,10 @@ def test_lch14_fft_roundtrip_full_size(G):
 # ---------------------------------------------------------------- K3 / K4 RS rows
 @pytest.mark.parametrize("k,n,m,nrow", [(4, 1, 7, 2), (4, 5, 5, 2), (4, 21, 128, 8), (4, 100, 128, 3), (4, 64, 64, 1),
                                         (4, 64, 300, 2), (4, 455, 4096, 20), (4, 909, 4096, 3), (4, 910, 8192, 5),
-                                        (4, 1819, 8192, 2), (4, 682, 4096, 8), (4, 461, 4151, 3), (5, 1000, 5000, 2)])
+                                        (4, 1819, 8192, 2), (4, 682, 4096, 8), (4, 461, 4151, 3), (5, 1000, 5000, 2),
+                                        # rows larger than LDS (2^l > 4096): global-memory op sweeps + batched coset FFTs
+                                        (4, 4097, 8192, 2), (4, 5000, 20000, 3), (4, 7279, 32768, 40), (5, 9000, 70000, 2),
+                                        (4, 8192, 8192 + 5, 1), (4, 16384, 65536, 33)])
 def test_gf2128_rs_encode_rows(G, k, n, m, nrow):
     o = ol.oracle()
     rng = np.random.default_rng(n * 3 + m)
