@@ -105,15 +105,14 @@ struct ScSmall {
   elt_t* W[2];    // hand arrays before the bind
   u32 nW[2];
   elt_t* Wdst;    // destination of the dense bind (== W[bind_hand] for in place)
-  u64* QW;        // scratch: GF 2 words / Fp 4 limb accumulators per target, then the QW elements
-  const elt_t* fp_pow;  // Fp128: Montgomery images of 2^(32j), j < 5
+  u64* QW;        // scratch: GF 2 words / Fp 4 limb accumulators per target
 };
 int lf_sc_small_step(lfgpu_ctx* c, const ScSmall& a, u64 out[8]);
 int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_W_shared, void* wtmp);
 int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]);
 bool lf_sc_resident_ok(lfgpu_ctx* c);
 int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, void* W0, size_t nW0,
-                     void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, const void* fp_pow, size_t rh0,
+                     void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
                      size_t logw, void* d_state);
 #define LF_SC_GRID_WGS 64                          // most workgroups the shrinking-grid kernel starts with
 #define LF_SC_GRID_MAX (LF_SC_GRID_WGS * 1024)     // largest HQUAD / hand array it takes

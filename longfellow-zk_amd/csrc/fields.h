@@ -361,6 +361,41 @@ LF_HD elt_t fp_mul(elt_t a, elt_t b) { return fp_mul_c(a, b); }
 
 LF_HD elt_t fp_from_mont(elt_t a) { return fp_mul(a, elt_t{1ull, 0ull}); }
 
+// sum_k a_k 2^(32k) mod p for four u64 limb accumulators (sums of 32-bit limbs of residues: the integer-limb
+// accumulators of the Fp128 scatters).  Plain integer folding with 2^128 = 2^108 - 1 (mod p): the value is < 2^160,
+// so one fold leaves < 2^141 and a second one < 2^128; three residues are then added.  ~40 integer ops instead of
+// the eight Montgomery products of a limb-by-limb recombination.  (A sum of Montgomery images is the image of the sum.)
+LF_HD elt_t fp_canon128(elt_t x) {  // x < 2^128 < 2p  ->  x mod p
+  const bool ge = x.hi > FP_P_HI || (x.hi == FP_P_HI && x.lo >= FP_P_LO);
+  if (ge) {
+    const u64 lo = x.lo - FP_P_LO;
+    const u64 bw = x.lo < FP_P_LO;
+    x = elt_t{lo, x.hi - FP_P_HI - bw};
+  }
+  return x;
+}
+LF_HD elt_t fp_reduce_limbs(u64 a0, u64 a1, u64 a2, u64 a3) {
+  // S = (w2 : w1 : w0) in 64-bit words
+  const u64 w0 = a0 + (a1 << 32);
+  const u64 c0 = w0 < a0;
+  u64 w1 = a2 + ((a1 >> 32) + c0);
+  u64 c1 = w1 < a2;
+  const u64 t = a3 << 32;
+  w1 += t;
+  c1 += w1 < t;
+  const u64 w2 = (a3 >> 32) + c1;  // < 2^32 + 2
+  const elt_t x = fp_canon128(elt_t{w0, w1});
+  // w2 * 2^128 = w2 * (2^108 - 1) = ytop 2^128 + (yh 2^64) - w2
+  const u64 yh = w2 << 44;
+  u64 ytop = w2 >> 20;
+  const u64 br = w2 != 0;
+  if (yh < br) ytop -= 1;  // borrow out of the low 128 bits (then w2 >= 2^20, so ytop >= 1)
+  const elt_t y = fp_canon128(elt_t{0ull - w2, yh - br});
+  // ytop * 2^128 = ytop * (2^108 - 1) < 2^121
+  const elt_t z{0ull - ytop, (ytop << 44) - (u64)(ytop != 0)};
+  return fp_add(fp_add(x, y), z);
+}
+
 // ===================================================================== GF(2^128)
 LF_HD elt_t gf_add(elt_t a, elt_t b) { return elt_t{a.lo ^ b.lo, a.hi ^ b.hi}; }
 

@@ -193,18 +193,11 @@ __global__ __launch_bounds__(QD_THREADS) void bindg_emit_fp_kernel(size_t n, con
   atomicAdd(&a[2], (u64)(u32)pv.hi);
   atomicAdd(&a[3], pv.hi >> 32);
 }
-__global__ __launch_bounds__(QD_THREADS) void fp_limb_normalize4_kernel(const u32* __restrict__ total,
-                                                                        const u64* __restrict__ acc,
-                                                                        const elt_t* __restrict__ c, elt_t* __restrict__ out) {
+__global__ __launch_bounds__(QD_THREADS) void fp_limb_normalize4_kernel(const u32* __restrict__ total, const u64* __restrict__ acc,
+                                                                        elt_t* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x;
   if (i >= *total) return;
-  elt_t sum = elt_zero();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const u64 a = acc[4 * i + k];
-    sum = fp_add(sum, fp_add(fp_mul(elt_t{(u64)(u32)a, 0}, ld16(&c[k])), fp_mul(elt_t{a >> 32, 0}, ld16(&c[k + 1]))));
-  }
-  st16(&out[i], sum);
+  st16(&out[i], fp_reduce_limbs(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]));
 }
 
 #define QD_DISPATCH(field, KERNEL, grid, block, ...)                                    \
@@ -341,19 +334,11 @@ extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, c
     if (n >> 32) return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_g: more than 2^32 terms");
     void* accv = nullptr;
     LF_TRY(lf_scratch2(c, n * 32 + 64, &accv));
-    void* dconst = nullptr;
-    if (!lf_table_lookup(c, "fp:pow2_32j", &dconst)) {
-      elt_t cs[5];  // Montgomery images of 2^(32j)
-      cs[0] = h_fp_of_scalar(1);
-      const elt_t two32 = h_fp_of_scalar(1ull << 32);
-      for (int j = 1; j < 5; ++j) cs[j] = fp_mul(cs[j - 1], two32);
-      LF_TRY(lf_table(c, "fp:pow2_32j", cs, sizeof(cs), &dconst));
-    }
     LF_HIP(c, hipMemsetAsync(accv, 0, n * 32, c->stream));
     hipLaunchKernelGGL(bindg_emit_fp_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
                        (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)counts, (uint2*)d_hc_out, (u64*)accv);
     hipLaunchKernelGGL(fp_limb_normalize4_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, (const u32*)total, (const u64*)accv,
-                       (const elt_t*)dconst, (elt_t*)d_vc_out);
+                       (elt_t*)d_vc_out);
   }
   LF_HIP(c, hipGetLastError());
   LF_HIP(c, hipMemcpyAsync(c->mailbox_h, total, 4, hipMemcpyDeviceToHost, c->stream));
@@ -438,13 +423,8 @@ extern "C" int lfgpu_quad_bind_gh_all(lfgpu_quad* q, size_t logv, const void* h_
   if (field == LFGPU_FIELD_GF2_128) {
     out[0] = w[0];
     out[1] = w[1];
-  } else {  // recombine the limbs: sum_k w[k] 2^(32k) mod p on Montgomery images
-    elt_t pw = h_fp_of_scalar(1), sum{0, 0};
-    const elt_t two32 = h_fp_of_scalar(1ull << 32);
-    for (int k = 0; k < 4; ++k) {
-      sum = fp_add(sum, fp_add(fp_mul(elt_t{(u64)(u32)w[k], 0}, pw), fp_mul(fp_mul(elt_t{w[k] >> 32, 0}, pw), two32)));
-      pw = fp_mul(pw, two32);
-    }
+  } else {  // recombine the limbs: sum_k w[k] 2^(32k) mod p (a sum of Montgomery images is the image of the sum)
+    const elt_t sum = fp_reduce_limbs(w[0], w[1], w[2], w[3]);
     out[0] = sum.lo;
     out[1] = sum.hi;
   }
@@ -485,18 +465,6 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   void* qw = base + 2 * nt * 8 + 2 * nt * 16;
   void* wtmp = (uint8_t*)qw + qw_bytes;  // 4 half-size hand buffers; the first is the detach buffer of the step paths
   void* grid_state = (uint8_t*)wtmp + 4 * half;
-  const elt_t* fp_pow = nullptr;
-  if (field == LFGPU_FIELD_FP128) {
-    void* dconst = nullptr;
-    if (!lf_table_lookup(c, "fp:pow2_32j", &dconst)) {
-      elt_t cs[5];  // Montgomery images of 2^(32j)
-      cs[0] = h_fp_of_scalar(1);
-      const elt_t two32 = h_fp_of_scalar(1ull << 32);
-      for (int j = 1; j < 5; ++j) cs[j] = fp_mul(cs[j - 1], two32);
-      LF_TRY(lf_table(c, "fp:pow2_32j", cs, sizeof(cs), &dconst));
-    }
-    fp_pow = (const elt_t*)dconst;
-  }
   size_t nh = 0;
   static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
   auto clk = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -557,7 +525,6 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     a.nW[1] = (u32)nW[1];
     a.Wdst = (elt_t*)((pending && phand == 0 && WH[0] == d_W) ? wtmp : WH[phand]);  // hand 0 detaches from the shared input
     a.QW = (u64*)qw;
-    a.fp_pow = fp_pow;
     LF_TRY(lf_sc_small_step(c, a, out));
     if (pending) {
       WH[phand] = a.Wdst;
@@ -578,7 +545,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
         if (!resident && sc_mode == 3) {  // hand the rest of the layer to the shrinking grid
           uint8_t* wb = (uint8_t*)wtmp;
           LF_TRY(lf_sc_grid_begin(c, field, hc[cur], vc[cur], hc[1 - cur], vc[1 - cur], nh, WH[0], nW[0], WH[1], nW[1], wb, wb + half,
-                                  wb + 2 * half, wb + 3 * half, qw, fp_pow, 2 * rnd + hand, logw, grid_state));
+                                  wb + 2 * half, wb + 3 * half, qw, 2 * rnd + hand, logw, grid_state));
         } else if (!resident) {  // ... or to the resident workgroup
           ScSmall a{};
           a.field = field;
@@ -592,8 +559,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
           a.nW[0] = (u32)nW[0];
           a.nW[1] = (u32)nW[1];
           a.QW = (u64*)qw;
-          a.fp_pow = fp_pow;
-          LF_TRY(lf_sc_layer_begin(c, a, (u32)(2 * rnd + hand), (u32)(2 * logw), d_W, wtmp));
+                LF_TRY(lf_sc_layer_begin(c, a, (u32)(2 * rnd + hand), (u32)(2 * logw), d_W, wtmp));
         }
         resident = true;
         u64 out[8];

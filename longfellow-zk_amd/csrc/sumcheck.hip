@@ -131,22 +131,12 @@ __global__ __launch_bounds__(SC_THREADS) void qw_scatter_fp_kernel(size_t n, con
   atomicAdd(&a[2], (u64)(u32)t.hi);
   atomicAdd(&a[3], t.hi >> 32);
 }
-// S = sum_k acc[k] * 2^(32k) mod p on PLAIN integers (S is then again a Montgomery image, because images add).
-// acc[k] = lo32 + hi32 * 2^32; piece * 2^(32j) mod p = fp_mul(piece, c[j]) with c[j] = image of 2^(32j).
-__global__ __launch_bounds__(SC_THREADS) void fp_limb_normalize_kernel(size_t n, const u64* __restrict__ acc,
-                                                                       const elt_t* __restrict__ c /*5 constants*/,
-                                                                       elt_t* __restrict__ out) {
+// S = sum_k acc[k] * 2^(32k) mod p on PLAIN integers (S is then again a Montgomery image, because images add):
+// fp_reduce_limbs (fields.h) folds the 160-bit integer with 2^128 = 2^108 - 1.
+__global__ __launch_bounds__(SC_THREADS) void fp_limb_normalize_kernel(size_t n, const u64* __restrict__ acc, elt_t* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
   if (i >= n) return;
-  elt_t sum = elt_zero();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const u64 a = acc[4 * i + k];
-    const elt_t lo = fp_mul(elt_t{(u64)(u32)a, 0}, ld16(&c[k]));
-    const elt_t hi = fp_mul(elt_t{a >> 32, 0}, ld16(&c[k + 1]));
-    sum = fp_add(sum, fp_add(lo, hi));
-  }
-  st16(&out[i], sum);
+  st16(&out[i], fp_reduce_limbs(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]));
 }
 
 // out[i] = in[2i] + r*(in[2i+1]-in[2i]);  tail: in*(1-r)   (dense.h:70-87, affine.h:26-52)
@@ -352,7 +342,7 @@ __device__ __forceinline__ void sc_bind(ScState& st, ScShared& sh, int bh, elt_t
 
 // QW scatter + ProverLayers::evaluations for hand eh; the sums are valid in thread 0
 template <int F>
-__device__ __forceinline__ void sc_eval(const ScState& st, ScShared& sh, int eh, u64* QW, const elt_t* fp_pow, elt_t& a0, elt_t& a2) {
+__device__ __forceinline__ void sc_eval(const ScState& st, ScShared& sh, int eh, u64* QW, elt_t& a0, elt_t& a2) {
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32 nq = st.nW[eh], nh = st.nh;
   const elt_t* Wo = st.W[1 - eh];
@@ -403,13 +393,8 @@ __device__ __forceinline__ void sc_eval(const ScState& st, ScShared& sh, int eh,
   const u32 nodd = nq / 2;
   auto qw_at = [&](u32 j) -> elt_t {
     if (F == FIELD_GF2_128) return elt_t{QW[2 * (size_t)j], QW[2 * (size_t)j + 1]};
-    elt_t sum = elt_zero();  // recombine the limbs and reduce once (see fp_limb_normalize_kernel)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const u64 x = QW[4 * (size_t)j + k];
-      sum = fp_add(sum, fp_add(fp_mul(elt_t{(u64)(u32)x, 0}, ld16(&fp_pow[k])), fp_mul(elt_t{x >> 32, 0}, ld16(&fp_pow[k + 1]))));
-    }
-    return sum;
+    const u64* q = QW + 4 * (size_t)j;  // recombine the limbs and reduce once
+    return fp_reduce_limbs(q[0], q[1], q[2], q[3]);
   };
   a0 = elt_zero();
   a2 = elt_zero();
@@ -473,7 +458,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_small_step_kernel(ScSmall a, u6
   ScState st = sc_state_of(a);
   if (a.do_bind) sc_bind<F>(st, sh, a.bind_hand, a.r, a.Wdst);
   elt_t a0 = elt_zero(), a2 = elt_zero();
-  if (a.do_eval) sc_eval<F>(st, sh, a.eval_hand, a.QW, a.fp_pow, a0, a2);
+  if (a.do_eval) sc_eval<F>(st, sh, a.eval_hand, a.QW, a0, a2);
   if (threadIdx.x == 0) {
     if (!a.do_eval) {  // end of the layer: the two bound hand arrays (and the HQUAD scalar)
       a0 = st.nW[0] ? ld16(&st.W[0][0]) : elt_zero();
@@ -497,7 +482,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_small_layer_kernel(ScSmall a, u
   for (u32 rh = rh0; rh < rh1; ++rh, ++seq) {
     const int hand = (int)(rh & 1);
     elt_t a0, a2;
-    sc_eval<F>(st, sh, hand, a.QW, a.fp_pow, a0, a2);
+    sc_eval<F>(st, sh, hand, a.QW, a0, a2);
     if (threadIdx.x == 0) {
       sc_post(st, a0, a2, seq, 0, post);
       const u64 t0 = wall_clock64();
@@ -599,7 +584,6 @@ struct ScGrid {
   u32 nW[2];
   elt_t* Wb[2][2];  // bind destinations per hand (ping-pong), (nw+1)/2 elements each
   u64* QW;
-  const elt_t* fp_pow;
   u32 rh0, rh1;     // round-hands [rh0, rh1), rh1 = 2 * logw
   u64 seq0, timeout_ticks;
   volatile u64* post;
@@ -730,13 +714,8 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       const elt_t* Wh = W[hand];
       auto qw_at = [&](u32 j) -> elt_t {
         if (F == FIELD_GF2_128) return elt_t{a.QW[2 * (size_t)j], a.QW[2 * (size_t)j + 1]};
-        elt_t sum = elt_zero();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const u64 x = a.QW[4 * (size_t)j + k];
-          sum = fp_add(sum, fp_add(fp_mul(elt_t{(u64)(u32)x, 0}, ld16(&a.fp_pow[k])), fp_mul(elt_t{x >> 32, 0}, ld16(&a.fp_pow[k + 1]))));
-        }
-        return sum;
+        const u64* q = a.QW + 4 * (size_t)j;
+        return fp_reduce_limbs(q[0], q[1], q[2], q[3]);
       };
       elt_t a0 = elt_zero(), a2 = elt_zero();
       for (u32 i = gtid; i < nodd; i += GT) {
@@ -1105,7 +1084,7 @@ int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_
 // round-hands [rh0, 2*logw) of a layer as one cooperative launch on ceil(max size / 1024) workgroups;
 // d_state: LF_SC_GRID_STATE_BYTES of device scratch (ScGridSync + the per-workgroup counts)
 int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, void* W0, size_t nW0,
-                     void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, const void* fp_pow, size_t rh0,
+                     void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
                      size_t logw, void* d_state) {
   const size_t big = std::max(nh, std::max(nW0, nW1));
   if (rh0 >= 2 * logw || big > LF_SC_GRID_MAX) return lf_fail(c, LFGPU_ERR_ARG, "sc_grid_begin: bad operands");
@@ -1122,7 +1101,6 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   a.nW[0] = (u32)nW0; a.nW[1] = (u32)nW1;
   a.Wb[0][0] = (elt_t*)Wb00; a.Wb[0][1] = (elt_t*)Wb01; a.Wb[1][0] = (elt_t*)Wb10; a.Wb[1][1] = (elt_t*)Wb11;
   a.QW = (u64*)qw;
-  a.fp_pow = (const elt_t*)fp_pow;
   a.rh0 = (u32)rh0;
   a.rh1 = (u32)(2 * logw);
   a.seq0 = c->poll_seq + 1;
@@ -1201,14 +1179,6 @@ extern "C" int lfgpu_qw_scatter(lfgpu_ctx* c, int field, size_t n, const void* d
     void* sc = nullptr;
     LF_TRY(lf_scratch2(c, nqw * 32 + 5 * 16 + 64, &sc));
     u64* acc = (u64*)sc;
-    void* dconst = nullptr;
-    if (!lf_table_lookup(c, "fp:pow2_32j", &dconst)) {
-      elt_t cs[5];  // Montgomery images of 2^(32j), j = 0..4
-      cs[0] = h_fp_of_scalar(1);
-      const elt_t two32 = h_fp_of_scalar(1ull << 32);
-      for (int j = 1; j < 5; ++j) cs[j] = fp_mul(cs[j - 1], two32);
-      LF_TRY(lf_table(c, "fp:pow2_32j", cs, sizeof(cs), &dconst));
-    }
     LF_HIP(c, hipMemsetAsync(acc, 0, nqw * 32, c->stream));
     if (n) {
       u32 nb = (u32)((n + SC_THREADS - 1) / SC_THREADS);
@@ -1216,8 +1186,7 @@ extern "C" int lfgpu_qw_scatter(lfgpu_ctx* c, int field, size_t n, const void* d
                          (const elt_t*)d_vc, hand ? 1 : 0, (const elt_t*)d_Wother, acc);
     }
     u32 nb2 = (u32)((nqw + SC_THREADS - 1) / SC_THREADS);
-    hipLaunchKernelGGL(fp_limb_normalize_kernel, dim3(nb2), dim3(SC_THREADS), 0, c->stream, nqw, (const u64*)acc,
-                       (const elt_t*)dconst, (elt_t*)d_QW);
+    hipLaunchKernelGGL(fp_limb_normalize_kernel, dim3(nb2), dim3(SC_THREADS), 0, c->stream, nqw, (const u64*)acc, (elt_t*)d_QW);
     LF_HIP(c, hipGetLastError());
     return LFGPU_OK;
   }

@@ -7,6 +7,7 @@ extern "C" {
 void hf_fp_mul(const u64* a, const u64* b, u64* o) { elt_t r = fp_mul(elt_t{a[0], a[1]}, elt_t{b[0], b[1]}); o[0] = r.lo; o[1] = r.hi; }
 void hf_fp_add(const u64* a, const u64* b, u64* o) { elt_t r = fp_add(elt_t{a[0], a[1]}, elt_t{b[0], b[1]}); o[0] = r.lo; o[1] = r.hi; }
 void hf_fp_sub(const u64* a, const u64* b, u64* o) { elt_t r = fp_sub(elt_t{a[0], a[1]}, elt_t{b[0], b[1]}); o[0] = r.lo; o[1] = r.hi; }
+void hf_fp_reduce_limbs(const u64* a, u64* o) { elt_t r = fp_reduce_limbs(a[0], a[1], a[2], a[3]); o[0] = r.lo; o[1] = r.hi; }
 void hf_gf_mul(const u64* a, const u64* b, u64* o) { elt_t r = gf_mul(elt_t{a[0], a[1]}, elt_t{b[0], b[1]}); o[0] = r.lo; o[1] = r.hi; }
 // SHA-256 of nblk whole 64-byte blocks (no padding): returns raw state words
 void hf_sha_blocks(const unsigned char* p, unsigned nblk, u32* h) {

@@ -52,6 +52,26 @@ def test_fp_ops_match_oracle():
         assert (_bin(L.hf_fp_sub, x, y) == arr(o.lfo_fp_sub(elt(x), elt(y)))).all()
 
 
+def test_fp_reduce_limbs_matches_big_integers():
+    """fp_reduce_limbs: sum_k a_k 2^(32k) mod p for u64 limb accumulators, incl. the extreme words"""
+    L = _lib()
+    p = 2**128 - 2**108 + 1
+    rng = np.random.default_rng(9)
+    cases = [rng.integers(0, 2**64, size=4, dtype=np.uint64) for _ in range(4000)]
+    m = 2**64 - 1
+    ext = [0, 1, m, 2**32, 2**32 - 1, 2**63, 0xFFFFF00000000000, 0xFFFFF, 1 << 20, (1 << 20) - 1]
+    for a in ext:
+        for b in ext:
+            cases.append(np.array([a, b, ext[(a + b) % len(ext)], ext[(a ^ b) % len(ext)]], dtype=np.uint64))
+            cases.append(np.array([b, 0, 0, a], dtype=np.uint64))
+            cases.append(np.array([m, m, a, b], dtype=np.uint64))
+    for a in cases:
+        out = np.zeros(2, dtype=np.uint64)
+        L.hf_fp_reduce_limbs(P(a), P(out))
+        want = sum(int(a[k]) << (32 * k) for k in range(4)) % p
+        assert int(out[0]) | (int(out[1]) << 64) == want, [hex(int(x)) for x in a]
+
+
 def test_gf_mul_matches_oracle():
     L, o = _lib(), ol.oracle()
     rng = np.random.default_rng(6)
