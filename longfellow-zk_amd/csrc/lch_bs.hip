@@ -9,7 +9,8 @@
 // Pipeline (all device-resident, "internal" = bit-sliced tower units of m words):
 //   bs_cin   : rows (reference Elt layout) -> transpose 32x32 bits -> poly->tower basis -> units
 //   bs_bfly  : one launch per group of <= 4 index bits; tile = 32 (row-group, coordinate) combos x
-//              16 columns in LDS, lanes run over combos so a wave shares its twiddle (scalar branches)
+//              16 columns in LDS, lanes run over combos so a wave shares its twiddle (scalar branches);
+//              measured HBM-bound (32 GiB moved per pass at 3.7 TB/s)
 //   bs_cout  : units -> tower->poly basis -> transpose -> rows
 // Internal buffer: unit index ((rg*D + q)*n + c), m words each; 128-byte (k=5) / 64-byte (k=4)
 // contiguous chunks in every pass.
@@ -21,7 +22,8 @@
 #define BS_COLS 64      // columns per conversion tile (one wave = one plane row)
 #define BS_NB_MAX 4     // index bits per butterfly pass (array bound)
 // Butterfly tile = 2^r_log (row-group, coordinate) combos x 2^nb columns = 512 units.  r_log 5 / nb 4
-// (one masked per-lane stage per pass) or r_log 6 / nb 3 (every stage wave-uniform, more passes):
+// (one stage per pass whose twiddle differs between the two halves of a wave: run as two exec-masked scalar-branched
+// products, bs_mac_groups) or r_log 6 / nb 3 (every stage wave-uniform, more passes):
 // LFGPU_BS_RLOG selects; see DESIGN.md.
 static u32 g_bs_rlog = 5;
 #define BS_PS(units) ((units) + 1)  // LDS plane stride (words): +1 keeps the 8x4-byte scatter of a 128-byte chunk on distinct banks
