@@ -590,7 +590,10 @@ struct ScGrid {
   const volatile u64* cmd;
   ScGridSync* gs;
   u32* counts;      // one word per workgroup
+  u32 tail_lds;     // 1: the launch reserved SC_TAIL_LDS_BYTES of dynamic LDS for the tail
 };
+#define SC_TAIL 1024u
+#define SC_TAIL_LDS_BYTES (2 * SC_TAIL * 8 + 2 * SC_TAIL * 16 + 4 * SC_TAIL * 16 + SC_TAIL * 32)
 
 // barrier among the first `G` workgroups; false = aborted (every caller then returns)
 __device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen, u64 timeout_ticks) {
@@ -648,11 +651,16 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
   const elt_t* W[2] = {a.W[0], a.W[1]};
   u32 nW[2] = {a.nW[0], a.nW[1]};
   u32 wsel[2] = {a.W[0] == a.Wb[0][0] ? 1u : 0u, a.W[1] == a.Wb[1][0] ? 1u : 0u};
+  // pointers the tail may redirect into LDS (generic address space from here on)
+  u64* QW = a.QW;
+  elt_t* Wdst[2][2] = {{a.Wb[0][0], a.Wb[0][1]}, {a.Wb[1][0], a.Wb[1][1]}};
+  bool in_lds = false;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sc_dyn[];
   u32 gen = 0;
   u64 seq = a.seq0;
   {
     const u32 GT = G * SM_THREADS, gtid = g * SM_THREADS + tid;
-    for (u32 i = gtid; i < qwords * nW[a.rh0 & 1]; i += GT) a.QW[i] = 0;
+    for (u32 i = gtid; i < qwords * nW[a.rh0 & 1]; i += GT) QW[i] = 0;
   }
   if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
 #ifdef LF_SC_PROF
@@ -693,11 +701,11 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
             }
           }
           if (valid && head) {
-            atomicXor(&a.QW[2 * (size_t)key], t.lo);
-            atomicXor(&a.QW[2 * (size_t)key + 1], t.hi);
+            atomicXor(&QW[2 * (size_t)key], t.lo);
+            atomicXor(&QW[2 * (size_t)key + 1], t.hi);
           }
         } else if (valid) {  // integer limb accumulators (see qw_scatter_fp_kernel)
-          u64* acc = a.QW + 4 * (size_t)key;
+          u64* acc = QW + 4 * (size_t)key;
           atomicAdd(&acc[0], (u64)(u32)t.lo);
           atomicAdd(&acc[1], t.lo >> 32);
           atomicAdd(&acc[2], (u64)(u32)t.hi);
@@ -713,8 +721,8 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       const u32 nq = nW[hand], nodd = nq / 2;
       const elt_t* Wh = W[hand];
       auto qw_at = [&](u32 j) -> elt_t {
-        if (F == FIELD_GF2_128) return elt_t{a.QW[2 * (size_t)j], a.QW[2 * (size_t)j + 1]};
-        const u64* q = a.QW + 4 * (size_t)j;
+        if (F == FIELD_GF2_128) return elt_t{QW[2 * (size_t)j], QW[2 * (size_t)j + 1]};
+        const u64* q = QW + 4 * (size_t)j;
         return fp_reduce_limbs(q[0], q[1], q[2], q[3]);
       };
       elt_t a0 = elt_zero(), a2 = elt_zero();
@@ -842,7 +850,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
     const u32 n0 = nW[hand], nout = (n0 + 1) / 2;
     {
       const elt_t* in = W[hand];
-      elt_t* out = a.Wb[hand][wsel[hand]];
+      elt_t* out = Wdst[hand][wsel[hand]];
       for (u32 i = gtid; i < nout; i += GT) {
         const elt_t f0 = ld16(&in[2 * i]);
         elt_t v;
@@ -875,7 +883,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
     }
     {
       const u32 nnext = nW[(rh + 1) & 1];  // the next evaluation is for the other hand (sizes after this bind)
-      for (u32 i = gtid; i < qwords * nnext; i += GT) a.QW[i] = 0;
+      for (u32 i = gtid; i < qwords * nnext; i += GT) QW[i] = 0;
     }
     SC_LAP(4);
     if (G > 1 && !sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
@@ -949,6 +957,37 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       want = want ? want : 1;
       if (want < G) G = want;
       if (g >= G) return;
+      // tail: once everything fits (<= SC_TAIL entries) the last workgroup moves the whole state into LDS and the
+      // remaining rounds never touch global memory for data: every phase is then a product plus an LDS round trip
+      // instead of a product plus a global-memory round trip
+      if (G == 1 && !in_lds && a.tail_lds && big <= SC_TAIL) {
+        uint2* hcL0 = (uint2*)sc_dyn;                              // 2 x SC_TAIL corner pairs
+        uint2* hcL1 = hcL0 + SC_TAIL;
+        elt_t* vcL0 = (elt_t*)(hcL1 + SC_TAIL);                    // 2 x SC_TAIL values
+        elt_t* vcL1 = vcL0 + SC_TAIL;
+        elt_t* wL = vcL1 + SC_TAIL;                                // per hand: current (SC_TAIL) + two bind destinations (SC_TAIL / 2 each)
+        u64* qwL = (u64*)(wL + 4 * SC_TAIL);                        // SC_TAIL targets x up to 4 words
+        for (u32 i = tid; i < nh; i += SM_THREADS) {
+          hcL0[i] = hc[i];
+          st16(&vcL0[i], ld16(&vc[i]));
+        }
+        for (int h = 0; h < 2; ++h)
+          for (u32 i = tid; i < nW[h]; i += SM_THREADS) st16(&wL[h * 2 * SC_TAIL + i], ld16(&W[h][i]));
+        {
+          const u32 nnext = nW[(rh + 1) & 1];  // the global QW was cleared for the next evaluation: so is this one
+          for (u32 i = tid; i < qwords * nnext; i += SM_THREADS) qwL[i] = 0;
+        }
+        __syncthreads();
+        hc = hcL0; vc = vcL0; hc_o = hcL1; vc_o = vcL1;
+        for (int h = 0; h < 2; ++h) {
+          W[h] = wL + h * 2 * SC_TAIL;
+          Wdst[h][0] = wL + h * 2 * SC_TAIL + SC_TAIL;
+          Wdst[h][1] = wL + h * 2 * SC_TAIL + SC_TAIL + SC_TAIL / 2;
+          wsel[h] = 0;
+        }
+        QW = qwL;
+        in_lds = true;
+      }
     }
   }
 #ifdef LF_SC_PROF
@@ -1114,7 +1153,16 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   LF_HIP(c, hipMemsetAsync(d_state, 0, 64, c->stream));  // counters, abort flag, challenge slot
   void* args[] = {&a};
   const void* fn = field == LFGPU_FIELD_GF2_128 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
-  LF_HIP(c, hipLaunchCooperativeKernel(fn, dim3(G), dim3(SM_THREADS), args, 0, c->stream));
+  static int tail_ok = -1;  // dynamic LDS for the tail (112 KiB) needs the attribute once per kernel
+  if (tail_ok < 0) {
+    const bool off = getenv("LFGPU_SC_TAIL") && atoi(getenv("LFGPU_SC_TAIL")) == 0;
+    tail_ok = !off && hipFuncSetAttribute((const void*)sc_grid_layer_kernel<FIELD_GF2_128>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_TAIL_LDS_BYTES) == hipSuccess &&
+                      hipFuncSetAttribute((const void*)sc_grid_layer_kernel<FIELD_FP128>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_TAIL_LDS_BYTES) == hipSuccess
+                  ? 1 : 0;
+    (void)hipGetLastError();
+  }
+  a.tail_lds = (u32)tail_ok;
+  LF_HIP(c, hipLaunchCooperativeKernel(fn, dim3(G), dim3(SM_THREADS), args, tail_ok ? SC_TAIL_LDS_BYTES : 0, c->stream));
   return LFGPU_OK;
 }
 
