@@ -71,6 +71,37 @@ __global__ __launch_bounds__(QD_THREADS) void raw_eq2_kernel(u32 logn, u32 n, co
   st16(&eq[i], Fld<F>::add(e0, e1));
 }
 
+// The same vector with 2 products per entry instead of 2*logn: EQ(G, i) factors over the low and the high half of
+// the index bits, EQ(G, i) = LO[i mod 2^lb] * HI[i >> lb].  eq_tables_kernel builds the four factor tables
+// (LO0 | HI0 | LO1 | HI1, alpha folded into HI1; at most 2^ceil(logn/2) entries each, a product of <= 20 factors per
+// entry), raw_eq2_split_kernel combines them.  Exact field arithmetic: the association does not matter.
+template <int F>
+__global__ __launch_bounds__(QD_THREADS) void eq_tables_kernel(u32 logn, u32 lb, const elt_t* __restrict__ G /*G0|G1|1-G0|1-G1*/, elt_t alpha,
+                                                               elt_t one, elt_t* __restrict__ tab) {
+  const u32 hb = logn - lb, nlo = 1u << lb, nhi = 1u << hb;
+  const u32 t = blockIdx.x * QD_THREADS + threadIdx.x;
+  if (t >= 2 * (nlo + nhi)) return;
+  const u32 which = t < nlo ? 0 : t < nlo + nhi ? 1 : t < 2 * nlo + nhi ? 2 : 3;  // LO0, HI0, LO1, HI1
+  const u32 j = which == 0 ? t : which == 1 ? t - nlo : which == 2 ? t - nlo - nhi : t - 2 * nlo - nhi;
+  const u32 bits = (which & 1) ? hb : lb, shift = (which & 1) ? lb : 0, g = which >> 1;  // g: 0 -> G0, 1 -> G1
+  elt_t e = which == 3 ? alpha : one;
+  for (u32 l = 0; l < bits; ++l) {
+    const u32 bit = (j >> l) & 1;
+    e = Fld<F>::mul(e, ld16(&G[(bit ? g * logn : (2 + g) * logn) + shift + l]));
+  }
+  st16(&tab[t], e);
+}
+template <int F>
+__global__ __launch_bounds__(QD_THREADS) void raw_eq2_split_kernel(u32 logn, u32 lb, u32 n, const elt_t* __restrict__ tab, elt_t* __restrict__ eq) {
+  const u32 i = blockIdx.x * QD_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const u32 nlo = 1u << lb, nhi = 1u << (logn - lb);
+  const u32 lo = i & (nlo - 1), hi = i >> lb;
+  const elt_t e0 = Fld<F>::mul(ld16(&tab[lo]), ld16(&tab[nlo + hi]));
+  const elt_t e1 = Fld<F>::mul(ld16(&tab[nlo + nhi + lo]), ld16(&tab[2 * nlo + nhi + hi]));
+  st16(&eq[i], Fld<F>::add(e0, e1));
+}
+
 // ---- K10 step 2: run heads (first term of each distinct hand pair)
 __device__ __forceinline__ bool is_head(const corner4* t, size_t i) {
   if (i == 0) return true;
@@ -297,12 +328,22 @@ extern "C" int lfgpu_raw_eq2(lfgpu_ctx* c, int field, size_t logn, size_t n, con
     Gt[2 * logn + l] = field == LFGPU_FIELD_GF2_128 ? gf_add(one, G0[l]) : fp_sub(one, G0[l]);
     Gt[3 * logn + l] = field == LFGPU_FIELD_GF2_128 ? gf_add(one, G1[l]) : fp_sub(one, G1[l]);
   }
+  const u32 lb = (u32)(logn / 2), hb = (u32)logn - lb;
+  const size_t ntab = 2 * (((size_t)1 << lb) + ((size_t)1 << hb));
   void* d_G = nullptr;
-  LF_TRY(lf_scratch2(c, Gt.size() * 16, &d_G));
+  LF_TRY(lf_scratch2(c, (Gt.size() + ntab) * 16, &d_G));
+  elt_t* d_tab = (elt_t*)d_G + Gt.size();
   LF_TRY(lf_stage_upload(c, d_G, Gt.data(), Gt.size() * 16));  // 4*logn+1 <= 161 elements: through the pinned ring
   const elt_t al{alpha[0], alpha[1]};
-  QD_DISPATCH(field, raw_eq2_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, (u32)n,
-              (const elt_t*)d_G, al, one, (elt_t*)d_eq);
+  if (logn < 6) {  // tiny: the direct product per entry
+    QD_DISPATCH(field, raw_eq2_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, (u32)n,
+                (const elt_t*)d_G, al, one, (elt_t*)d_eq);
+  } else {
+    QD_DISPATCH(field, eq_tables_kernel, dim3((u32)((ntab + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, lb, (const elt_t*)d_G, al,
+                one, d_tab);
+    QD_DISPATCH(field, raw_eq2_split_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, lb, (u32)n,
+                (const elt_t*)d_tab, (elt_t*)d_eq);
+  }
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
 }
