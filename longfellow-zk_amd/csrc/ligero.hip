@@ -283,15 +283,25 @@ extern "C" int lfgpu_ligero_tableau(lfgpu_ligero_prover* pr, void** d_T) {
 }
 
 // y[j] = T0[j] + sum_i A[i][j] * T[i][j]        (dot_proof accumulation, Blas::vaxpy blas.h:71-78)
+// Workgroup = 64 columns x 16 row slices (a lane per column alone would be <= 4 workgroups of 150 sequential
+// products each: latency-bound); slices are folded through LDS.
 template <int F>
-__global__ void rows_vaxpy_kernel(u32 nrows, size_t n, const elt_t* __restrict__ T0, const elt_t* __restrict__ A,
-                                  size_t lda, const elt_t* __restrict__ T, size_t ld, elt_t* __restrict__ y) {
-  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  elt_t acc = ld16(&T0[j]);
-  for (u32 i = 0; i < nrows; ++i)
-    acc = Fld<F>::add(acc, Fld<F>::mul(ld16(&T[(size_t)i * ld + j]), ld16(&A[(size_t)i * lda + j])));
-  st16(&y[j], acc);
+__global__ __launch_bounds__(1024) void rows_vaxpy_kernel(u32 nrows, size_t n, const elt_t* __restrict__ T0, const elt_t* __restrict__ A,
+                                                          size_t lda, const elt_t* __restrict__ T, size_t ld, elt_t* __restrict__ y) {
+  __shared__ elt_t part[16][64];
+  const u32 col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const size_t j = (size_t)blockIdx.x * 64 + col;
+  elt_t acc = elt_zero();
+  if (j < n)
+    for (u32 i = slice; i < nrows; i += 16)
+      acc = Fld<F>::add(acc, Fld<F>::mul(ld16(&T[(size_t)i * ld + j]), ld16(&A[(size_t)i * lda + j])));
+  part[slice][col] = acc;
+  __syncthreads();
+  if (slice == 0 && j < n) {
+    acc = ld16(&T0[j]);
+    for (u32 k = 0; k < 16; ++k) acc = Fld<F>::add(acc, part[k][col]);
+    st16(&y[j], acc);
+  }
 }
 // y[j] = Tq[j] + sum_i u[i] * (z_i[j] - x_i[j]*y_i[j])   (quadratic_proof :311-333)
 template <int F>
@@ -351,7 +361,7 @@ extern "C" int lfgpu_ligero_dot_proof(lfgpu_ligero_prover* pr, const void* h_A, 
   hipLaunchKernelGGL(layout_aext_kernel, dim3((u32)((p.block + 255) / 256), (u32)p.nwqrow), dim3(256), 0, c->stream,
                      (u32)p.r, (u32)p.w, lda, (const elt_t*)dA, dAext);
   LF_TRY(lf_rs_rows(c, pr->field, pr->k, p.nwqrow, p.block, p.dblock, dAext, lda));
-  LIG_DISPATCH(pr->field, rows_vaxpy_kernel, dim3((u32)((p.dblock + 255) / 256)), dim3(256), (u32)p.nwqrow, p.dblock,
+  LIG_DISPATCH(pr->field, rows_vaxpy_kernel, dim3((u32)((p.dblock + 63) / 64)), dim3(1024), (u32)p.nwqrow, p.dblock,
                (const elt_t*)(pr->d_T + p.idot * p.block_enc), (const elt_t*)dAext, lda,
                (const elt_t*)(pr->d_T + p.iw * p.block_enc), p.block_enc, dy);
   LF_HIP(c, hipGetLastError());

@@ -514,16 +514,24 @@ __global__ __launch_bounds__(SM_THREADS) void sc_small_layer_kernel(ScSmall a, u
   }
 }
 
-// y[j] += sum_i u[i]*T[i][j]
+// y[j] += sum_i u[i]*T[i][j].  Workgroup = 64 columns x 16 row slices folded through LDS (one lane per column
+// alone leaves a handful of workgroups with nrows sequential products each).
 template <int F>
-__global__ __launch_bounds__(SC_THREADS) void rows_axpy_kernel(u32 nrows, size_t n, elt_t* __restrict__ y,
-                                                               const elt_t* __restrict__ u,
-                                                               const elt_t* __restrict__ T, size_t ld) {
-  size_t j = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
-  if (j >= n) return;
-  elt_t acc = ld16(&y[j]);
-  for (u32 i = 0; i < nrows; ++i) acc = Fld<F>::add(acc, Fld<F>::mul(ld16(&T[(size_t)i * ld + j]), ld16(&u[i])));
-  st16(&y[j], acc);
+__global__ __launch_bounds__(1024) void rows_axpy_kernel(u32 nrows, size_t n, elt_t* __restrict__ y, const elt_t* __restrict__ u,
+                                                         const elt_t* __restrict__ T, size_t ld) {
+  __shared__ elt_t part[16][64];
+  const u32 col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const size_t j = (size_t)blockIdx.x * 64 + col;
+  elt_t acc = elt_zero();
+  if (j < n)
+    for (u32 i = slice; i < nrows; i += 16) acc = Fld<F>::add(acc, Fld<F>::mul(ld16(&T[(size_t)i * ld + j]), ld16(&u[i])));
+  part[slice][col] = acc;
+  __syncthreads();
+  if (slice == 0 && j < n) {
+    acc = ld16(&y[j]);
+    for (u32 k = 0; k < 16; ++k) acc = Fld<F>::add(acc, part[k][col]);
+    st16(&y[j], acc);
+  }
 }
 __global__ void gather_columns_kernel(u32 nrow, size_t ld, size_t col0, const elt_t* __restrict__ T,
                                       const u64* __restrict__ idx, u32 nreq, elt_t* __restrict__ req) {
@@ -1298,8 +1306,8 @@ extern "C" int lfgpu_rows_axpy(lfgpu_ctx* c, int field, size_t nrows, size_t n, 
   void* du = nullptr;
   LF_TRY(lf_scratch2(c, nrows * 16, &du));
   LF_HIP(c, hipMemcpyAsync(du, h_u, nrows * 16, hipMemcpyHostToDevice, c->stream));
-  u32 nb = (u32)((n + SC_THREADS - 1) / SC_THREADS);
-  DISPATCH_FIELD(field, rows_axpy_kernel, dim3(nb), dim3(SC_THREADS), (u32)nrows, n, (elt_t*)d_y, (const elt_t*)du,
+  u32 nb = (u32)((n + 63) / 64);
+  DISPATCH_FIELD(field, rows_axpy_kernel, dim3(nb), dim3(1024), (u32)nrows, n, (elt_t*)d_y, (const elt_t*)du,
                  (const elt_t*)d_T, ld);
   LF_HIP(c, hipGetLastError());
   LF_HIP(c, hipStreamSynchronize(c->stream));  // h_u / du are reused by the caller
