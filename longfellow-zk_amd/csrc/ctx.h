@@ -119,6 +119,9 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
 #define LF_SC_GRID_STATE_BYTES (64 + 32 * LF_SC_GRID_WGS + 4 * LF_SC_GRID_WGS + 64)
 #define LF_SC_SMALL_MAX 8192  // largest HQUAD / hand array the single-workgroup step takes
 
+struct lfgpu_quad;
+int lf_eval_quad_async(lfgpu_quad* q, const void* d_W, void* d_V, int* d_fail);  // quad.hip
+
 static inline unsigned lf_log2(size_t n) {
   unsigned l = 0;
   while (((size_t)1 << l) < n) ++l;

@@ -292,6 +292,16 @@ extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32
   return LFGPU_OK;
 }
 
+// one layer, asynchronously: assert-zero failures are OR-ed into *d_fail (device); the caller clears and reads it
+int lf_eval_quad_async(lfgpu_quad* q, const void* d_W, void* d_V, int* d_fail) {
+  lfgpu_ctx* c = q->c;
+  u32 nb = (u32)((q->nv + QD_THREADS - 1) / QD_THREADS);
+  QD_DISPATCH(q->field, eval_quad_kernel, dim3(nb), dim3(QD_THREADS), (u32)q->nv, (const u32*)q->d_goff,
+              (const corner4*)q->d_bygate, (const elt_t*)q->d_kvec, (const elt_t*)d_W, (elt_t*)d_V, d_fail);
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
 extern "C" int lfgpu_eval_quad(lfgpu_quad* q, size_t nw, const void* d_W, void* d_V, int* ok_out) {
   if (!q || !d_W || !d_V || !ok_out) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = q->c;
@@ -299,10 +309,7 @@ extern "C" int lfgpu_eval_quad(lfgpu_quad* q, size_t nw, const void* d_W, void* 
   LF_HIP(c, hipSetDevice(c->device));
   int* d_fail = (int*)((uint8_t*)c->mailbox_d + 128);
   LF_HIP(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
-  u32 nb = (u32)((q->nv + QD_THREADS - 1) / QD_THREADS);
-  QD_DISPATCH(q->field, eval_quad_kernel, dim3(nb), dim3(QD_THREADS), (u32)q->nv, (const u32*)q->d_goff,
-              (const corner4*)q->d_bygate, (const elt_t*)q->d_kvec, (const elt_t*)d_W, (elt_t*)d_V, d_fail);
-  LF_HIP(c, hipGetLastError());
+  LF_TRY(lf_eval_quad_async(q, d_W, d_V, d_fail));
   LF_HIP(c, hipMemcpyAsync(c->mailbox_h, d_fail, 4, hipMemcpyDeviceToHost, c->stream));
   LF_HIP(c, hipStreamSynchronize(c->stream));
   *ok_out = *(const int*)c->mailbox_h ? 0 : 1;

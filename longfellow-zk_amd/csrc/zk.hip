@@ -653,16 +653,16 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
   // eval_circuit (prover_layers.h:52-104): layer inputs stay resident for the sumcheck
   double t0 = now_ms();
   LF_HIP(c, hipMemcpyAsync(zk->d_in[nl - 1], W, I.ninputs * 16, hipMemcpyHostToDevice, c->stream));
-  for (size_t l = nl; l-- > 0;) {
-    void* dst = l ? zk->d_in[l - 1] : zk->d_V;
-    int good = 0;
-    LF_TRY(lfgpu_eval_quad(C->layers[l].q, C->layers[l].nw, zk->d_in[l], dst, &good));
-    if (!good) return LFGPU_OK;  // an assert-zero term is non-zero: eval_circuit returns nullptr
-  }
-  {
+  {  // all layers back to back; assert-zero failures and the outputs are read once at the end
+    int* d_fail = (int*)((uint8_t*)c->mailbox_d + 128);
+    LF_HIP(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
+    for (size_t l = nl; l-- > 0;) LF_TRY(lf_eval_quad_async(C->layers[l].q, zk->d_in[l], l ? zk->d_in[l - 1] : zk->d_V, d_fail));
     std::vector<elt_t> V(I.nv);
+    int failed = 0;
     LF_HIP(c, hipMemcpyAsync(V.data(), zk->d_V, I.nv * 16, hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(c, hipMemcpyAsync(&failed, d_fail, 4, hipMemcpyDeviceToHost, c->stream));
     LF_HIP(c, hipStreamSynchronize(c->stream));
+    if (failed) return LFGPU_OK;  // an assert-zero term is non-zero: eval_circuit returns nullptr
     for (const elt_t& v : V)
       if (v.lo | v.hi) return LFGPU_OK;  // "V->v_[i] != F.zero()"
   }
