@@ -40,6 +40,12 @@ struct lfgpu_ctx {
   // small pinned host mailbox for results read back every call (roots, partial sums)
   void* mailbox_h = nullptr;
   void* mailbox_d = nullptr;
+  // one-entry cache of the last freed Ligero tableau / Merkle buffers (a prover that commits repeatedly with the same
+  // parameters does not pay hipMalloc + hipFree per proof)
+  void* lig_T = nullptr;
+  size_t lig_T_bytes = 0;
+  void* lig_L = nullptr;
+  size_t lig_L_bytes = 0;
   // pinned staging ring for small host tables that are uploaded without a stream synchronisation: slot i may be
   // rewritten once stage_ev[i] (recorded after its copy) has completed
   void* stage_h = nullptr;
@@ -86,6 +92,7 @@ elt_t h_fp_to_mont(elt_t raw);  // raw < p -> Montgomery image
 bool h_fp_fits(elt_t raw);      // raw < p
 // Reed-Solomon row extension for either field (GF2_128<k>: LCH14; Fp128: convolution with the 2^32-order root)
 int lf_rs_rows(lfgpu_ctx* c, int field, int k, size_t nrow, size_t n, size_t m, elt_t* d, size_t ld);
+int lf_gf_rs_rows_mixed(lfgpu_ctx* c, int k, size_t nrow, size_t n1, size_t n2, size_t lo2, size_t hi2, size_t m, elt_t* d_T, size_t ld);
 const GfHostCtx* lf_gf_ctx(lfgpu_ctx* c, int k);
 elt_t h_lch14_twiddle(const GfHostCtx* g, unsigned i, u64 u);
 

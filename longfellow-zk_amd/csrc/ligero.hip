@@ -17,6 +17,7 @@ struct lfgpu_ligero_prover {
   lfgpu_ligero_param p;
   elt_t* d_T;             // [nrow][block_enc]
   uint8_t* d_layers;      // [2*block_ext][32]
+  size_t T_bytes = 0, L_bytes = 0;
   std::vector<uint8_t> nonces;  // block_ext * 32 (host copy for open)
 };
 
@@ -251,8 +252,21 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
     lfgpu_ligero_free(pr);
     return rc;
   };
-  if (hipMalloc((void**)&pr->d_T, p.nrow * ld * 16) != hipSuccess) return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit: tableau alloc"));
-  if (hipMalloc((void**)&pr->d_layers, 2 * p.block_ext * 32) != hipSuccess) return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit: layers alloc"));
+  const size_t tb = p.nrow * ld * 16, lb = 2 * p.block_ext * 32;
+  if (c->lig_T && c->lig_T_bytes == tb) {  // buffers of the last freed prover with the same shape
+    pr->d_T = (elt_t*)c->lig_T;
+    c->lig_T = nullptr;
+  } else if (hipMalloc((void**)&pr->d_T, tb) != hipSuccess) {
+    return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit: tableau alloc"));
+  }
+  if (c->lig_L && c->lig_L_bytes == lb) {
+    pr->d_layers = (decltype(pr->d_layers))c->lig_L;
+    c->lig_L = nullptr;
+  } else if (hipMalloc((void**)&pr->d_layers, lb) != hipSuccess) {
+    return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit: layers alloc"));
+  }
+  pr->T_bytes = tb;
+  pr->L_bytes = lb;
   void* d_non = nullptr;
   int rc = lf_scratch3(c, p.block_ext * 32, &d_non);
   if (rc) return fail(rc);
@@ -260,9 +274,16 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
       hipMemcpyAsync(d_non, pr->nonces.data(), p.block_ext * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess)
     return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit: upload failed"));
   // rows 0 (ILDT) and all witness/quadratic rows: block -> block_enc; rows 1,2: dblock -> block_enc
-  if ((rc = lf_rs_rows(c, field, k, 1, p.block, p.block_enc, pr->d_T + p.ildt * ld, ld))) return fail(rc);
-  if ((rc = lf_rs_rows(c, field, k, 2, p.dblock, p.block_enc, pr->d_T + p.idot * ld, ld))) return fail(rc);
-  if ((rc = lf_rs_rows(c, field, k, p.nwqrow, p.block, p.block_enc, pr->d_T + p.iw * ld, ld))) return fail(rc);
+  rc = field == LFGPU_FIELD_GF2_128 && p.ildt == 0 && p.idot == 1 && p.iquad == 2 && p.iw == 3
+           ? lf_gf_rs_rows_mixed(c, k, p.nrow, p.block, p.dblock, p.idot, p.iquad + 1, p.block_enc, pr->d_T, ld)
+           : LFGPU_ERR_UNSUPPORTED;
+  if (rc == LFGPU_ERR_UNSUPPORTED) {  // general shapes / Fp128: group by group
+    if ((rc = lf_rs_rows(c, field, k, 1, p.block, p.block_enc, pr->d_T + p.ildt * ld, ld))) return fail(rc);
+    if ((rc = lf_rs_rows(c, field, k, 2, p.dblock, p.block_enc, pr->d_T + p.idot * ld, ld))) return fail(rc);
+    if ((rc = lf_rs_rows(c, field, k, p.nwqrow, p.block, p.block_enc, pr->d_T + p.iw * ld, ld))) return fail(rc);
+  } else if (rc) {
+    return fail(rc);
+  }
   if ((rc = lfgpu_column_commit(c, field, p.nrow, ld, p.dblock, p.block_ext, pr->d_T, d_non, pr->d_layers, root_out)))
     return fail(rc);
   *out = pr;
@@ -271,8 +292,21 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
 
 extern "C" int lfgpu_ligero_free(lfgpu_ligero_prover* pr) {
   if (!pr) return LFGPU_ERR_ARG;
-  if (pr->d_T) (void)hipFree(pr->d_T);
-  if (pr->d_layers) (void)hipFree(pr->d_layers);
+  lfgpu_ctx* c = pr->c;
+  // keep the buffers for the next commit of the same shape (one-entry cache per context); the stream is in order,
+  // so work still queued on them finishes before anything a later commit enqueues
+  auto stash = [&](void* p, size_t bytes, void** slot, size_t* slot_bytes) {
+    if (!p) return;
+    if (c && bytes) {
+      if (*slot) (void)hipFree(*slot);
+      *slot = p;
+      *slot_bytes = bytes;
+    } else {
+      (void)hipFree(p);
+    }
+  };
+  stash(pr->d_T, pr->T_bytes, &c->lig_T, &c->lig_T_bytes);
+  stash(pr->d_layers, pr->L_bytes, &c->lig_L, &c->lig_L_bytes);
   delete pr;
   return LFGPU_OK;
 }

@@ -78,7 +78,10 @@ __device__ __forceinline__ void run_op(elt_t* B, const RsOp op, const elt_t* __r
   }
 }
 
-__global__ __launch_bounds__(RS_THREADS) void gf_rs_rows_kernel(RsPlan p, elt_t* __restrict__ T, size_t ld) {
+// rows [lo2, hi2) use plan p2 (another n): the Ligero tableau mixes block- and dblock-long rows (ligero_prover.h:171-270)
+// and one launch for all of them beats three latency-bound ones
+__global__ __launch_bounds__(RS_THREADS) void gf_rs_rows_kernel(RsPlan p1, RsPlan p2, u32 lo2, u32 hi2, elt_t* __restrict__ T, size_t ld) {
+  const RsPlan& p = (blockIdx.x >= lo2 && blockIdx.x < hi2) ? p2 : p1;
   extern __shared__ elt_t lds[];
   const u32 fftn = 1u << p.l, tid = threadIdx.x;
   elt_t* Cc = lds;          // coefficients
@@ -207,6 +210,41 @@ struct PlanBuilder {
 };
 
 
+static int gf_rs_plan(lfgpu_ctx* c, const GfHostCtx* g, int k, size_t n, size_t m, RsPlan* out) {
+  const unsigned l = lf_log2(n);
+  RsPlan plan;
+  char kb[96];
+  snprintf(kb, sizeof(kb), "rsplan:%d:%zu:%zu", k, n, m);
+  std::string key(kb);
+  auto it = c->blobs.find(key);
+  if (it == c->blobs.end()) {
+    PlanBuilder pb{g, {}, {}};
+    pb.bidir(l, 0, (u32)n, 0);
+    plan.nops_bidir = (u32)pb.ops.size();
+    plan.l = l;
+    plan.n = (u32)n;
+    plan.m = (u32)m;
+    u32 ncoset = 1;
+    while (((size_t)ncoset << l) < m) ++ncoset;
+    plan.ncoset = ncoset;
+    plan.coset_tw_off = (u32)pb.tw.size();
+    for (u32 cs = 1; cs < ncoset; ++cs)
+      for (unsigned i = l; i-- > 0;) pb.stage_table(i, l, (u64)cs << l);
+    if (pb.ops.empty()) pb.ops.push_back(RsOp{OP_FWD, 0, 0, 0, 0, 0});
+    if (pb.tw.empty()) pb.tw.push_back(elt_t{0, 0});
+    void *dops = nullptr, *dtw = nullptr;
+    LF_TRY(lf_table(c, key + ":ops", pb.ops.data(), pb.ops.size() * sizeof(RsOp), &dops));
+    LF_TRY(lf_table(c, key + ":tw", pb.tw.data(), pb.tw.size() * 16, &dtw));
+    plan.ops = (const RsOp*)dops;
+    plan.tw = (const elt_t*)dtw;
+    c->blobs[key] = std::string((const char*)&plan, sizeof(plan));
+  } else {
+    memcpy(&plan, it->second.data(), sizeof(plan));
+  }
+  *out = plan;
+  return LFGPU_OK;
+}
+
 extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx*, int, int, size_t, unsigned, uint64_t, void*, size_t);
 
 static int gf_rs_rows_big(lfgpu_ctx* c, const GfHostCtx* g, int k, size_t nrow, size_t n, size_t m, elt_t* T, size_t ld, unsigned l) {
@@ -272,42 +310,37 @@ extern "C" int lfgpu_gf2128_rs_encode_rows(lfgpu_ctx* c, int k, size_t nrow, siz
   LF_HIP(c, hipSetDevice(c->device));
   if (l > 12) return gf_rs_rows_big(c, g, k, nrow, n, m, (elt_t*)d_T, ld, l);
 
-  char kb[96];
-  snprintf(kb, sizeof(kb), "rsplan:%d:%zu:%zu", k, n, m);
-  std::string key(kb);
   RsPlan plan;
-  auto it = c->blobs.find(key);
-  if (it == c->blobs.end()) {
-    PlanBuilder pb{g, {}, {}};
-    pb.bidir(l, 0, (u32)n, 0);
-    plan.nops_bidir = (u32)pb.ops.size();
-    plan.l = l;
-    plan.n = (u32)n;
-    plan.m = (u32)m;
-    u32 ncoset = 1;
-    while (((size_t)ncoset << l) < m) ++ncoset;
-    plan.ncoset = ncoset;
-    plan.coset_tw_off = (u32)pb.tw.size();
-    for (u32 cs = 1; cs < ncoset; ++cs)
-      for (unsigned i = l; i-- > 0;) pb.stage_table(i, l, (u64)cs << l);
-    if (pb.ops.empty()) pb.ops.push_back(RsOp{OP_FWD, 0, 0, 0, 0, 0});
-    if (pb.tw.empty()) pb.tw.push_back(elt_t{0, 0});
-    void *dops = nullptr, *dtw = nullptr;
-    LF_TRY(lf_table(c, key + ":ops", pb.ops.data(), pb.ops.size() * sizeof(RsOp), &dops));
-    LF_TRY(lf_table(c, key + ":tw", pb.tw.data(), pb.tw.size() * 16, &dtw));
-    plan.ops = (const RsOp*)dops;
-    plan.tw = (const elt_t*)dtw;
-    c->blobs[key] = std::string((const char*)&plan, sizeof(plan));
-  } else {
-    memcpy(&plan, it->second.data(), sizeof(plan));
-  }
+  LF_TRY(gf_rs_plan(c, g, k, n, m, &plan));
   size_t lds = (size_t)32 << l;
   static bool attr = false;
   if (!attr) {
     LF_HIP(c, hipFuncSetAttribute((const void*)gf_rs_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 << 12));
     attr = true;
   }
-  hipLaunchKernelGGL(gf_rs_rows_kernel, dim3((u32)nrow), dim3(RS_THREADS), lds, c->stream, plan, (elt_t*)d_T, ld);
+  hipLaunchKernelGGL(gf_rs_rows_kernel, dim3((u32)nrow), dim3(RS_THREADS), lds, c->stream, plan, plan, 0u, 0u, (elt_t*)d_T, ld);
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
+// all rows of a Ligero tableau in one launch: rows [lo2, hi2) are n2 long, the others n1 (both <= 4096 -> LDS rows);
+// returns LFGPU_ERR_UNSUPPORTED when the shapes need the general path (the caller then encodes group by group)
+int lf_gf_rs_rows_mixed(lfgpu_ctx* c, int k, size_t nrow, size_t n1, size_t n2, size_t lo2, size_t hi2, size_t m, elt_t* d_T, size_t ld) {
+  const GfHostCtx* g = lf_gf_ctx(c, k);
+  if (!g || n1 == 0 || n2 == 0 || m <= n1 || m <= n2 || ld < m || lf_log2(n1) > 12 || lf_log2(n2) > 12 ||
+      (g->sub_bits < 64 && m > ((size_t)1 << g->sub_bits)))
+    return LFGPU_ERR_UNSUPPORTED;
+  LF_HIP(c, hipSetDevice(c->device));
+  RsPlan p1, p2;
+  LF_TRY(gf_rs_plan(c, g, k, n1, m, &p1));
+  LF_TRY(gf_rs_plan(c, g, k, n2, m, &p2));
+  static bool attr = false;
+  if (!attr) {
+    LF_HIP(c, hipFuncSetAttribute((const void*)gf_rs_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 << 12));
+    attr = true;
+  }
+  const size_t lds = (size_t)32 << (p1.l > p2.l ? p1.l : p2.l);
+  hipLaunchKernelGGL(gf_rs_rows_kernel, dim3((u32)nrow), dim3(RS_THREADS), lds, c->stream, p1, p2, (u32)lo2, (u32)hi2, d_T, ld);
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
 }
