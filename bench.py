@@ -54,7 +54,7 @@ def cpu_baseline(logn, budget_s=12.0):
 def ligero_commit_shape(gpu, torch, np, stream, with_cpu):
     """BASELINE configs[2]: Ligero RS encode + Merkle column commit on the flatsha256 32-block tableau
     shape (GF2_128<4>: 150 rows, block 910, dblock 1819, block_enc 8192, block_ext 6373 -- SURVEY 6b),
-    synthetic witness rows resident in HBM.  GPU: K3 (3 launches) + K5 + K6."""
+    synthetic witness rows resident in HBM.  GPU: K3 (one launch for all rows) + K5 + K6."""
     import oracle_lib as ol
     nrow, block, dblock, be = 150, 910, 1819, 8192
     ext = be - dblock
@@ -68,9 +68,7 @@ def ligero_commit_shape(gpu, torch, np, stream, with_cpu):
 
     def run():
         p = dT.data_ptr()
-        gpu.gf2128_rs_encode_rows(p, 1, block, be, ld=be)
-        gpu.gf2128_rs_encode_rows(p + be * 16, 2, dblock, be, ld=be)
-        gpu.gf2128_rs_encode_rows(p + 3 * be * 16, nrow - 3, block, be, ld=be)
+        gpu.gf2128_rs_encode_tableau(p, nrow, block, dblock, 1, 3, be, ld=be)  # rows 1, 2 (IDOT, IQUAD) are dblock long
         return gpu.column_commit(4, nrow, be, dblock, ext, p, dN.data_ptr(), dL.data_ptr())
 
     root = run()
@@ -83,7 +81,7 @@ def ligero_commit_shape(gpu, torch, np, stream, with_cpu):
     torch.cuda.synchronize()
     gpu_ms = (time.perf_counter() - t0) / reps * 1e3
     res = {"shape": "150 rows x 8192 (block 910, dblock 1819, 6373 leaves), GF2_128<4>", "gpu_ms": gpu_ms,
-           "includes": "device copy of the 19.7 MB tableau + 3 RS launches + leaf hash + tree + 32-byte root readback"}
+           "includes": "device copy of the 19.7 MB tableau + RS encode of all rows (one launch) + leaf hash + tree + 32-byte root readback"}
     if with_cpu:
         r = ol.ref()
         if r is not None:

@@ -81,6 +81,12 @@ int lfgpu_gf2128_lch14_fft(lfgpu_ctx* ctx, int subfield_log_bits, int dir, size_
  * (lib/ligero/ligero_prover.h:34,175,184,210,237,295). */
 int lfgpu_gf2128_rs_encode_rows(lfgpu_ctx* ctx, int subfield_log_bits, size_t nrow, size_t n, size_t m,
                                 void* d_T, size_t ld);
+/* The three interpolate loops of LigeroProver::commit (layout_blinding_rows / layout_witness_rows /
+ * layout_quadratic_rows, lib/ligero/ligero_prover.h:171-270) in one launch: rows [lo2, hi2) hold n2 valid values,
+ * every other row n1; all are extended to m.  Both lengths must fit the LDS-resident kernel (<= 4096);
+ * LFGPU_ERR_UNSUPPORTED otherwise (call lfgpu_gf2128_rs_encode_rows per group instead). */
+int lfgpu_gf2128_rs_encode_tableau(lfgpu_ctx* ctx, int subfield_log_bits, size_t nrow, size_t n1, size_t n2, size_t lo2,
+                                   size_t hi2, size_t m, void* d_T, size_t ld);
 int lfgpu_fp128_rs_encode_rows(lfgpu_ctx* ctx, size_t nrow, size_t n, size_t m, const uint64_t omega[2],
                                uint64_t omega_order, void* d_T, size_t ld);
 

@@ -24,7 +24,7 @@ FP128_P = 2**128 - 2**108 + 1
 ABI_SYMBOLS = [
     "lfgpu_init", "lfgpu_shutdown", "lfgpu_last_error", "lfgpu_set_stream", "lfgpu_sync", "lfgpu_malloc",
     "lfgpu_free", "lfgpu_memcpy_h2d", "lfgpu_memcpy_d2h", "lfgpu_fp128_fft", "lfgpu_gf2128_lch14_fft",
-    "lfgpu_gf2128_rs_encode_rows", "lfgpu_fp128_rs_encode_rows", "lfgpu_column_commit", "lfgpu_merkle_build_tree",
+    "lfgpu_gf2128_rs_encode_rows", "lfgpu_gf2128_rs_encode_tableau", "lfgpu_fp128_rs_encode_rows", "lfgpu_column_commit", "lfgpu_merkle_build_tree",
     "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
     "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_field_binop", "lfgpu_fp128_fft_host", "lfgpu_gf2128_lch14_fft_host",
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
@@ -88,6 +88,7 @@ def load_library():
         "lfgpu_fp128_fft": [vp, ci, sz, sz, pu64, u64, vp, sz],
         "lfgpu_gf2128_lch14_fft": [vp, ci, ci, sz, C.c_uint, u64, vp, sz],
         "lfgpu_gf2128_rs_encode_rows": [vp, ci, sz, sz, sz, vp, sz],
+        "lfgpu_gf2128_rs_encode_tableau": [vp, ci, sz, sz, sz, sz, sz, sz, vp, sz],
         "lfgpu_fp128_rs_encode_rows": [vp, sz, sz, sz, pu64, u64, vp, sz],
         "lfgpu_column_commit": [vp, ci, sz, sz, sz, sz, vp, vp, vp, vp],
         "lfgpu_merkle_build_tree": [vp, sz, vp, vp],
@@ -213,6 +214,11 @@ class LfGpu:
     def gf2128_rs_encode_rows(self, d_ptr, nrow, n, m, ld=None, subfield_log_bits=4):
         self._ck(self.L.lfgpu_gf2128_rs_encode_rows(self.h, subfield_log_bits, nrow, n, m, C.c_void_p(d_ptr),
                                                     m if ld is None else ld))
+
+    def gf2128_rs_encode_tableau(self, d_ptr, nrow, n1, n2, lo2, hi2, m, ld=None, subfield_log_bits=4):
+        """all rows of a Ligero tableau in one launch: rows [lo2, hi2) have n2 valid values, the others n1"""
+        self._ck(self.L.lfgpu_gf2128_rs_encode_tableau(self.h, subfield_log_bits, nrow, n1, n2, lo2, hi2, m, C.c_void_p(d_ptr),
+                                                       m if ld is None else ld))
 
     # --- K4 ReedSolomon::interpolate over rows (reference lib/algebra/reed_solomon.h:93-110)
     def fp128_rs_encode_rows(self, d_ptr, nrow, n, m, ld=None, omega=None, omega_order=1 << 32):

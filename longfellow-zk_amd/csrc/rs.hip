@@ -345,6 +345,15 @@ int lf_gf_rs_rows_mixed(lfgpu_ctx* c, int k, size_t nrow, size_t n1, size_t n2, 
   return LFGPU_OK;
 }
 
+extern "C" int lfgpu_gf2128_rs_encode_tableau(lfgpu_ctx* c, int k, size_t nrow, size_t n1, size_t n2, size_t lo2, size_t hi2, size_t m,
+                                              void* d_T, size_t ld) {
+  if (!c || (!d_T && nrow) || lo2 > hi2 || hi2 > nrow) return lf_fail(c, LFGPU_ERR_ARG, "gf2128_rs_encode_tableau: bad argument");
+  if (nrow == 0) return LFGPU_OK;
+  const int rc = lf_gf_rs_rows_mixed(c, k, nrow, n1, n2, lo2, hi2, m, (elt_t*)d_T, ld);
+  if (rc == LFGPU_ERR_UNSUPPORTED) return lf_fail(c, rc, "gf2128_rs_encode_tableau: shapes need lfgpu_gf2128_rs_encode_rows per group");
+  return rc;
+}
+
 extern "C" int lfgpu_gf2128_rs_encode_rows_host(lfgpu_ctx* c, int k, size_t nrow, size_t n, size_t m, void* h_T,
                                                 size_t ld) {
   if (!c || !h_T) return LFGPU_ERR_ARG;

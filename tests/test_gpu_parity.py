@@ -184,6 +184,22 @@ def test_gf2128_rs_encode_rows(G, k, n, m, nrow):
     assert (G.from_dev(d, np.uint64, T.shape) == want).all()
 
 
+@pytest.mark.parametrize("k,nrow,n1,n2,lo2,hi2,m", [(4, 20, 455, 909, 1, 3, 4096), (4, 150, 910, 1819, 1, 3, 8192), (4, 7, 21, 64, 0, 7, 128),
+                                                     (4, 5, 100, 33, 2, 2, 300), (5, 9, 300, 500, 4, 9, 70000 // 16)])
+def test_gf2128_rs_encode_tableau_equals_row_groups(G, k, nrow, n1, n2, lo2, hi2, m):
+    """the single-launch tableau encode (rows [lo2, hi2) are n2 long) == the oracle row by row"""
+    o = ol.oracle()
+    rng = np.random.default_rng(nrow * 7 + m)
+    ld = m + 1
+    T = ol.rand_elts(rng, nrow * ld).reshape(nrow, ld, 2)
+    want = T.copy()
+    for r in range(nrow):
+        o.lfo_lch14_rs_interpolate(C.byref(ol.gf_ctx(k)), n2 if lo2 <= r < hi2 else n1, m, P(want[r]))
+    d = G.to_dev(T)
+    G.gpu().gf2128_rs_encode_tableau(d.data_ptr(), nrow, n1, n2, lo2, hi2, m, ld=ld, subfield_log_bits=k)
+    assert (G.from_dev(d, np.uint64, T.shape) == want).all()
+
+
 @pytest.mark.parametrize("n,m,nrow", [(1, 4, 2), (3, 8, 2), (21, 128, 4), (100, 257, 3), (455, 4096, 2)])
 def test_fp128_rs_encode_rows(G, n, m, nrow):
     o = ol.oracle()
