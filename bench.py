@@ -271,6 +271,16 @@ def main():
                      "kernel": "fp_fft_tile", "launches_per_step": launches_per_step, "avg_launch_ms": kern_ms,
                      "note": "integer-ALU-bound (no 64-bit multiplier on CDNA4): see DESIGN.md"},
     }
+    if logn == 20:
+        # the roofline that actually binds this kernel: VALU instruction issue.  Static instruction counts of the
+        # hand-written arithmetic (csrc/fields.h): 84 per Montgomery product, 27 per add+sub pair; per element and
+        # transform: 9 products (4 + 4 butterfly products of the two 1024-point passes, skipping w^0, + 1 inter-pass
+        # twiddle) and 10 butterfly add/sub pairs.  Peak: 36 T lane-instr/s measured with tools/ubench.hip
+        # (profiles/r01/ubench_int_rates.txt).
+        instr = nelem * (9 * 84 + 10 * 27)
+        rate = instr / (dev_ms / args.steps * 1e-3) / 1e12
+        out["alu_roofline"] = {"bound": "valu", "achieved": rate, "peak": 36.0, "unit": "T lane-instr/s", "frac": rate / 36.0,
+                               "basis": "static instruction counts x live kernel time"}
 
     if rank == 0 and not args.no_secondary:
         # secondary: same batch through the GF(2^128) LCH14 additive FFT (GF2_128<5>, l = logn)
