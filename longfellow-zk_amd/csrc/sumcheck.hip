@@ -598,10 +598,11 @@ struct ScGrid {
   const volatile u64* cmd;
   ScGridSync* gs;
   u32* counts;      // one word per workgroup
+  u32* src;         // one word per HQUAD entry: where each bound entry comes from
   u32 tail_lds;     // 1: the launch reserved SC_TAIL_LDS_BYTES of dynamic LDS for the tail
 };
 #define SC_TAIL 1024u
-#define SC_TAIL_LDS_BYTES (2 * SC_TAIL * 8 + 2 * SC_TAIL * 16 + 4 * SC_TAIL * 16 + SC_TAIL * 32)
+#define SC_TAIL_LDS_BYTES (2 * SC_TAIL * 8 + 2 * SC_TAIL * 16 + 4 * SC_TAIL * 16 + SC_TAIL * 32 + SC_TAIL * 4)
 
 // barrier among the first `G` workgroups; false = aborted (every caller then returns)
 __device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen, u64 timeout_ticks) {
@@ -661,6 +662,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
   u32 wsel[2] = {a.W[0] == a.Wb[0][0] ? 1u : 0u, a.W[1] == a.Wb[1][0] ? 1u : 0u};
   // pointers the tail may redirect into LDS (generic address space from here on)
   u64* QW = a.QW;
+  u32* src = a.src;
   elt_t* Wdst[2][2] = {{a.Wb[0][0], a.Wb[0][1]}, {a.Wb[1][0], a.Wb[1][1]}};
   bool in_lds = false;
   extern __shared__ __attribute__((aligned(16))) unsigned char sc_dyn[];
@@ -810,6 +812,73 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       }
     }
     SC_LAP(2);
+    // ---- while the host works on the challenge: everything of HQuad::bind_h that does not depend on it -- which
+    // entries merge (pair / lone even / lone odd), where each result goes, the halved corner indices
+    u32 my_off, my_end, new_nh;
+    {
+      const u32 R = ((nh + G - 1) / G + SM_THREADS - 1) / SM_THREADS * SM_THREADS;  // range per workgroup, whole chunks
+      const u32 lo = (u64)g * R < nh ? g * R : nh, hi = (u64)lo + R < nh ? lo + R : nh;
+      if (tid == 0) {
+        sh.carry = 0;
+        s_off = 0;
+        s_tot = 0;
+      }
+      __syncthreads();
+      if (G > 1) {
+        u32 mine = 0;
+        for (u32 base = lo; base < hi; base += SM_THREADS) {
+          const u32 i = base + tid;
+          const bool head = i < hi && !is_second(hc, i, hand);
+          mine += (u32)__popcll(__ballot(head));
+        }
+        if (lane == 0 && mine) atomicAdd(&sh.carry, mine);
+        __syncthreads();
+        if (tid == 0) a.counts[g] = sh.carry;
+        SC_LAP(4);
+        if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
+        SC_LAP(5);
+        if (tid < G) {
+          const u32 cnt = a.counts[tid];
+          if (cnt) {
+            atomicAdd(&s_tot, cnt);
+            if (tid < g) atomicAdd(&s_off, cnt);
+          }
+        }
+        __syncthreads();
+      }
+      my_off = s_off;
+      __syncthreads();
+      if (tid == 0) sh.carry = my_off;
+      __syncthreads();
+      for (u32 base = lo; base < hi; base += SM_THREADS) {
+        const u32 i = base + tid;
+        const bool head = i < hi && !is_second(hc, i, hand);
+        const u64 mask = __ballot(head);
+        if (lane == 0) sh.wave[wave] = (u32)__popcll(mask);
+        __syncthreads();
+        u32 off = sh.carry;
+        for (u32 w = 0; w < wave; ++w) off += sh.wave[w];
+        off += (u32)__popcll(mask & ((1ull << lane) - 1));
+        if (head) {
+          uint2 h = hc[i];
+          const u32 hh = hand ? h.y : h.x;
+          const u32 kind = (i + 1 < nh && is_second(hc, i + 1, hand)) ? 0u : ((hh & 1) == 0 ? 1u : 2u);
+          if (hand) h.y = hh >> 1; else h.x = hh >> 1;
+          hc_o[off] = h;
+          src[off] = i | (kind << 30);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          u32 tot = 0;
+          for (u32 w = 0; w < SM_THREADS / 64; ++w) tot += sh.wave[w];
+          sh.carry += tot;
+        }
+        __syncthreads();
+      }
+      my_end = sh.carry;
+      new_nh = G > 1 ? s_tot : my_end;
+    }
+    SC_LAP(6);
     // ---- the challenge: workgroup 0 takes it from the host, the others from the device slot
     if (tid == 0) {
       const u64 t0 = wall_clock64();
@@ -854,7 +923,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
     if (sh.cmd[2] != seq) return;  // uniform per workgroup; the barriers of the others see the abort flag
     const elt_t r{sh.cmd[0], sh.cmd[1]};
     SC_LAP(3);
-    // ---- Dense::bind of W[hand] (out of place), head counts of this workgroup's HQUAD range, clear QW
+    // ---- Dense::bind of W[hand] (out of place), clear QW, values of the HQUAD entries laid out above
     const u32 n0 = nW[hand], nout = (n0 + 1) / 2;
     {
       const elt_t* in = W[hand];
@@ -874,80 +943,26 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       nW[hand] = nout;
       wsel[hand] ^= 1;
     }
-    const u32 R = ((nh + G - 1) / G + SM_THREADS - 1) / SM_THREADS * SM_THREADS;  // range per workgroup, whole chunks
-    const u32 lo = (u64)g * R < nh ? g * R : nh, hi = (u64)lo + R < nh ? lo + R : nh;
-    if (G > 1) {
-      if (tid == 0) sh.carry = 0;
-      __syncthreads();
-      u32 mine = 0;
-      for (u32 base = lo; base < hi; base += SM_THREADS) {
-        const u32 i = base + tid;
-        const bool head = i < hi && !is_second(hc, i, hand);
-        mine += (u32)__popcll(__ballot(head));
-      }
-      if (lane == 0 && mine) atomicAdd(&sh.carry, mine);
-      __syncthreads();
-      if (tid == 0) a.counts[g] = sh.carry;
-    }
     {
       const u32 nnext = nW[(rh + 1) & 1];  // the next evaluation is for the other hand (sizes after this bind)
       for (u32 i = gtid; i < qwords * nnext; i += GT) QW[i] = 0;
     }
-    SC_LAP(4);
-    if (G > 1 && !sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
-    SC_LAP(5);
-    // ---- HQuad::bind_h: emit this workgroup's range at its offset
+    for (u32 o = my_off + tid; o < my_end; o += SM_THREADS) {  // HQuad::bind_h values (hquad.h:94-118)
+      const u32 sidx = src[o], i = sidx & 0x3fffffffu, kind = sidx >> 30;
+      const elt_t v0 = ld16(&vc[i]);
+      elt_t v;
+      if (kind == 0) {
+        const elt_t v1 = ld16(&vc[i + 1]);
+        v = Fld<F>::add(v0, Fld<F>::mul(Fld<F>::sub(v1, v0), r));
+      } else if (kind == 1) {
+        v = Fld<F>::sub(v0, Fld<F>::mul(v0, r));
+      } else {
+        v = Fld<F>::mul(v0, r);
+      }
+      st16(&vc_o[o], v);
+    }
     {
-      if (tid == 0) {
-        s_off = 0;
-        s_tot = 0;
-      }
-      __syncthreads();
-      if (G > 1 && tid < G) {
-        const u32 cnt = a.counts[tid];
-        if (cnt) {
-          atomicAdd(&s_tot, cnt);
-          if (tid < g) atomicAdd(&s_off, cnt);
-        }
-      }
-      __syncthreads();
-      if (tid == 0) sh.carry = s_off;
-      __syncthreads();
-      for (u32 base = lo; base < hi; base += SM_THREADS) {
-        const u32 i = base + tid;
-        const bool head = i < hi && !is_second(hc, i, hand);
-        const u64 mask = __ballot(head);
-        if (lane == 0) sh.wave[wave] = (u32)__popcll(mask);
-        __syncthreads();
-        u32 off = sh.carry;
-        for (u32 w = 0; w < wave; ++w) off += sh.wave[w];
-        off += (u32)__popcll(mask & ((1ull << lane) - 1));
-        if (head) {
-          uint2 h = hc[i];
-          const u32 hh = hand ? h.y : h.x;
-          const elt_t v0 = ld16(&vc[i]);
-          elt_t v;
-          if (i + 1 < nh && is_second(hc, i + 1, hand)) {
-            const elt_t v1 = ld16(&vc[i + 1]);
-            v = Fld<F>::add(v0, Fld<F>::mul(Fld<F>::sub(v1, v0), r));
-          } else if ((hh & 1) == 0) {
-            v = Fld<F>::sub(v0, Fld<F>::mul(v0, r));
-          } else {
-            v = Fld<F>::mul(v0, r);
-          }
-          if (hand) h.y = hh >> 1; else h.x = hh >> 1;
-          hc_o[off] = h;
-          st16(&vc_o[off], v);
-        }
-        __syncthreads();
-        if (tid == 0) {
-          u32 tot = 0;
-          for (u32 w = 0; w < SM_THREADS / 64; ++w) tot += sh.wave[w];
-          sh.carry += tot;
-        }
-        __syncthreads();
-      }
-      nh = G > 1 ? s_tot : sh.carry;
+      nh = new_nh;
       uint2* th = const_cast<uint2*>(hc);
       elt_t* tv = const_cast<elt_t*>(vc);
       hc = hc_o;
@@ -994,6 +1009,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
           wsel[h] = 0;
         }
         QW = qwL;
+        src = (u32*)(qwL + 4 * SC_TAIL);
         in_lds = true;
       }
     }
@@ -1135,7 +1151,7 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
                      size_t logw, void* d_state) {
   const size_t big = std::max(nh, std::max(nW0, nW1));
   if (rh0 >= 2 * logw || big > LF_SC_GRID_MAX) return lf_fail(c, LFGPU_ERR_ARG, "sc_grid_begin: bad operands");
-  static_assert(sizeof(ScGridSync) + 4 * LF_SC_GRID_WGS <= LF_SC_GRID_STATE_BYTES, "grid state size");
+  static_assert(sizeof(ScGridSync) + 4 * LF_SC_GRID_WGS + 4 * LF_SC_GRID_MAX <= LF_SC_GRID_STATE_BYTES, "grid state size");
   u32 G = (u32)((big + SM_THREADS - 1) / SM_THREADS);
   G = G ? G : 1;
   if (G > LF_SC_GRID_WGS) G = LF_SC_GRID_WGS;
@@ -1158,6 +1174,7 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   a.cmd = c->poll_h + 64;
   a.gs = (ScGridSync*)d_state;
   a.counts = (u32*)((uint8_t*)d_state + sizeof(ScGridSync));
+  a.src = (u32*)((uint8_t*)d_state + LF_SC_GRID_STATE_BYTES - 4 * LF_SC_GRID_MAX);
   LF_HIP(c, hipMemsetAsync(d_state, 0, 64, c->stream));  // counters, abort flag, challenge slot
   void* args[] = {&a};
   const void* fn = field == LFGPU_FIELD_GF2_128 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
@@ -1191,9 +1208,9 @@ int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]) {
     static int layers = 0;
     for (int k = 0; k < 8; ++k) tot[k] += c->poll_h[16 + k];
     if (++layers % 13 == 0) {
-      fprintf(stderr, "sc_grid phases (us, %d layers): scatter %.0f bar1 %.0f partials %.0f wait %.0f bind %.0f bar2 %.0f emit %.0f bar3 %.0f\n", layers,
+      fprintf(stderr, "sc_grid phases (us, %d layers): scatter %.0f bar1 %.0f partials %.0f wait %.0f bind+values %.0f counts %.0f bar2 %.0f layout %.0f (bar3 in scatter)\n", layers,
               tot[0] * 1e3 / c->wall_khz, tot[1] * 1e3 / c->wall_khz, tot[2] * 1e3 / c->wall_khz, tot[3] * 1e3 / c->wall_khz,
-              tot[4] * 1e3 / c->wall_khz, tot[5] * 1e3 / c->wall_khz, tot[6] * 1e3 / c->wall_khz, tot[7] * 1e3 / c->wall_khz);
+              tot[7] * 1e3 / c->wall_khz, tot[4] * 1e3 / c->wall_khz, tot[5] * 1e3 / c->wall_khz, tot[6] * 1e3 / c->wall_khz);
       for (int k = 0; k < 8; ++k) tot[k] = 0;
     }
   }
