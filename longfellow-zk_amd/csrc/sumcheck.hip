@@ -9,6 +9,9 @@
 // The Fiat-Shamir transcript stays on the host, so each round returns two field
 // elements through a pinned mailbox and receives one challenge.
 #include "ctx.h"
+#include <chrono>
+#include <utility>
+#include <vector>
 
 #define SC_THREADS 256
 #define SC_MAX_BLOCKS 1024
@@ -592,6 +595,7 @@ struct ScGrid {
   u32 nW[2];
   elt_t* Wb[2][2];  // bind destinations per hand (ping-pong), (nw+1)/2 elements each
   u64* QW;
+  u64* QW2;         // second accumulator array (same size)
   u32 rh0, rh1;     // round-hands [rh0, rh1), rh1 = 2 * logw
   u64 seq0, timeout_ticks;
   volatile u64* post;
@@ -600,6 +604,7 @@ struct ScGrid {
   u32* counts;      // one word per workgroup
   u32* src;         // one word per HQUAD entry: where each bound entry comes from
   u32 tail_lds;     // 1: the launch reserved SC_TAIL_LDS_BYTES of dynamic LDS for the tail
+  u32 per_wg;       // entries of the largest array per active workgroup (the grid shrinks to keep it)
 };
 #define SC_TAIL 1024u
 #define SC_TAIL_LDS_BYTES (2 * SC_TAIL * 8 + 2 * SC_TAIL * 16 + 4 * SC_TAIL * 16 + SC_TAIL * 32 + SC_TAIL * 4)
@@ -614,7 +619,8 @@ __device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen,
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
+    // one release (with the arrival), one acquire (after the wait): every further fence is an L2 write-back or
+    // invalidate of this XCD that the barrier's latency would pay for nothing
     u32 ab = 0;
     const u64 t0 = wall_clock64();
     const u32 t = __hip_atomic_fetch_add(&gs->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -622,7 +628,7 @@ __device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen,
       __hip_atomic_store(&gs->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&gs->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      while (__hip_atomic_load(&gs->gen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+      while (__hip_atomic_load(&gs->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
         if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           ab = 1;
           break;
@@ -634,8 +640,8 @@ __device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen,
         }
         __builtin_amdgcn_s_sleep(1);
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    __threadfence();
     s_abort = ab;
   }
   ++gen;
@@ -661,18 +667,66 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
   u32 nW[2] = {a.nW[0], a.nW[1]};
   u32 wsel[2] = {a.W[0] == a.Wb[0][0] ? 1u : 0u, a.W[1] == a.Wb[1][0] ? 1u : 0u};
   // pointers the tail may redirect into LDS (generic address space from here on)
-  u64* QW = a.QW;
+  u64* QW = a.QW;    // accumulators of the evaluation being summed
+  u64* QWn = a.QW2;  // of the next evaluation: filled while the current hand is bound (one buffer once in LDS)
   u32* src = a.src;
   elt_t* Wdst[2][2] = {{a.Wb[0][0], a.Wb[0][1]}, {a.Wb[1][0], a.Wb[1][1]}};
   bool in_lds = false;
   extern __shared__ __attribute__((aligned(16))) unsigned char sc_dyn[];
   u32 gen = 0;
   u64 seq = a.seq0;
+  // QW[key] += t for one term per lane; every lane of the wave calls it (valid = false for the idle ones)
+  auto qw_add = [&](u64* Q, u32 key, elt_t t, bool valid) {
+    if (F == FIELD_GF2_128) {  // fold runs of equal targets inside the wave first (see qw_scatter_gf_kernel)
+      const u32 pkey = __shfl_up(key, 1, 64);
+      const bool head = lane == 0 || pkey != key;
+      const u64 hmask = __ballot(head);
+      const u32 rid = (u32)__popcll(hmask & ((2ull << lane) - 1));
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const u64 olo = __shfl_down(t.lo, off, 64), ohi = __shfl_down(t.hi, off, 64);
+        const u32 orid = __shfl_down(rid, off, 64);
+        if (lane + off < 64 && orid == rid) {
+          t.lo ^= olo;
+          t.hi ^= ohi;
+        }
+      }
+      if (valid && head) {
+        atomicXor(&Q[2 * (size_t)key], t.lo);
+        atomicXor(&Q[2 * (size_t)key + 1], t.hi);
+      }
+    } else if (valid) {  // integer limb accumulators (see qw_scatter_fp_kernel)
+      u64* acc = Q + 4 * (size_t)key;
+      atomicAdd(&acc[0], (u64)(u32)t.lo);
+      atomicAdd(&acc[1], t.lo >> 32);
+      atomicAdd(&acc[2], (u64)(u32)t.hi);
+      atomicAdd(&acc[3], t.hi >> 32);
+    }
+  };
   {
-    const u32 GT = G * SM_THREADS, gtid = g * SM_THREADS + tid;
-    for (u32 i = gtid; i < qwords * nW[a.rh0 & 1]; i += GT) QW[i] = 0;
+    const u32 GT = G * SM_THREADS, gtid = (wave * G + g) * 64 + lane;  // 64-entry chunks dealt round-robin: few entries = few waves on EVERY workgroup
+    const u32 h0 = a.rh0 & 1;
+    for (u32 i = gtid; i < qwords * nW[h0]; i += GT) QW[i] = 0;
+    for (u32 i = gtid; i < qwords * nW[1 - h0]; i += GT) QWn[i] = 0;
   }
   if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
+  {  // first evaluation of the hand-off: QW[h[hand]] += v * Wother[h[1-hand]] over the whole HQUAD
+    const int hand = (int)(a.rh0 & 1);
+    const u32 GT = G * SM_THREADS;
+    const elt_t* Wo = W[1 - hand];
+    for (u32 base = (wave * G + g) * 64; base < (nh + 63) / 64 * 64; base += GT) {  // whole waves: qw_add shuffles
+      const u32 i = base + lane;
+      const bool valid = i < nh;
+      u32 key = 0xffffffffu;
+      elt_t t = elt_zero();
+      if (valid) {
+        const uint2 h = hc[i];
+        key = hand ? h.y : h.x;
+        t = Fld<F>::mul(ld16(&vc[i]), ld16(&Wo[hand ? h.x : h.y]));
+      }
+      qw_add(QW, key, t, valid);
+    }
+  }
 #ifdef LF_SC_PROF
   u64 pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   u64 tl = wall_clock64();
@@ -680,51 +734,51 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
 #else
 #define SC_LAP(k) do { } while (0)
 #endif
+  // One round-hand = [barrier] sums a0, a2 -> post | layout of the HQUAD bind (hidden behind the host) | challenge |
+  // bind both structures AND accumulate the next evaluation's QW from the values just produced.
   for (u32 rh = a.rh0; rh < a.rh1; ++rh, ++seq) {
     const int hand = (int)(rh & 1);
-    const u32 GT = G * SM_THREADS, gtid = g * SM_THREADS + tid;
-    // ---- QW[h[hand]] += v * Wother[h[1-hand]]
-    {
-      const elt_t* Wo = W[1 - hand];
-      for (u32 base = g * SM_THREADS; base < nh; base += GT) {
-        const u32 i = base + tid;
-        const bool valid = i < nh;
-        u32 key = 0xffffffffu;
-        elt_t t = elt_zero();
-        if (valid) {
-          const uint2 h = hc[i];
-          key = hand ? h.y : h.x;
-          t = Fld<F>::mul(ld16(&vc[i]), ld16(&Wo[hand ? h.x : h.y]));
+    if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;  // QW of this evaluation is complete
+    SC_LAP(0);
+    {  // shrink: one workgroup per 1024 entries of the largest array; the others are done
+      u32 big = nh > nW[0] ? nh : nW[0];
+      big = big > nW[1] ? big : nW[1];
+      u32 want = (big + a.per_wg - 1) / a.per_wg;
+      want = want ? want : 1;
+      if (want < G) G = want;
+      if (g >= G) return;
+      // tail: once everything fits (<= SC_TAIL entries) the last workgroup moves the whole state into LDS and the
+      // remaining rounds never touch global memory for data: every phase is then a product plus an LDS round trip
+      // instead of a product plus a global-memory round trip
+      if (G == 1 && !in_lds && a.tail_lds && big <= SC_TAIL) {
+        uint2* hcL0 = (uint2*)sc_dyn;                              // 2 x SC_TAIL corner pairs
+        uint2* hcL1 = hcL0 + SC_TAIL;
+        elt_t* vcL0 = (elt_t*)(hcL1 + SC_TAIL);                    // 2 x SC_TAIL values
+        elt_t* vcL1 = vcL0 + SC_TAIL;
+        elt_t* wL = vcL1 + SC_TAIL;                                // per hand: current (SC_TAIL) + two bind destinations (SC_TAIL / 2 each)
+        u64* qwL = (u64*)(wL + 4 * SC_TAIL);                        // SC_TAIL targets x up to 4 words
+        for (u32 i = tid; i < nh; i += SM_THREADS) {
+          hcL0[i] = hc[i];
+          st16(&vcL0[i], ld16(&vc[i]));
         }
-        if (F == FIELD_GF2_128) {  // fold runs of equal targets inside the wave first (see qw_scatter_gf_kernel)
-          const u32 pkey = __shfl_up(key, 1, 64);
-          const bool head = lane == 0 || pkey != key;
-          const u64 hmask = __ballot(head);
-          const u32 rid = (u32)__popcll(hmask & ((2ull << lane) - 1));
-#pragma unroll
-          for (int off = 1; off < 64; off <<= 1) {
-            const u64 olo = __shfl_down(t.lo, off, 64), ohi = __shfl_down(t.hi, off, 64);
-            const u32 orid = __shfl_down(rid, off, 64);
-            if (lane + off < 64 && orid == rid) {
-              t.lo ^= olo;
-              t.hi ^= ohi;
-            }
-          }
-          if (valid && head) {
-            atomicXor(&QW[2 * (size_t)key], t.lo);
-            atomicXor(&QW[2 * (size_t)key + 1], t.hi);
-          }
-        } else if (valid) {  // integer limb accumulators (see qw_scatter_fp_kernel)
-          u64* acc = QW + 4 * (size_t)key;
-          atomicAdd(&acc[0], (u64)(u32)t.lo);
-          atomicAdd(&acc[1], t.lo >> 32);
-          atomicAdd(&acc[2], (u64)(u32)t.hi);
-          atomicAdd(&acc[3], t.hi >> 32);
+        for (int h = 0; h < 2; ++h)
+          for (u32 i = tid; i < nW[h]; i += SM_THREADS) st16(&wL[h * 2 * SC_TAIL + i], ld16(&W[h][i]));
+        for (u32 i = tid; i < qwords * nW[hand]; i += SM_THREADS) qwL[i] = QW[i];  // the sums of this evaluation
+        __syncthreads();
+        hc = hcL0; vc = vcL0; hc_o = hcL1; vc_o = vcL1;
+        for (int h = 0; h < 2; ++h) {
+          W[h] = wL + h * 2 * SC_TAIL;
+          Wdst[h][0] = wL + h * 2 * SC_TAIL + SC_TAIL;
+          Wdst[h][1] = wL + h * 2 * SC_TAIL + SC_TAIL + SC_TAIL / 2;
+          wsel[h] = 0;
         }
+        QW = qwL;
+        QWn = qwL;
+        src = (u32*)(qwL + 4 * SC_TAIL);
+        in_lds = true;
       }
     }
-    SC_LAP(0);
-    if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
+    const u32 GT = G * SM_THREADS, gtid = (wave * G + g) * 64 + lane;  // 64-entry chunks dealt round-robin: few entries = few waves on EVERY workgroup
     SC_LAP(1);
     // ---- ProverLayers::evaluations: a0, a2
     {
@@ -777,11 +831,9 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         if (tid == 0) {
           u64* sl = &gs->slots[4 * g];
           sl[0] = a0.lo; sl[1] = a0.hi; sl[2] = a2.lo; sl[3] = a2.hi;
-          __threadfence();
-          const u32 t = __hip_atomic_fetch_add(&gs->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          const u32 t = __hip_atomic_fetch_add(&gs->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);  // releases the slot
           s_last = t == G - 1 ? 1u : 0u;
           if (s_last) __hip_atomic_store(&gs->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __threadfence();
         }
         __syncthreads();
         poster = false;
@@ -816,7 +868,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
     // entries merge (pair / lone even / lone odd), where each result goes, the halved corner indices
     u32 my_off, my_end, new_nh;
     {
-      const u32 R = ((nh + G - 1) / G + SM_THREADS - 1) / SM_THREADS * SM_THREADS;  // range per workgroup, whole chunks
+      const u32 R = ((nh + G - 1) / G + 63) / 64 * 64;  // range per workgroup, whole waves
       const u32 lo = (u64)g * R < nh ? g * R : nh, hi = (u64)lo + R < nh ? lo + R : nh;
       if (tid == 0) {
         sh.carry = 0;
@@ -834,9 +886,9 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         if (lane == 0 && mine) atomicAdd(&sh.carry, mine);
         __syncthreads();
         if (tid == 0) a.counts[g] = sh.carry;
-        SC_LAP(4);
+        SC_LAP(3);
         if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
-        SC_LAP(5);
+        SC_LAP(4);
         if (tid < G) {
           const u32 cnt = a.counts[tid];
           if (cnt) {
@@ -878,25 +930,25 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       my_end = sh.carry;
       new_nh = G > 1 ? s_tot : my_end;
     }
-    SC_LAP(6);
+    SC_LAP(5);
     // ---- the challenge: workgroup 0 takes it from the host, the others from the device slot
     if (tid == 0) {
       const u64 t0 = wall_clock64();
       u64 got = 0;
       if (g == 0) {
-        for (;;) {
-          got = __hip_atomic_load((const u64*)&a.cmd[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (;;) {  // uncached pinned host memory: relaxed polls, the challenge words are read after the sequence word
+          got = __hip_atomic_load((const u64*)&a.cmd[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           if (got == seq) break;
           if (wall_clock64() - t0 > a.timeout_ticks) break;
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(1);
         }
         if (got == seq) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // orders the loads below after the poll (s_waitcnt only)
           sh.cmd[0] = __hip_atomic_load((const u64*)&a.cmd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           sh.cmd[1] = __hip_atomic_load((const u64*)&a.cmd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           if (G > 1) {
-            gs->chal[0] = sh.cmd[0];
-            gs->chal[1] = sh.cmd[1];
-            __threadfence();
+            __hip_atomic_store(&gs->chal[0], sh.cmd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&gs->chal[1], sh.cmd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&gs->chal_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           }
         } else {  // the host went away: release every workgroup and report
@@ -907,13 +959,13 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         }
       } else {
         for (;;) {
-          got = __hip_atomic_load(&gs->chal_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          got = __hip_atomic_load(&gs->chal_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (got == seq) break;
           if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
           if (wall_clock64() - t0 > 2 * a.timeout_ticks) break;
           __builtin_amdgcn_s_sleep(1);
         }
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         sh.cmd[0] = __hip_atomic_load(&gs->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sh.cmd[1] = __hip_atomic_load(&gs->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -922,44 +974,56 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
     __syncthreads();
     if (sh.cmd[2] != seq) return;  // uniform per workgroup; the barriers of the others see the abort flag
     const elt_t r{sh.cmd[0], sh.cmd[1]};
-    SC_LAP(3);
-    // ---- Dense::bind of W[hand] (out of place), clear QW, values of the HQUAD entries laid out above
+    SC_LAP(6);
+    // ---- Dense::bind of W[hand] (out of place); HQuad::bind_h values for the layout above; and, from those values,
+    // the next evaluation's sums QWn[h'[other]] += v' * bind(W[hand])[h'[hand]] -- the bound hand entry is recomputed
+    // from the unbound array (one more product) so that no workgroup waits for another one's Dense::bind
+    const elt_t* Wold = W[hand];
     const u32 n0 = nW[hand], nout = (n0 + 1) / 2;
+    auto bind_at = [&](u32 j) -> elt_t {
+      const elt_t f0 = ld16(&Wold[2 * j]);
+      if (2 * j + 1 < n0) return Fld<F>::add(f0, Fld<F>::mul(Fld<F>::sub(ld16(&Wold[2 * j + 1]), f0), r));
+      return Fld<F>::sub(f0, Fld<F>::mul(f0, r));
+    };
+    const bool more = rh + 1 < a.rh1;
+    if (QWn == QW) {  // one buffer (LDS tail, a single workgroup): this evaluation's sums are spent, clear for the next
+      for (u32 i = tid; i < qwords * nW[1 - hand]; i += SM_THREADS) QW[i] = 0;
+      __syncthreads();
+    } else {  // two buffers: this one is next written two round-hands from now, for this hand again
+      for (u32 i = gtid; i < qwords * nout; i += GT) QW[i] = 0;
+    }
     {
-      const elt_t* in = W[hand];
       elt_t* out = Wdst[hand][wsel[hand]];
-      for (u32 i = gtid; i < nout; i += GT) {
-        const elt_t f0 = ld16(&in[2 * i]);
-        elt_t v;
-        if (2 * i + 1 < n0) {
-          const elt_t f1 = ld16(&in[2 * i + 1]);
-          v = Fld<F>::add(f0, Fld<F>::mul(Fld<F>::sub(f1, f0), r));
-        } else {
-          v = Fld<F>::sub(f0, Fld<F>::mul(f0, r));
-        }
-        st16(&out[i], v);
-      }
+      for (u32 i = gtid; i < nout; i += GT) st16(&out[i], bind_at(i));
       W[hand] = out;
       nW[hand] = nout;
       wsel[hand] ^= 1;
     }
-    {
-      const u32 nnext = nW[(rh + 1) & 1];  // the next evaluation is for the other hand (sizes after this bind)
-      for (u32 i = gtid; i < qwords * nnext; i += GT) QW[i] = 0;
-    }
-    for (u32 o = my_off + tid; o < my_end; o += SM_THREADS) {  // HQuad::bind_h values (hquad.h:94-118)
-      const u32 sidx = src[o], i = sidx & 0x3fffffffu, kind = sidx >> 30;
-      const elt_t v0 = ld16(&vc[i]);
-      elt_t v;
-      if (kind == 0) {
-        const elt_t v1 = ld16(&vc[i + 1]);
-        v = Fld<F>::add(v0, Fld<F>::mul(Fld<F>::sub(v1, v0), r));
-      } else if (kind == 1) {
-        v = Fld<F>::sub(v0, Fld<F>::mul(v0, r));
-      } else {
-        v = Fld<F>::mul(v0, r);
+    for (u32 base = my_off; base < my_end; base += SM_THREADS) {  // HQuad::bind_h values (hquad.h:94-118)
+      const u32 o = base + tid;
+      const bool valid = o < my_end;
+      u32 key = 0xffffffffu;
+      elt_t t = elt_zero();
+      if (valid) {
+        const u32 sidx = src[o], i = sidx & 0x3fffffffu, kind = sidx >> 30;
+        const elt_t v0 = ld16(&vc[i]);
+        elt_t v;
+        if (kind == 0) {
+          const elt_t v1 = ld16(&vc[i + 1]);
+          v = Fld<F>::add(v0, Fld<F>::mul(Fld<F>::sub(v1, v0), r));
+        } else if (kind == 1) {
+          v = Fld<F>::sub(v0, Fld<F>::mul(v0, r));
+        } else {
+          v = Fld<F>::mul(v0, r);
+        }
+        st16(&vc_o[o], v);
+        if (more) {
+          const uint2 h = hc_o[o];
+          key = hand ? h.x : h.y;  // the next evaluation is for the other hand
+          t = Fld<F>::mul(v, bind_at(hand ? h.y : h.x));
+        }
       }
-      st16(&vc_o[o], v);
+      if (more) qw_add(QWn, key, t, valid);
     }
     {
       nh = new_nh;
@@ -969,50 +1033,11 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       vc = vc_o;
       hc_o = th;
       vc_o = tv;
+      u64* tq = QW;
+      QW = QWn;
+      QWn = tq;
     }
-    SC_LAP(6);
-    if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
     SC_LAP(7);
-    {  // shrink: one workgroup per 1024 entries of the largest array; the others are done
-      u32 big = nh > nW[0] ? nh : nW[0];
-      big = big > nW[1] ? big : nW[1];
-      u32 want = (big + SM_THREADS - 1) / SM_THREADS;
-      want = want ? want : 1;
-      if (want < G) G = want;
-      if (g >= G) return;
-      // tail: once everything fits (<= SC_TAIL entries) the last workgroup moves the whole state into LDS and the
-      // remaining rounds never touch global memory for data: every phase is then a product plus an LDS round trip
-      // instead of a product plus a global-memory round trip
-      if (G == 1 && !in_lds && a.tail_lds && big <= SC_TAIL) {
-        uint2* hcL0 = (uint2*)sc_dyn;                              // 2 x SC_TAIL corner pairs
-        uint2* hcL1 = hcL0 + SC_TAIL;
-        elt_t* vcL0 = (elt_t*)(hcL1 + SC_TAIL);                    // 2 x SC_TAIL values
-        elt_t* vcL1 = vcL0 + SC_TAIL;
-        elt_t* wL = vcL1 + SC_TAIL;                                // per hand: current (SC_TAIL) + two bind destinations (SC_TAIL / 2 each)
-        u64* qwL = (u64*)(wL + 4 * SC_TAIL);                        // SC_TAIL targets x up to 4 words
-        for (u32 i = tid; i < nh; i += SM_THREADS) {
-          hcL0[i] = hc[i];
-          st16(&vcL0[i], ld16(&vc[i]));
-        }
-        for (int h = 0; h < 2; ++h)
-          for (u32 i = tid; i < nW[h]; i += SM_THREADS) st16(&wL[h * 2 * SC_TAIL + i], ld16(&W[h][i]));
-        {
-          const u32 nnext = nW[(rh + 1) & 1];  // the global QW was cleared for the next evaluation: so is this one
-          for (u32 i = tid; i < qwords * nnext; i += SM_THREADS) qwL[i] = 0;
-        }
-        __syncthreads();
-        hc = hcL0; vc = vcL0; hc_o = hcL1; vc_o = vcL1;
-        for (int h = 0; h < 2; ++h) {
-          W[h] = wL + h * 2 * SC_TAIL;
-          Wdst[h][0] = wL + h * 2 * SC_TAIL + SC_TAIL;
-          Wdst[h][1] = wL + h * 2 * SC_TAIL + SC_TAIL + SC_TAIL / 2;
-          wsel[h] = 0;
-        }
-        QW = qwL;
-        src = (u32*)(qwL + 4 * SC_TAIL);
-        in_lds = true;
-      }
-    }
   }
 #ifdef LF_SC_PROF
   if (g == 0 && tid == 0)
@@ -1151,8 +1176,13 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
                      size_t logw, void* d_state) {
   const size_t big = std::max(nh, std::max(nW0, nW1));
   if (rh0 >= 2 * logw || big > LF_SC_GRID_MAX) return lf_fail(c, LFGPU_ERR_ARG, "sc_grid_begin: bad operands");
-  static_assert(sizeof(ScGridSync) + 4 * LF_SC_GRID_WGS + 4 * LF_SC_GRID_MAX <= LF_SC_GRID_STATE_BYTES, "grid state size");
-  u32 G = (u32)((big + SM_THREADS - 1) / SM_THREADS);
+  static_assert(sizeof(ScGridSync) + 4 * LF_SC_GRID_WGS + 36 * LF_SC_GRID_MAX <= LF_SC_GRID_STATE_BYTES, "grid state size");
+  // entries per active workgroup: a workgroup's share of the products runs on ONE CU, so fewer entries per workgroup
+  // buy shorter phases until the barrier among more workgroups costs more (measured: GF(2^128) products are ~4x the
+  // Fp128 ones, hence the smaller share)
+  static const int per_wg_env = getenv("LFGPU_SC_PER_WG") ? std::max(64, atoi(getenv("LFGPU_SC_PER_WG"))) : 0;
+  const u32 per_wg = per_wg_env ? (u32)per_wg_env : (field == LFGPU_FIELD_GF2_128 ? 512u : 1024u);
+  u32 G = (u32)((big + per_wg - 1) / per_wg);
   G = G ? G : 1;
   if (G > LF_SC_GRID_WGS) G = LF_SC_GRID_WGS;
   if ((int)G > c->num_cu) G = (u32)c->num_cu;
@@ -1174,7 +1204,8 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   a.cmd = c->poll_h + 64;
   a.gs = (ScGridSync*)d_state;
   a.counts = (u32*)((uint8_t*)d_state + sizeof(ScGridSync));
-  a.src = (u32*)((uint8_t*)d_state + LF_SC_GRID_STATE_BYTES - 4 * LF_SC_GRID_MAX);
+  a.src = (u32*)((uint8_t*)d_state + LF_SC_GRID_STATE_BYTES - 36 * LF_SC_GRID_MAX);
+  a.QW2 = (u64*)((uint8_t*)d_state + LF_SC_GRID_STATE_BYTES - 32 * LF_SC_GRID_MAX);
   LF_HIP(c, hipMemsetAsync(d_state, 0, 64, c->stream));  // counters, abort flag, challenge slot
   void* args[] = {&a};
   const void* fn = field == LFGPU_FIELD_GF2_128 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
@@ -1187,6 +1218,7 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
     (void)hipGetLastError();
   }
   a.tail_lds = (u32)tail_ok;
+  a.per_wg = per_wg;
   LF_HIP(c, hipLaunchCooperativeKernel(fn, dim3(G), dim3(SM_THREADS), args, tail_ok ? SC_TAIL_LDS_BYTES : 0, c->stream));
   return LFGPU_OK;
 }
@@ -1203,14 +1235,27 @@ int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]) {
   ++c->poll_next;
   for (int i = 0; i < 8; ++i) out[i] = c->poll_h[i];
 #ifdef LF_SC_PROF
+  {  // per round-hand arrival times against the HQUAD size (LFGPU_SC_TRACE=1)
+    static std::vector<std::pair<double, u64>> tr;
+    static const bool on = getenv("LFGPU_SC_TRACE") != nullptr;
+    if (on) {
+      tr.emplace_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(), c->poll_h[4]);
+      if (c->poll_next == c->poll_seq + 1) {
+        fprintf(stderr, "sc_trace:");
+        for (size_t i = 1; i < tr.size(); ++i) fprintf(stderr, " %llu:%.1f", (unsigned long long)tr[i - 1].second, tr[i].first - tr[i - 1].first);
+        fprintf(stderr, "\n");
+        tr.clear();
+      }
+    }
+  }
   if (c->poll_next == c->poll_seq + 1) {  // final post of a layer: fold the phase clocks
     static u64 tot[8];
     static int layers = 0;
     for (int k = 0; k < 8; ++k) tot[k] += c->poll_h[16 + k];
     if (++layers % 13 == 0) {
-      fprintf(stderr, "sc_grid phases (us, %d layers): scatter %.0f bar1 %.0f partials %.0f wait %.0f bind+values %.0f counts %.0f bar2 %.0f layout %.0f (bar3 in scatter)\n", layers,
+      fprintf(stderr, "sc_grid phases (us, %d layers): bar1 %.0f shrink %.0f sums+post %.0f counts %.0f bar2 %.0f layout %.0f wait %.0f bind+scatter %.0f\n", layers,
               tot[0] * 1e3 / c->wall_khz, tot[1] * 1e3 / c->wall_khz, tot[2] * 1e3 / c->wall_khz, tot[3] * 1e3 / c->wall_khz,
-              tot[7] * 1e3 / c->wall_khz, tot[4] * 1e3 / c->wall_khz, tot[5] * 1e3 / c->wall_khz, tot[6] * 1e3 / c->wall_khz);
+              tot[4] * 1e3 / c->wall_khz, tot[5] * 1e3 / c->wall_khz, tot[6] * 1e3 / c->wall_khz, tot[7] * 1e3 / c->wall_khz);
       for (int k = 0; k < 8; ++k) tot[k] = 0;
     }
   }
