@@ -223,6 +223,18 @@ int lfgpu_ligero_commit(lfgpu_ctx* ctx, int field, int subfield_log_bits, const 
 int lfgpu_ligero_low_degree_proof(lfgpu_ligero_prover* pr, const void* h_u_ldt, void* h_y);
 /* dot_proof (:293-309): y[dblock] = T[idot] + sum_i RS(block->dblock)([0^r | A_i]) (.) T[iw+i] */
 int lfgpu_ligero_dot_proof(lfgpu_ligero_prover* pr, const void* h_A, void* h_y);
+/* The same with the matrix A built on the device (inner_product_vector + layout_Aext, ligero_param.h:382-430):
+ *   A[t] = scale * d_dense[t] for t < ndense  (the private-input block of the last constraint: d_dense is the
+ *          device-resident EQ table of lfgpu_raw_eq2 past the public inputs, scale its alphal),
+ *   A[h_idx[t]] += h_val[t] for the nsparse remaining terms (host side: strictly increasing flat indices, duplicates
+ *          folded by the caller).
+ * lfgpu_ligero_inner_product_rows writes the rows [0^r | A_i] at stride ld into d_rows (nrows rows; the first r + w
+ * columns of every row are cleared first) -- what LigeroVerifier extends and compares (ligero_verifier.h:150-190). */
+int lfgpu_ligero_inner_product_rows(lfgpu_ctx* ctx, int field, size_t w, size_t r, size_t ld, size_t nrows, const void* d_dense,
+                                    size_t ndense, const uint64_t scale[2], const uint64_t* h_idx, const void* h_val,
+                                    size_t nsparse, void* d_rows);
+int lfgpu_ligero_dot_proof_sparse(lfgpu_ligero_prover* pr, const void* d_dense, size_t ndense, const uint64_t scale[2],
+                                  const uint64_t* h_idx, const void* h_val, size_t nsparse, void* h_y);
 /* quadratic_proof (:311-344); LFGPU_ERR_ASSERT if the W part of y is non-zero */
 int lfgpu_ligero_quadratic_proof(lfgpu_ligero_prover* pr, const void* h_u_quad, void* h_y0, void* h_y2);
 /* compute_req (:346-351) + MerkleCommitment::open (merkle_commitment.h:66-73) */

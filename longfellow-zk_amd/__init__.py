@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_field_binop", "lfgpu_fp128_fft_host", "lfgpu_gf2128_lch14_fft_host",
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
     "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
+    "lfgpu_ligero_inner_product_rows", "lfgpu_ligero_dot_proof_sparse",
     "lfgpu_ligero_quadratic_proof", "lfgpu_ligero_open", "lfgpu_ligero_tableau", "lfgpu_ligero_free",
     "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g", "lfgpu_sumcheck_layer", "lfgpu_raw_eq2", "lfgpu_quad_bind_gh_all",
     # include/lfgpu_zk.h
@@ -108,6 +109,8 @@ def load_library():
         "lfgpu_ligero_commit": [vp, ci, ci, C.POINTER(LigeroParam), vp, sz, vp, RNG_FN, vp, vp, C.POINTER(vp)],
         "lfgpu_ligero_low_degree_proof": [vp, vp, vp],
         "lfgpu_ligero_dot_proof": [vp, vp, vp],
+        "lfgpu_ligero_inner_product_rows": [vp, ci, sz, sz, sz, sz, vp, sz, vp, vp, vp, sz, vp],
+        "lfgpu_ligero_dot_proof_sparse": [vp, vp, sz, vp, vp, vp, sz, vp],
         "lfgpu_ligero_quadratic_proof": [vp, vp, vp, vp],
         "lfgpu_ligero_open": [vp, vp, vp, vp, vp, sz, C.POINTER(sz)],
         "lfgpu_ligero_tableau": [vp, C.POINTER(vp)],
@@ -355,6 +358,18 @@ class LigeroProver:
         y = np.zeros((self.p.dblock, 2), dtype=np.uint64)
         A = np.ascontiguousarray(A)
         self.gpu._ck(self.gpu.L.lfgpu_ligero_dot_proof(self.h, C.c_void_p(A.ctypes.data), C.c_void_p(y.ctypes.data)))
+        return y
+
+    def dot_proof_sparse(self, d_dense, ndense, scale, idx, val):
+        """dot_proof with A built on the device: A[t] = scale * d_dense[t] (device pointer), A[idx] += val."""
+        import numpy as np
+        y = np.zeros((self.p.dblock, 2), dtype=np.uint64)
+        sc = np.ascontiguousarray(scale, dtype=np.uint64)
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        val = np.ascontiguousarray(val, dtype=np.uint64)
+        self.gpu._ck(self.gpu.L.lfgpu_ligero_dot_proof_sparse(self.h, C.c_void_p(d_dense), ndense, C.c_void_p(sc.ctypes.data),
+                                                              C.c_void_p(idx.ctypes.data), C.c_void_p(val.ctypes.data), len(idx),
+                                                              C.c_void_p(y.ctypes.data)))
         return y
 
     def quadratic_proof(self, u_quad):

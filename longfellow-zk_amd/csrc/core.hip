@@ -180,6 +180,7 @@ int lfgpu_shutdown(lfgpu_ctx* c) {
   if (c->scratch3) hipFree(c->scratch3);
   if (c->lig_T) hipFree(c->lig_T);
   if (c->lig_L) hipFree(c->lig_L);
+  if (c->zk_eq) hipFree(c->zk_eq);
   if (c->mailbox_h) hipHostFree(c->mailbox_h);
   if (c->poll_h) hipHostFree((void*)c->poll_h);
   for (int i = 0; i < 4; ++i)

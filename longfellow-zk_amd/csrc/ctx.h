@@ -46,6 +46,10 @@ struct lfgpu_ctx {
   size_t lig_T_bytes = 0;
   void* lig_L = nullptr;
   size_t lig_L_bytes = 0;
+  // EQ table over the circuit inputs of the last verifier_constraints run (the dense block of the Ligero inner-product
+  // matrix is built from it on the device)
+  void* zk_eq = nullptr;
+  size_t zk_eq_bytes = 0;
   // pinned staging ring for small host tables that are uploaded without a stream synchronisation: slot i may be
   // rewritten once stage_ev[i] (recorded after its copy) has completed
   void* stage_h = nullptr;

@@ -379,6 +379,79 @@ extern "C" int lfgpu_ligero_low_degree_proof(lfgpu_ligero_prover* pr, const void
   return lfgpu_memcpy_d2h(c, h_y, dy, p.block * 16);
 }
 
+// ---- the inner-product matrix built on the device (inner_product_vector + layout_Aext, ligero_param.h:382-430)
+// rows[i][r + j] = scale * dense[i*w + j] over the first ndense flat positions (the private-input block of the last
+// constraint), then rows[pos(idx)] += val for the caller's sparse terms (duplicates already folded by the caller)
+template <int F>
+__global__ void a_rows_dense_kernel(u32 r, u32 w, size_t ld, elt_t scale, const elt_t* __restrict__ dense, size_t n,
+                                    elt_t* __restrict__ rows) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const size_t i = t / w, j = t % w;
+  st16(&rows[i * ld + r + j], Fld<F>::mul(scale, ld16(&dense[t])));
+}
+template <int F>
+__global__ void a_rows_sparse_kernel(u32 r, u32 w, size_t ld, const u64* __restrict__ idx, const elt_t* __restrict__ val, size_t n,
+                                     elt_t* __restrict__ rows) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const size_t i = idx[t] / w, j = idx[t] % w;
+  elt_t* dst = &rows[i * ld + r + j];
+  st16(dst, Fld<F>::add(ld16(dst), ld16(&val[t])));
+}
+
+extern "C" int lfgpu_ligero_inner_product_rows(lfgpu_ctx* c, int field, size_t w, size_t r, size_t ld, size_t nrows, const void* d_dense,
+                                               size_t ndense, const uint64_t scale[2], const uint64_t* h_idx, const void* h_val,
+                                               size_t nsparse, void* d_rows) {
+  if (!c || !d_rows || w == 0 || r + w > ld || (ndense && (!d_dense || !scale)) || (nsparse && (!h_idx || !h_val)) || ndense > nrows * w)
+    return lf_fail(c, LFGPU_ERR_ARG, "ligero_inner_product_rows: bad argument");
+  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "ligero_inner_product_rows: field");
+  for (size_t t = 0; t < nsparse; ++t) {
+    if (h_idx[t] >= nrows * w) return lf_fail(c, LFGPU_ERR_ARG, "ligero_inner_product_rows: sparse index out of range");
+    if (t && h_idx[t] <= h_idx[t - 1]) return lf_fail(c, LFGPU_ERR_ARG, "ligero_inner_product_rows: sparse indices must be strictly increasing");
+  }
+  LF_HIP(c, hipSetDevice(c->device));
+  LF_HIP(c, hipMemset2DAsync(d_rows, ld * 16, 0, (r + w) * 16, nrows, c->stream));
+  if (ndense) {
+    const elt_t sc{scale[0], scale[1]};
+    LIG_DISPATCH(field, a_rows_dense_kernel, dim3((u32)((ndense + 255) / 256)), dim3(256), (u32)r, (u32)w, ld, sc, (const elt_t*)d_dense, ndense,
+                 (elt_t*)d_rows);
+  }
+  if (nsparse) {
+    void* d_sp = nullptr;
+    LF_TRY(lf_scratch2(c, nsparse * 24 + 64, &d_sp));
+    elt_t* d_val = (elt_t*)d_sp;
+    u64* d_idx = (u64*)(d_val + nsparse);
+    if (nsparse * 24 <= LF_STAGE_SLOT) {  // one staged copy: values then indices
+      std::vector<uint8_t> pack(nsparse * 24);
+      memcpy(pack.data(), h_val, nsparse * 16);
+      memcpy(pack.data() + nsparse * 16, h_idx, nsparse * 8);
+      LF_TRY(lf_stage_upload(c, d_sp, pack.data(), pack.size()));
+    } else {
+      LF_HIP(c, hipMemcpyAsync(d_val, h_val, nsparse * 16, hipMemcpyHostToDevice, c->stream));
+      LF_HIP(c, hipMemcpyAsync(d_idx, h_idx, nsparse * 8, hipMemcpyHostToDevice, c->stream));
+      LF_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    LIG_DISPATCH(field, a_rows_sparse_kernel, dim3((u32)((nsparse + 255) / 256)), dim3(256), (u32)r, (u32)w, ld, (const u64*)d_idx,
+                 (const elt_t*)d_val, nsparse, (elt_t*)d_rows);
+  }
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
+// dot_proof once the rows [0^r | A_i | 0...] stand in dAext (lda = dblock): extend, combine, read back
+static int dot_proof_finish(lfgpu_ligero_prover* pr, elt_t* dAext, elt_t* dy, void* h_y) {
+  lfgpu_ctx* c = pr->c;
+  const lfgpu_ligero_param& p = pr->p;
+  const size_t lda = p.dblock;
+  LF_TRY(lf_rs_rows(c, pr->field, pr->k, p.nwqrow, p.block, p.dblock, dAext, lda));
+  LIG_DISPATCH(pr->field, rows_vaxpy_kernel, dim3((u32)((p.dblock + 63) / 64)), dim3(1024), (u32)p.nwqrow, p.dblock,
+               (const elt_t*)(pr->d_T + p.idot * p.block_enc), (const elt_t*)dAext, lda,
+               (const elt_t*)(pr->d_T + p.iw * p.block_enc), p.block_enc, dy);
+  LF_HIP(c, hipGetLastError());
+  return lfgpu_memcpy_d2h(c, h_y, dy, p.dblock * 16);
+}
+
 extern "C" int lfgpu_ligero_dot_proof(lfgpu_ligero_prover* pr, const void* h_A, void* h_y) {
   if (!pr || !h_A || !h_y) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = pr->c;
@@ -394,12 +467,28 @@ extern "C" int lfgpu_ligero_dot_proof(lfgpu_ligero_prover* pr, const void* h_A, 
   LF_HIP(c, hipMemsetAsync(dAext, 0, p.nwqrow * lda * 16, c->stream));
   hipLaunchKernelGGL(layout_aext_kernel, dim3((u32)((p.block + 255) / 256), (u32)p.nwqrow), dim3(256), 0, c->stream,
                      (u32)p.r, (u32)p.w, lda, (const elt_t*)dA, dAext);
-  LF_TRY(lf_rs_rows(c, pr->field, pr->k, p.nwqrow, p.block, p.dblock, dAext, lda));
-  LIG_DISPATCH(pr->field, rows_vaxpy_kernel, dim3((u32)((p.dblock + 63) / 64)), dim3(1024), (u32)p.nwqrow, p.dblock,
-               (const elt_t*)(pr->d_T + p.idot * p.block_enc), (const elt_t*)dAext, lda,
-               (const elt_t*)(pr->d_T + p.iw * p.block_enc), p.block_enc, dy);
-  LF_HIP(c, hipGetLastError());
-  return lfgpu_memcpy_d2h(c, h_y, dy, p.dblock * 16);
+  return dot_proof_finish(pr, dAext, dy, h_y);
+}
+
+extern "C" int lfgpu_ligero_dot_proof_sparse(lfgpu_ligero_prover* pr, const void* d_dense, size_t ndense, const uint64_t scale[2],
+                                             const uint64_t* h_idx, const void* h_val, size_t nsparse, void* h_y) {
+  if (!pr || !h_y) return LFGPU_ERR_ARG;
+  lfgpu_ctx* c = pr->c;
+  const lfgpu_ligero_param& p = pr->p;
+  LF_HIP(c, hipSetDevice(c->device));
+  const size_t lda = p.dblock;
+  void* sc = nullptr;
+  LF_TRY(lf_scratch3(c, (p.nwqrow * lda + p.dblock) * 16 + 64, &sc));
+  if (d_dense && ndense) {  // the dense block must not live in the scratch this call is about to overwrite
+    const uint8_t* lo = (const uint8_t*)sc;
+    const uint8_t* d = (const uint8_t*)d_dense;
+    if (d + ndense * 16 > lo && d < lo + (p.nwqrow * lda + p.dblock) * 16) return lf_fail(c, LFGPU_ERR_ARG, "ligero_dot_proof_sparse: dense block aliases scratch");
+  }
+  elt_t* dAext = (elt_t*)sc;
+  elt_t* dy = dAext + p.nwqrow * lda;
+  LF_HIP(c, hipMemsetAsync(dAext, 0, p.nwqrow * lda * 16, c->stream));
+  LF_TRY(lfgpu_ligero_inner_product_rows(c, pr->field, p.w, p.r, lda, p.nwqrow, d_dense, ndense, scale, h_idx, h_val, nsparse, dAext));
+  return dot_proof_finish(pr, dAext, dy, h_y);
 }
 
 extern "C" int lfgpu_ligero_quadratic_proof(lfgpu_ligero_prover* pr, const void* h_u_quad, void* h_y0, void* h_y2) {

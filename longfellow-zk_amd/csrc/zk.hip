@@ -11,6 +11,7 @@
 //   ZkProof::write                     lib/zk/zk_proof.h:90-185
 // Every data-parallel step is a kernel behind lfgpu.h (eval_quad, sumcheck_layer, raw_eq2, ligero_*); what runs
 // here is the sequential bookkeeping the reference also keeps on the host.  This file has no device code.
+#include <algorithm>
 #include <chrono>
 #include <memory>
 
@@ -404,7 +405,8 @@ struct LinTerm {
 struct ConstraintSet {
   std::vector<LinTerm> a;
   std::vector<elt_t> b;       // one entry per constraint
-  std::vector<elt_t> eq_in;   // EQ(g0, i) + alpha EQ(g1, i), i < ninputs: dense coefficients of the last constraint
+  std::vector<elt_t> eq_in;   // EQ(g0, i) + alpha EQ(g1, i) for the npub public inputs (folded into b)
+  const elt_t* d_eq = nullptr;  // the whole table, i < ninputs, on the device: dense coefficients of the last constraint
   size_t n = 0;               // number of constraints; the dense one is n - 1
 };
 int build_constraints(lfgpu_ctx* c, const lfgpu_circuit* C, const HostField& F, const Ts& ts, const std::vector<lfgpu_zk_prover::LayerPad>& proof,
@@ -492,13 +494,21 @@ int build_constraints(lfgpu_ctx* c, const lfgpu_circuit* C, const HostField& F, 
   out.a.push_back({ci, pi - 2, F.sub(elt_t{0, 0}, alpha)});
   out.n = ci + 1;
   // EQ table over the inputs on the device: public part folded into b, private part = dense block of A
-  out.eq_in.assign(I.ninputs, elt_t{0, 0});
+  out.eq_in.assign(npub, elt_t{0, 0});
   const size_t logn = C->layers[nl - 1].logw;
-  void* d_eq = nullptr;
-  LF_TRY(lf_scratch3(c, I.ninputs * 16, &d_eq));
+  if (c->zk_eq_bytes < I.ninputs * 16) {  // context-owned: stays valid until the next run on this context
+    LF_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->zk_eq) hipFree(c->zk_eq);
+    c->zk_eq = nullptr;
+    c->zk_eq_bytes = 0;
+    if (hipMalloc(&c->zk_eq, I.ninputs * 16) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "zk: EQ table over the inputs");
+    c->zk_eq_bytes = I.ninputs * 16;
+  }
+  void* d_eq = c->zk_eq;
   const uint64_t al[2] = {alpha.lo, alpha.hi};
   LF_TRY(lfgpu_raw_eq2(c, I.field, logn, I.ninputs, gh[0].data(), gh[1].data(), al, d_eq));
-  LF_HIP(c, hipMemcpyAsync(out.eq_in.data(), d_eq, I.ninputs * 16, hipMemcpyDeviceToHost, c->stream));
+  out.d_eq = (const elt_t*)d_eq;
+  if (npub) LF_HIP(c, hipMemcpyAsync(out.eq_in.data(), d_eq, npub * 16, hipMemcpyDeviceToHost, c->stream));
   LF_HIP(c, hipStreamSynchronize(c->stream));
   const auto& P = proof[nl - 1];
   elt_t pub_binding{0, 0};
@@ -507,24 +517,33 @@ int build_constraints(lfgpu_ctx* c, const lfgpu_circuit* C, const HostField& F, 
   return LFGPU_OK;
 }
 
-// LigeroCommon::inner_product_vector (lib/ligero/ligero_param.h:382-421): A[nwqrow][w] from the linear constraints
-// (sparse terms + the dense private-input block), alphal, the quadratic constraints and alphaq
-void inner_product_vector(const HostField& F, std::vector<elt_t>& A, const lfgpu_ligero_param& p, const ConstraintSet& cs, size_t npub,
-                          size_t n_witness, const std::vector<elt_t>& alphal, const std::vector<size_t>& lqc, const std::vector<elt_t>& alphaq) {
-  A.assign(p.nwqrow * p.w, elt_t{0, 0});
-  const elt_t ad = alphal[cs.n - 1];
-  for (size_t w = 0; w < n_witness; ++w) A[w] = F.mul(ad, cs.eq_in[npub + w]);
-  for (const LinTerm& t : cs.a) A[t.w] = F.add(A[t.w], F.mul(t.k, alphal[t.c]));
-  // quadratic constraints W[x] * W[y] = W[z] live in their own rows: copy constraints tie them to the witness rows
-  // (A[copy] += aq, A[original] -= aq)
+// LigeroCommon::inner_product_vector (lib/ligero/ligero_param.h:382-421), host share: the sparse terms of A[nwqrow][w]
+// -- the linear constraints' terms times alphal and the quadratic copy constraints (A[copy] += aq, A[original] -= aq) --
+// as (flat index, value) pairs, sorted with duplicates folded.  The dense private-input block alphal[n-1] * EQ[npub + w]
+// is built on the device (lfgpu_ligero_inner_product_rows); the sums commute, so the result is the reference's A.
+void inner_product_sparse(const HostField& F, const lfgpu_ligero_param& p, const ConstraintSet& cs, const std::vector<elt_t>& alphal,
+                          const std::vector<size_t>& lqc, const std::vector<elt_t>& alphaq, std::vector<uint64_t>& idx, std::vector<elt_t>& val) {
+  std::vector<std::pair<uint64_t, elt_t>> t;
+  t.reserve(cs.a.size() + 6 * p.nq);
+  for (const LinTerm& l : cs.a) t.emplace_back((uint64_t)l.w, F.mul(l.k, alphal[l.c]));
   const size_t base = p.nwrow * p.w;
   const size_t Ax = base, Ay = base + p.nqtriples * p.w, Az = base + 2 * p.nqtriples * p.w;
   for (size_t iw = 0; iw < p.nq; ++iw) {
     const size_t off[3] = {Ax + iw, Ay + iw, Az + iw};
     for (int j = 0; j < 3; ++j) {
       const elt_t aq = alphaq[3 * iw + j];
-      A[off[j]] = F.add(A[off[j]], aq);
-      A[lqc[3 * iw + j]] = F.sub(A[lqc[3 * iw + j]], aq);
+      t.emplace_back((uint64_t)off[j], aq);
+      t.emplace_back((uint64_t)lqc[3 * iw + j], F.sub(elt_t{0, 0}, aq));
+    }
+  }
+  std::stable_sort(t.begin(), t.end(), [](const std::pair<uint64_t, elt_t>& a, const std::pair<uint64_t, elt_t>& b) { return a.first < b.first; });
+  idx.clear();
+  val.clear();
+  for (const auto& e : t) {
+    if (!idx.empty() && idx.back() == e.first) val.back() = F.add(val.back(), e.second);
+    else {
+      idx.push_back(e.first);
+      val.push_back(e.second);
     }
   }
 }
@@ -731,11 +750,16 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
     std::vector<elt_t> alphal(nconstraints), alphaq(3 * p.nq);
     for (auto& e : alphal) e = ts.elt();
     for (auto& e : alphaq) e = ts.elt();
-    std::vector<elt_t> A;
-    inner_product_vector(F, A, p, cs, zk->npub, zk->n_witness, alphal, zk->lqc, alphaq);
+    std::vector<uint64_t> a_idx;
+    std::vector<elt_t> a_val;
+    inner_product_sparse(F, p, cs, alphal, zk->lqc, alphaq, a_idx, a_val);
     zk->y_dot.assign(p.dblock, elt_t{0, 0});
     tq[2] = now_ms();
-    LF_TRY(lfgpu_ligero_dot_proof(zk->lp, A.data(), zk->y_dot.data()));
+    {
+      const elt_t ad = alphal[cs.n - 1];
+      const uint64_t sc[2] = {ad.lo, ad.hi};
+      LF_TRY(lfgpu_ligero_dot_proof_sparse(zk->lp, cs.d_eq + zk->npub, zk->n_witness, sc, a_idx.data(), a_val.data(), a_idx.size(), zk->y_dot.data()));
+    }
     tq[3] = now_ms();
     std::vector<elt_t> u_quad(p.nqtriples ? p.nqtriples : 1);
     for (size_t i = 0; i < p.nqtriples; ++i) u_quad[i] = ts.elt();
@@ -756,7 +780,7 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
     LF_TRY(lfgpu_ligero_open(zk->lp, idx.data(), zk->req.data(), zk->nonces.data(), zk->path.data(), cap, &zk->npath));
     tq[5] = now_ms();
     if (verbose)
-      fprintf(stderr, "lfgpu zk ligero_prove: ldt %.2f ms | host A vector %.2f | dot %.2f | quad %.2f | challenges+open %.2f\n", tq[1] - tq[0],
+      fprintf(stderr, "lfgpu zk ligero_prove: ldt %.2f ms | sparse terms of A %.2f | dot %.2f | quad %.2f | challenges+open %.2f\n", tq[1] - tq[0],
               tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4]);
   }
   zk->ms[5] = now_ms() - t0;
@@ -1089,8 +1113,9 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
 
   tv[3] = now_ms();
   // device: rows [0, nwqrow) = [0^r | A_i] extended block -> block_enc, rows nwqrow.. = y_ldt, y_dot, y_quad
-  std::vector<elt_t> A;
-  inner_product_vector(F, A, p, cs, npub, n_witness, alphal, lqc, alphaq);
+  std::vector<uint64_t> a_idx;
+  std::vector<elt_t> a_val;
+  inner_product_sparse(F, p, cs, alphal, lqc, alphaq, a_idx, a_val);
   const size_t nrows_dev = p.nwqrow + 3, ld = p.block_enc;
   void* dT = nullptr;
   LF_TRY(lf_scratch(c, (nrows_dev * ld + (size_t)nrows_dev * p.nreq) * 16 + 256, &dT));
@@ -1098,7 +1123,11 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   elt_t* d_req = d_T + nrows_dev * ld;
   {  // only the first dblock columns of a row are inputs: clear them on the device, then strided copies
     LF_HIP(c, hipMemset2DAsync(d_T, ld * 16, 0, p.dblock * 16, nrows_dev, c->stream));
-    LF_HIP(c, hipMemcpy2DAsync(d_T + p.r, ld * 16, A.data(), p.w * 16, p.w * 16, p.nwqrow, hipMemcpyHostToDevice, c->stream));  // layout_Aext
+    {  // inner_product_vector + layout_Aext on the device
+      const elt_t ad = alphal[cs.n - 1];
+      const uint64_t sc[2] = {ad.lo, ad.hi};
+      LF_TRY(lfgpu_ligero_inner_product_rows(c, field, p.w, p.r, ld, p.nwqrow, cs.d_eq + npub, n_witness, sc, a_idx.data(), a_val.data(), a_idx.size(), d_T));
+    }
     LF_HIP(c, hipMemcpyAsync(d_T + (p.nwqrow + 0) * ld, pr.y_ldt.data(), p.block * 16, hipMemcpyHostToDevice, c->stream));
     LF_HIP(c, hipMemcpyAsync(d_T + (p.nwqrow + 1) * ld, pr.y_dot.data(), p.dblock * 16, hipMemcpyHostToDevice, c->stream));
     elt_t* yq = d_T + (p.nwqrow + 2) * ld;  // y_quad = y_quad_0 | 0^w | y_quad_2

@@ -480,6 +480,24 @@ def test_ligero_prove_pieces_vs_oracle(G, field):
             o.lfo_fp_rs_interpolate(p.block, p.dblock, P(ext))
         o.lfo_vaxpy(field, p.dblock, P(want), P(ext), P(np.ascontiguousarray(T[p.iw + i, :p.dblock])))
     assert (pr.dot_proof(A) == want).all()
+    # the same A handed over as dense block (on the device) x scale + sorted sparse terms (inner_product_vector on the device)
+    nd = (p.nwqrow * p.w) // 2 + 3
+    dense = ol.rand_elts(rng, nd, field)
+    scale = ol.rand_elts(rng, 1, field)[0]
+    sp_idx = np.sort(rng.choice(p.nwqrow * p.w, size=57, replace=False)).astype(np.uint64)
+    sp_idx[0], sp_idx[-1] = 0, p.nwqrow * p.w - 1
+    sp_idx = np.unique(sp_idx)
+    sp_val = ol.rand_elts(rng, len(sp_idx), field)
+    A2 = np.zeros((p.nwqrow * p.w, 2), dtype=np.uint64)
+    for t in range(nd):
+        A2[t] = arr(o.lfo_mul(field, elt(scale), elt(dense[t])))
+    for t, i in enumerate(sp_idx):
+        A2[int(i)] = arr(o.lfo_add(field, elt(A2[int(i)]), elt(sp_val[t])))
+    d_dense = G.to_dev(dense)
+    got = pr.dot_proof_sparse(d_dense.data_ptr(), nd, scale, sp_idx, sp_val)
+    assert (got == pr.dot_proof(A2)).all()
+    with pytest.raises(pkg.LfGpuError):  # unsorted sparse indices are refused
+        pr.dot_proof_sparse(d_dense.data_ptr(), nd, scale, sp_idx[::-1].copy(), sp_val)
     # quadratic
     uq = ol.rand_elts(rng, p.nqtriples, field)
     y = T[p.iquad, :p.dblock].copy()
