@@ -15,6 +15,7 @@
 #include <numeric>
 
 #include "ctx.h"
+#include <chrono>
 
 #define QD_THREADS 256
 
@@ -447,6 +448,8 @@ extern "C" int lfgpu_quad_bind_gh_all(lfgpu_quad* q, size_t logv, const void* h_
     return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_gh_all: table sizes");
   LF_HIP(c, hipSetDevice(c->device));
   const int field = q->field;
+  static const bool verbose_gh = getenv("LFGPU_VERBOSE") != nullptr;
+  const auto tgh0 = std::chrono::steady_clock::now();
   void* sc = nullptr;
   LF_TRY(lf_scratch3(c, (q->nv + 2 * nw) * 16 + 64, &sc));
   elt_t* d_eqg = (elt_t*)sc;
@@ -468,6 +471,9 @@ extern "C" int lfgpu_quad_bind_gh_all(lfgpu_quad* q, size_t logv, const void* h_
   u64 w[4];
   LF_HIP(c, hipMemcpyAsync(w, d_acc, 32, hipMemcpyDeviceToHost, c->stream));
   LF_HIP(c, hipStreamSynchronize(c->stream));
+  if (verbose_gh)
+    fprintf(stderr, "lfgpu bind_gh_all: nterms %zu nv %zu nw %zu | %.0f us\n", q->n, q->nv, nw,
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tgh0).count());
   if (field == LFGPU_FIELD_GF2_128) {
     out[0] = w[0];
     out[1] = w[1];
@@ -484,8 +490,6 @@ extern "C" int lfgpu_sumcheck_partials(lfgpu_ctx*, int, size_t, const void*, con
 extern "C" int lfgpu_qw_scatter(lfgpu_ctx*, int, size_t, const void*, const void*, int, const void*, size_t, void*);
 extern "C" int lfgpu_dense_bind(lfgpu_ctx*, int, size_t, const uint64_t*, const void*, void*);
 extern "C" int lfgpu_hquad_bind_h(lfgpu_ctx*, int, size_t, const void*, const void*, const uint64_t*, int, void*, void*, size_t*);
-
-#include <chrono>
 
 #include "hostfield.h"
 

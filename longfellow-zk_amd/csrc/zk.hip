@@ -337,12 +337,14 @@ struct lfgpu_zk_prover {
   // device buffers of the layer inputs (eval_circuit) and the circuit output
   std::vector<void*> d_in;
   void* d_V = nullptr;
+  void* h_V = nullptr;  // pinned: outputs (nv elements) then the assert-zero flag, read back without blocking the host
   double ms[6] = {0, 0, 0, 0, 0, 0};
   ~lfgpu_zk_prover() {
     if (lp) lfgpu_ligero_free(lp);
     for (void* p : d_in)
       if (p) (void)hipFree(p);
     if (d_V) (void)hipFree(d_V);
+    if (h_V) (void)hipHostFree(h_V);
   }
 };
 
@@ -570,6 +572,7 @@ extern "C" int lfgpu_zk_prover_new(lfgpu_ctx* c, const lfgpu_circuit* C, size_t 
   for (size_t l = 0; l < C->layers.size(); ++l)
     if (hipMalloc(&zk->d_in[l], C->layers[l].nw * 16) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "zk: layer %zu inputs", l);
   if (hipMalloc(&zk->d_V, C->info.nv * 16) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "zk: outputs");
+  if (hipHostMalloc(&zk->h_V, C->info.nv * 16 + 16, hipHostMallocDefault) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "zk: pinned outputs");
   *out = zk.release();
   return LFGPU_OK;
 }
@@ -652,6 +655,23 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
   zk->have_proof = false;
   LF_HIP(c, hipSetDevice(c->device));
 
+  // eval_circuit (prover_layers.h:52-104): layer inputs stay resident for the sumcheck
+  // The device works through all layers back to back (assert-zero failures and the outputs are read once at the end)
+  // while the host hashes the Fiat-Shamir preamble below -- SHA-256 over nterms zero bytes is sequential host work the
+  // reference's transcript format fixes, and the evaluation does not depend on it.
+  double t0 = now_ms();
+  const elt_t* V = (const elt_t*)zk->h_V;
+  const int* failed = (const int*)((const uint8_t*)zk->h_V + I.nv * 16);
+  {
+    LF_HIP(c, hipMemcpyAsync(zk->d_in[nl - 1], W, I.ninputs * 16, hipMemcpyHostToDevice, c->stream));
+    int* d_fail = (int*)((uint8_t*)c->mailbox_d + 128);
+    LF_HIP(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
+    for (size_t l = nl; l-- > 0;) LF_TRY(lf_eval_quad_async(C->layers[l].q, zk->d_in[l], l ? zk->d_in[l - 1] : zk->d_V, d_fail));
+    LF_HIP(c, hipMemcpyAsync(zk->h_V, zk->d_V, I.nv * 16, hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(c, hipMemcpyAsync((uint8_t*)zk->h_V + I.nv * 16, d_fail, 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  const double t_enq = now_ms() - t0;
+
   // initialize_sumcheck_fiat_shamir (zk_common.h:163-180)
   ts.write_bytes(I.id, 32);
   for (size_t i = 0; i < zk->npub; ++i) ts.write_elt(W[i]);
@@ -661,7 +681,10 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
     ts.write_bytes(z.data(), z.size());
   }
   void* cl = tso->clone(tso->user);
-  if (!cl) return lf_fail(c, LFGPU_ERR_NOMEM, "zk_prove: transcript clone");
+  if (!cl) {
+    hipStreamSynchronize(c->stream);
+    return lf_fail(c, LFGPU_ERR_NOMEM, "zk_prove: transcript clone");
+  }
   struct CloneGuard {
     const lfgpu_transcript_ops* o;
     void* u;
@@ -669,23 +692,12 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
   } cg{tso, cl};
   const Ts tst{tso, cl, I.field};
 
-  // eval_circuit (prover_layers.h:52-104): layer inputs stay resident for the sumcheck
-  double t0 = now_ms();
-  LF_HIP(c, hipMemcpyAsync(zk->d_in[nl - 1], W, I.ninputs * 16, hipMemcpyHostToDevice, c->stream));
-  {  // all layers back to back; assert-zero failures and the outputs are read once at the end
-    int* d_fail = (int*)((uint8_t*)c->mailbox_d + 128);
-    LF_HIP(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
-    for (size_t l = nl; l-- > 0;) LF_TRY(lf_eval_quad_async(C->layers[l].q, zk->d_in[l], l ? zk->d_in[l - 1] : zk->d_V, d_fail));
-    std::vector<elt_t> V(I.nv);
-    int failed = 0;
-    LF_HIP(c, hipMemcpyAsync(V.data(), zk->d_V, I.nv * 16, hipMemcpyDeviceToHost, c->stream));
-    LF_HIP(c, hipMemcpyAsync(&failed, d_fail, 4, hipMemcpyDeviceToHost, c->stream));
-    LF_HIP(c, hipStreamSynchronize(c->stream));
-    if (failed) return LFGPU_OK;  // an assert-zero term is non-zero: eval_circuit returns nullptr
-    for (const elt_t& v : V)
-      if (v.lo | v.hi) return LFGPU_OK;  // "V->v_[i] != F.zero()"
-  }
-  zk->ms[2] = now_ms() - t0;
+  t0 = now_ms();
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  if (*failed) return LFGPU_OK;  // an assert-zero term is non-zero: eval_circuit returns nullptr
+  for (size_t i = 0; i < I.nv; ++i)
+    if (V[i].lo | V[i].hi) return LFGPU_OK;  // "V->v_[i] != F.zero()"
+  zk->ms[2] = t_enq + now_ms() - t0;  // what the evaluation adds to the wall time: enqueue + the wait left after the hashing
 
   // padded sumcheck (ProverLayers::prove with pad, transcript copy tst)
   t0 = now_ms();
