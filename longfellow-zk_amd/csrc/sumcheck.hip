@@ -604,6 +604,7 @@ struct ScGrid {
   u32* counts;      // one word per workgroup
   u32* src;         // one word per HQUAD entry: where each bound entry comes from
   u32 tail_lds;     // 1: the launch reserved SC_TAIL_LDS_BYTES of dynamic LDS for the tail
+  u32 split_waves;  // 1: with one workgroup left, independent products go to different waves
   u32 per_wg;       // entries of the largest array per active workgroup (the grid shrinks to keep it)
 };
 #define SC_TAIL 1024u
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sc_dyn[];
   u32 gen = 0;
   u64 seq = a.seq0;
+  const bool split_waves = a.split_waves != 0;
   // QW[key] += t for one term per lane; every lane of the wave calls it (valid = false for the idle ones)
   auto qw_add = [&](u64* Q, u32 key, elt_t t, bool valid) {
     if (F == FIELD_GF2_128) {  // fold runs of equal targets inside the wave first (see qw_scatter_gf_kernel)
@@ -730,7 +732,11 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
 #ifdef LF_SC_PROF
   u64 pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   u64 tl = wall_clock64();
+#ifdef LF_SC_PROF_SMALL  // only the round-hands whose arrays hold <= 64 entries: the fixed cost of a round-hand
+#define SC_LAP(k) do { const u64 tn_ = wall_clock64(); if (nh <= 64 && nW[0] <= 64 && nW[1] <= 64) pt[k] += tn_ - tl; tl = tn_; } while (0)
+#else
 #define SC_LAP(k) do { const u64 tn_ = wall_clock64(); pt[k] += tn_ - tl; tl = tn_; } while (0)
+#endif
 #else
 #define SC_LAP(k) do { } while (0)
 #endif
@@ -790,16 +796,31 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         return fp_reduce_limbs(q[0], q[1], q[2], q[3]);
       };
       elt_t a0 = elt_zero(), a2 = elt_zero();
-      for (u32 i = gtid; i < nodd; i += GT) {
-        const elt_t q0 = qw_at(2 * i), q1 = qw_at(2 * i + 1);
-        const elt_t w0 = ld16(&Wh[2 * i]), w1 = ld16(&Wh[2 * i + 1]);
-        a0 = Fld<F>::add(a0, Fld<F>::mul(q0, w0));
-        a2 = Fld<F>::add(a2, Fld<F>::mul(Fld<F>::sub(q1, q0), Fld<F>::sub(w1, w0)));
-      }
-      if (gtid == 0 && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388)
-        const elt_t t = Fld<F>::mul(qw_at(2 * nodd), ld16(&Wh[2 * nodd]));
-        a0 = Fld<F>::add(a0, t);
-        a2 = Fld<F>::add(a2, t);
+      if (G == 1 && split_waves) {  // the two products of a pair on different waves (see the bind phase): even waves sum a0, odd waves a2
+        const u32 half = SM_THREADS / 2, ht = (wave >> 1) * 64 + lane;
+        const bool second = (wave & 1) != 0;
+        for (u32 i = ht; i < nodd; i += half) {
+          const elt_t q0 = qw_at(2 * i), w0 = ld16(&Wh[2 * i]);
+          if (!second) a0 = Fld<F>::add(a0, Fld<F>::mul(q0, w0));
+          else a2 = Fld<F>::add(a2, Fld<F>::mul(Fld<F>::sub(qw_at(2 * i + 1), q0), Fld<F>::sub(ld16(&Wh[2 * i + 1]), w0)));
+        }
+        if (ht == 0 && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388): in both sums
+          const elt_t t = Fld<F>::mul(qw_at(2 * nodd), ld16(&Wh[2 * nodd]));
+          if (!second) a0 = Fld<F>::add(a0, t);
+          else a2 = Fld<F>::add(a2, t);
+        }
+      } else {
+        for (u32 i = gtid; i < nodd; i += GT) {
+          const elt_t q0 = qw_at(2 * i), q1 = qw_at(2 * i + 1);
+          const elt_t w0 = ld16(&Wh[2 * i]), w1 = ld16(&Wh[2 * i + 1]);
+          a0 = Fld<F>::add(a0, Fld<F>::mul(q0, w0));
+          a2 = Fld<F>::add(a2, Fld<F>::mul(Fld<F>::sub(q1, q0), Fld<F>::sub(w1, w0)));
+        }
+        if (gtid == 0 && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388)
+          const elt_t t = Fld<F>::mul(qw_at(2 * nodd), ld16(&Wh[2 * nodd]));
+          a0 = Fld<F>::add(a0, t);
+          a2 = Fld<F>::add(a2, t);
+        }
       }
       // workgroup sum (wave shuffles, then the 16 wave sums through LDS)
       auto wg_sum = [&](elt_t& x0, elt_t& x2) {
@@ -992,39 +1013,63 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
     } else {  // two buffers: this one is next written two round-hands from now, for this hand again
       for (u32 i = gtid; i < qwords * nout; i += GT) QW[i] = 0;
     }
-    {
-      elt_t* out = Wdst[hand][wsel[hand]];
-      for (u32 i = gtid; i < nout; i += GT) st16(&out[i], bind_at(i));
-      W[hand] = out;
-      nW[hand] = nout;
-      wsel[hand] ^= 1;
-    }
-    for (u32 base = my_off; base < my_end; base += SM_THREADS) {  // HQuad::bind_h values (hquad.h:94-118)
-      const u32 o = base + tid;
-      const bool valid = o < my_end;
-      u32 key = 0xffffffffu;
-      elt_t t = elt_zero();
-      if (valid) {
-        const u32 sidx = src[o], i = sidx & 0x3fffffffu, kind = sidx >> 30;
-        const elt_t v0 = ld16(&vc[i]);
-        elt_t v;
-        if (kind == 0) {
-          const elt_t v1 = ld16(&vc[i + 1]);
-          v = Fld<F>::add(v0, Fld<F>::mul(Fld<F>::sub(v1, v0), r));
-        } else if (kind == 1) {
-          v = Fld<F>::sub(v0, Fld<F>::mul(v0, r));
-        } else {
-          v = Fld<F>::mul(v0, r);
-        }
-        st16(&vc_o[o], v);
-        if (more) {
-          const uint2 h = hc_o[o];
-          key = hand ? h.x : h.y;  // the next evaluation is for the other hand
-          t = Fld<F>::mul(v, bind_at(hand ? h.y : h.x));
+    auto bind_value = [&](u32 o) -> elt_t {  // HQuad::bind_h value of output o (hquad.h:94-118)
+      const u32 sidx = src[o], i = sidx & 0x3fffffffu, kind = sidx >> 30;
+      const elt_t v0 = ld16(&vc[i]);
+      if (kind == 0) return Fld<F>::add(v0, Fld<F>::mul(Fld<F>::sub(ld16(&vc[i + 1]), v0), r));
+      if (kind == 1) return Fld<F>::sub(v0, Fld<F>::mul(v0, r));
+      return Fld<F>::mul(v0, r);
+    };
+    elt_t* const Wout = Wdst[hand][wsel[hand]];
+    if (G == 1 && split_waves) {
+      // One workgroup left: what counts is the longest chain of products a single wave issues (a wave issues one
+      // instruction at a time, ~1.5 us per GF(2^128) product), so the independent products go to different waves --
+      // the even waves bind the HQUAD values while the odd waves bind the hand array -- and, a workgroup barrier being cheap,
+      // the next evaluation's sums take the bound hand entries from memory instead of recomputing them.
+      const u32 half = SM_THREADS / 2, ht = (wave >> 1) * 64 + lane;  // even / odd waves sit on different SIMDs
+      if ((wave & 1) == 0) {
+        for (u32 o = ht; o < my_end; o += half) st16(&vc_o[o], bind_value(o));
+      } else {
+        for (u32 i = ht; i < nout; i += half) st16(&Wout[i], bind_at(i));
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (more) {
+        for (u32 base = 0; base < my_end; base += SM_THREADS) {
+          const u32 o = base + tid;
+          const bool valid = o < my_end;
+          u32 key = 0xffffffffu;
+          elt_t t = elt_zero();
+          if (valid) {
+            const uint2 h = hc_o[o];
+            key = hand ? h.x : h.y;  // the next evaluation is for the other hand
+            t = Fld<F>::mul(ld16(&vc_o[o]), ld16(&Wout[hand ? h.y : h.x]));
+          }
+          qw_add(QWn, key, t, valid);
         }
       }
-      if (more) qw_add(QWn, key, t, valid);
+    } else {
+      for (u32 i = gtid; i < nout; i += GT) st16(&Wout[i], bind_at(i));
+      for (u32 base = my_off; base < my_end; base += SM_THREADS) {
+        const u32 o = base + tid;
+        const bool valid = o < my_end;
+        u32 key = 0xffffffffu;
+        elt_t t = elt_zero();
+        if (valid) {
+          const elt_t v = bind_value(o);
+          st16(&vc_o[o], v);
+          if (more) {
+            const uint2 h = hc_o[o];
+            key = hand ? h.x : h.y;  // the next evaluation is for the other hand
+            t = Fld<F>::mul(v, bind_at(hand ? h.y : h.x));
+          }
+        }
+        if (more) qw_add(QWn, key, t, valid);
+      }
     }
+    W[hand] = Wout;
+    nW[hand] = nout;
+    wsel[hand] ^= 1;
     {
       nh = new_nh;
       uint2* th = const_cast<uint2*>(hc);
@@ -1219,6 +1264,8 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   }
   a.tail_lds = (u32)tail_ok;
   a.per_wg = per_wg;
+  static const int split_env = getenv("LFGPU_SC_SPLIT") ? atoi(getenv("LFGPU_SC_SPLIT")) : -1;
+  a.split_waves = split_env >= 0 ? (u32)split_env : 1u;
   LF_HIP(c, hipLaunchCooperativeKernel(fn, dim3(G), dim3(SM_THREADS), args, tail_ok ? SC_TAIL_LDS_BYTES : 0, c->stream));
   return LFGPU_OK;
 }
