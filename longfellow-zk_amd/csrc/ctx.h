@@ -125,8 +125,8 @@ bool lf_sc_resident_ok(lfgpu_ctx* c);
 int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, void* W0, size_t nW0,
                      void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
                      size_t logw, void* d_state);
-#define LF_SC_GRID_WGS 64                          // most workgroups the shrinking-grid kernel starts with
-#define LF_SC_GRID_MAX (LF_SC_GRID_WGS * 1024)     // largest HQUAD / hand array it takes
+#define LF_SC_GRID_WGS 128                         // most workgroups the shrinking-grid kernel starts with
+#define LF_SC_GRID_MAX (256 * 1024)             // largest HQUAD / hand array it takes
 #define LF_SC_GRID_STATE_BYTES (64 + 32 * LF_SC_GRID_WGS + 4 * LF_SC_GRID_WGS + 64 + 36 * LF_SC_GRID_MAX)
 #define LF_SC_SMALL_MAX 8192  // largest HQUAD / hand array the single-workgroup step takes
 

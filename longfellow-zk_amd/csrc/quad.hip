@@ -551,7 +551,12 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   }();
   const bool no_fuse = sc_mode == 0;
   const bool use_resident = sc_mode >= 2 && lf_sc_resident_ok(c);
-  const size_t small_max = (sc_mode == 3 && use_resident) ? LF_SC_GRID_MAX : LF_SC_SMALL_MAX;
+  static const size_t grid_max = [] {  // hand-off point to the shrinking grid (entries of the largest array)
+    const char* e = getenv("LFGPU_SC_GRID_MAX");
+    const size_t v = e ? (size_t)atol(e) : (size_t)128 * 1024;
+    return std::min<size_t>(std::max<size_t>(v, 1024), LF_SC_GRID_MAX);
+  }();
+  const size_t small_max = (sc_mode == 3 && use_resident) ? grid_max : LF_SC_SMALL_MAX;
   bool resident = false, have_r = false;
   u64 last_r[2] = {0, 0};
   bool small = false, pending = false;  // pending: the binds of (phand, pr) ride in the next fused step

@@ -1229,7 +1229,8 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   const u32 per_wg = per_wg_env ? (u32)per_wg_env : (field == LFGPU_FIELD_GF2_128 ? 512u : 1024u);
   u32 G = (u32)((big + per_wg - 1) / per_wg);
   G = G ? G : 1;
-  if (G > LF_SC_GRID_WGS) G = LF_SC_GRID_WGS;
+  static const u32 wgs_cap = getenv("LFGPU_SC_WGS") ? (u32)std::min(LF_SC_GRID_WGS, std::max(1, atoi(getenv("LFGPU_SC_WGS")))) : 64u;
+  if (G > wgs_cap) G = wgs_cap;
   if ((int)G > c->num_cu) G = (u32)c->num_cu;
   ScGrid a{};
   a.field = field;
