@@ -87,6 +87,12 @@ bool lf_table_lookup(lfgpu_ctx* c, const std::string& key, void** out);
 // asynchronous upload of <= LF_STAGE_SLOT bytes through the pinned staging ring (no stream synchronisation)
 #define LF_STAGE_SLOT 4096
 int lf_stage_upload(lfgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes);
+// Quad::bind_gh_all without the read-back: enqueue on the stream into 4 device words, fold them on the host later
+struct lfgpu_quad;
+int lf_quad_bind_gh_all_enqueue(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                                const uint64_t beta[2], size_t logw, size_t nw, const void* h_H0, const void* h_H1, u64* d_acc);
+void lf_quad_bind_gh_all_fold(int field, const u64 w[4], uint64_t out[2]);
+#define LF_GH_BATCH_MAX 96  // layers whose sums fit the device mailbox (32 bytes each from offset 512)
 
 // host-side field helpers (use the LF_HD arithmetic of fields.h compiled for the host)
 elt_t h_gf_inv(elt_t a);

@@ -439,23 +439,21 @@ __global__ __launch_bounds__(QD_THREADS) void bind_gh_all_kernel(size_t n, const
   }
 }
 
-extern "C" int lfgpu_quad_bind_gh_all(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
-                                      const uint64_t beta[2], size_t logw, size_t nw, const void* h_H0, const void* h_H1,
-                                      uint64_t out[2]) {
-  if (!q || !alpha || !beta || !out || (logv && (!h_G0 || !h_G1)) || (logw && (!h_H0 || !h_H1))) return LFGPU_ERR_ARG;
+// enqueues the tables and the sum on the context's stream; d_acc: 4 words (zeroed here) that hold the XOR words / limb
+// sums afterwards.  No synchronisation: the host operands are staged before this returns.
+int lf_quad_bind_gh_all_enqueue(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                                const uint64_t beta[2], size_t logw, size_t nw, const void* h_H0, const void* h_H1, u64* d_acc) {
+  if (!q || !alpha || !beta || !d_acc || (logv && (!h_G0 || !h_G1)) || (logw && (!h_H0 || !h_H1))) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = q->c;
   if (logv > 40 || logw > 40 || ((size_t)1 << logv) < q->nv || nw == 0 || ((size_t)1 << logw) < nw)
     return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_gh_all: table sizes");
   LF_HIP(c, hipSetDevice(c->device));
   const int field = q->field;
-  static const bool verbose_gh = getenv("LFGPU_VERBOSE") != nullptr;
-  const auto tgh0 = std::chrono::steady_clock::now();
   void* sc = nullptr;
   LF_TRY(lf_scratch3(c, (q->nv + 2 * nw) * 16 + 64, &sc));
   elt_t* d_eqg = (elt_t*)sc;
   elt_t* d_eqh0 = d_eqg + q->nv;
   elt_t* d_eqh1 = d_eqh0 + nw;
-  u64* d_acc = (u64*)(d_eqh1 + nw);
   const uint64_t zero[2] = {0, 0};
   LF_TRY(lfgpu_raw_eq2(c, field, logv, q->nv, h_G0, h_G1, alpha, d_eqg));
   LF_TRY(lfgpu_raw_eq2(c, field, logw, nw, h_H0, h_H0, zero, d_eqh0));  // EQ(H0, i) + 0 * (...)
@@ -468,12 +466,10 @@ extern "C" int lfgpu_quad_bind_gh_all(lfgpu_quad* q, size_t logv, const void* h_
   QD_DISPATCH(field, bind_gh_all_kernel, dim3(nb), dim3(QD_THREADS), q->n, (const corner4*)q->d_morton, (const elt_t*)q->d_kvec,
               (const elt_t*)d_eqg, (const elt_t*)d_eqh0, (const elt_t*)d_eqh1, be, d_acc);
   LF_HIP(c, hipGetLastError());
-  u64 w[4];
-  LF_HIP(c, hipMemcpyAsync(w, d_acc, 32, hipMemcpyDeviceToHost, c->stream));
-  LF_HIP(c, hipStreamSynchronize(c->stream));
-  if (verbose_gh)
-    fprintf(stderr, "lfgpu bind_gh_all: nterms %zu nv %zu nw %zu | %.0f us\n", q->n, q->nv, nw,
-            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tgh0).count());
+  return LFGPU_OK;
+}
+// the 4 words of d_acc (on the host) -> the field element
+void lf_quad_bind_gh_all_fold(int field, const u64 w[4], uint64_t out[2]) {
   if (field == LFGPU_FIELD_GF2_128) {
     out[0] = w[0];
     out[1] = w[1];
@@ -482,6 +478,19 @@ extern "C" int lfgpu_quad_bind_gh_all(lfgpu_quad* q, size_t logv, const void* h_
     out[0] = sum.lo;
     out[1] = sum.hi;
   }
+}
+
+extern "C" int lfgpu_quad_bind_gh_all(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                                      const uint64_t beta[2], size_t logw, size_t nw, const void* h_H0, const void* h_H1,
+                                      uint64_t out[2]) {
+  if (!q || !out) return LFGPU_ERR_ARG;
+  lfgpu_ctx* c = q->c;
+  u64* d_acc = (u64*)((uint8_t*)c->mailbox_d + 256);
+  LF_TRY(lf_quad_bind_gh_all_enqueue(q, logv, h_G0, h_G1, alpha, beta, logw, nw, h_H0, h_H1, d_acc));
+  u64 w[4];
+  LF_HIP(c, hipMemcpyAsync(w, d_acc, 32, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  lf_quad_bind_gh_all_fold(q->field, w, out);
   return LFGPU_OK;
 }
 

@@ -423,6 +423,12 @@ int build_constraints(lfgpu_ctx* c, const lfgpu_circuit* C, const HostField& F, 
   size_t logv = I.logv, ci = 0, pi = I.ninputs - npub;
   elt_t claims[2] = {elt_t{0, 0}, elt_t{0, 0}};
   std::vector<elt_t> sym;
+  struct Deferred {
+    size_t ci, acp;  // constraint, position of its claim-pad terms in out.a
+    elt_t wc0, wc1;
+  };
+  std::vector<Deferred> deferred;
+  const bool batch_gh = nl <= LF_GH_BATCH_MAX;
   for (size_t ly = 0; ly < nl; ++ly) {
     const auto& L = C->layers[ly];
     const size_t logw = L.logw;
@@ -465,21 +471,34 @@ int build_constraints(lfgpu_ctx* c, const lfgpu_circuit* C, const HostField& F, 
         axpy(3 + 2 * r, t0e, lag[0]);
         axpy(3 + 2 * r + 1, t2e, lag[2]);
       }
-    elt_t eqq;  // EQ[Q,C] QUAD[R,L]; Eq::eval with logc = 0 is 1
+    // EQ[Q,C] QUAD[R,L] (Eq::eval with logc = 0 is 1): the prover's aux, or Quad::bind_gh_all on the device.  The
+    // verifier's value feeds only ConstraintBuilder::finalize, never the transcript, so the layers' sums are enqueued
+    // back to back and finalize runs for all layers after ONE synchronisation below.
+    elt_t eqq{0, 0};
+    const bool defer = !aux && batch_gh;
     if (aux) {
       eqq = (*aux)[ly];
     } else {
-      uint64_t bq[2];
       const uint64_t al[2] = {alpha.lo, alpha.hi}, be[2] = {beta.lo, beta.hi};
-      LF_TRY(lfgpu_quad_bind_gh_all(L.q, logv, G[0].data(), G[1].data(), al, be, logw, L.nw, gh[0].data(), gh[1].data(), bq));
-      eqq = elt_t{bq[0], bq[1]};
+      if (defer) {
+        LF_TRY(lf_quad_bind_gh_all_enqueue(L.q, logv, G[0].data(), G[1].data(), al, be, logw, L.nw, gh[0].data(), gh[1].data(),
+                                           (u64*)((uint8_t*)c->mailbox_d + 512) + 4 * ly));
+      } else {
+        uint64_t bq[2];
+        LF_TRY(lfgpu_quad_bind_gh_all(L.q, logv, G[0].data(), G[1].data(), al, be, logw, L.nw, gh[0].data(), gh[1].data(), bq));
+        eqq = elt_t{bq[0], bq[1]};
+      }
     }
     const size_t cp = 3 + 4 * logw;  // ConstraintBuilder::finalize
-    out.b.push_back(F.sub(F.mul(eqq, F.mul(P.wc[0], P.wc[1])), known));
-    sym[cp] = F.sub(sym[cp], F.mul(eqq, P.wc[1]));
-    sym[cp + 1] = F.sub(sym[cp + 1], F.mul(eqq, P.wc[0]));
-    sym[cp + 2] = F.sub(sym[cp + 2], eqq);
-    for (size_t i = ly == 0 ? 3 : 0; i < n; ++i) out.a.push_back({ci, pi + i - 3, sym[i]});
+    const size_t a0 = out.a.size(), skip = ly == 0 ? 3 : 0;
+    out.b.push_back(defer ? known : F.sub(F.mul(eqq, F.mul(P.wc[0], P.wc[1])), known));
+    if (!defer) {
+      sym[cp] = F.sub(sym[cp], F.mul(eqq, P.wc[1]));
+      sym[cp + 1] = F.sub(sym[cp + 1], F.mul(eqq, P.wc[0]));
+      sym[cp + 2] = F.sub(sym[cp + 2], eqq);
+    }
+    for (size_t i = skip; i < n; ++i) out.a.push_back({ci, pi + i - 3, sym[i]});
+    if (defer) deferred.push_back({ci, a0 + cp - skip, P.wc[0], P.wc[1]});
     ++ci;
     ts.write_array(P.wc, 2);
     claims[0] = P.wc[0];
@@ -490,6 +509,20 @@ int build_constraints(lfgpu_ctx* c, const lfgpu_circuit* C, const HostField& F, 
     }
     logv = logw;
     pi += layer_size(logw);
+  }
+  if (!deferred.empty()) {  // the layers' bind_gh_all sums: one read-back, then finalize each layer
+    std::vector<u64> w(4 * nl);
+    LF_HIP(c, hipMemcpyAsync(w.data(), (uint8_t*)c->mailbox_d + 512, nl * 32, hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(c, hipStreamSynchronize(c->stream));
+    for (const Deferred& d : deferred) {
+      uint64_t bq[2];
+      lf_quad_bind_gh_all_fold(I.field, &w[4 * d.ci], bq);
+      const elt_t eqq{bq[0], bq[1]};
+      out.b[d.ci] = F.sub(F.mul(eqq, F.mul(d.wc0, d.wc1)), out.b[d.ci]);  // b held `known` so far
+      out.a[d.acp].k = F.sub(out.a[d.acp].k, F.mul(eqq, d.wc1));
+      out.a[d.acp + 1].k = F.sub(out.a[d.acp + 1].k, F.mul(eqq, d.wc0));
+      out.a[d.acp + 2].k = F.sub(out.a[d.acp + 2].k, eqq);
+    }
   }
   const elt_t alpha = ts.elt();
   out.a.push_back({ci, pi - 3, F.sub(elt_t{0, 0}, F.one)});  // input_constraint: -1, -alpha on the input layer's claim pads
