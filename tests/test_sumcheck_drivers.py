@@ -1,0 +1,36 @@
+"""Every sumcheck round driver and tuning switch must produce the reference's proof bytes (DESIGN.md section 4,
+"Driving the rounds").  The switches are read once per process, hence one child process per combination."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = os.path.join(ROOT, "tests", "zk_mode_child.py")
+
+CASES = [
+    ("1", {"LFGPU_SC_MODE": "grid"}),
+    ("1", {"LFGPU_SC_MODE": "resident"}),
+    ("1", {"LFGPU_SC_MODE": "launch"}),
+    ("1", {"LFGPU_SC_MODE": "off"}),
+    ("1", {"LFGPU_SC_SPLIT": "0", "LFGPU_SC_TAIL": "0"}),
+    ("1", {"LFGPU_SC_PER_WG": "64", "LFGPU_SC_WGS": "128"}),
+    ("1", {"LFGPU_SC_GRID_MAX": "4096", "LFGPU_SC_PER_WG": "2048"}),
+    ("32", {"LFGPU_SC_GRID_MAX": "262144", "LFGPU_SC_WGS": "128", "LFGPU_SC_PER_WG": "256"}),
+    ("32", {"LFGPU_SC_WGS": "7", "LFGPU_SC_PER_WG": "1024"}),
+    ("1 fp128", {"LFGPU_SC_PER_WG": "128", "LFGPU_SC_SPLIT": "0"}),
+    ("1 fp128", {"LFGPU_SC_MODE": "resident"}),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,env", CASES, ids=[a + " " + ",".join("%s=%s" % kv for kv in e.items()) for a, e in CASES])
+def test_proof_bytes_under_every_driver(args, env):
+    e = dict(os.environ)
+    for k in list(e):
+        if k.startswith("LFGPU_SC_"):
+            del e[k]
+    e.update(env)
+    r = subprocess.run([sys.executable, CHILD] + args.split(), env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
