@@ -567,16 +567,20 @@ __global__ __launch_bounds__(SC_THREADS) void field_binop_kernel(int op, size_t 
 
 
 // ---- the rest of a layer in ONE cooperative launch on a grid that shrinks with the data.
-// A single workgroup is compute-bound beyond ~10^3 terms (a GF(2^128) product is ~600 VALU ops and a CU retires
-// ~1024 of them in 4.6 us), so for up to LF_SC_GRID_MAX entries the resident idea runs on one 1024-thread workgroup
-// per 1024 entries, synchronised by device-wide barriers.  Per round-hand:
-//   scatter | barrier | partial sums -> slots -> the last-arriving workgroup folds and posts to the host |
-//   challenge | dense bind + head counts + clear QW | barrier | emit (order-preserving: workgroup g owns a contiguous
-//   range) | barrier | workgroups beyond ceil(max size / 1024) leave
+// A workgroup's share of the products runs on one CU and a GF(2^128) product is ~510 instruction-equivalents, so the
+// phases are issue-bound per CU long before the chip is busy: the layer runs on one 1024-thread workgroup per
+// `per_wg` entries (512 for GF(2^128), 1024 for Fp128), work dealt in 64-entry chunks round-robin over the
+// workgroups, synchronised by device-wide barriers.  Per round-hand (see sc_grid_layer_kernel):
+//   barrier | sums a0, a2 -> slots -> the last-arriving workgroup folds and posts to the host |
+//   layout of HQuad::bind_h (merge kinds, counts, barrier, offsets, halved corners: nothing of it needs the
+//   challenge, so it hides behind the host round trip) | challenge |
+//   Dense::bind + HQUAD values + the NEXT evaluation's QW from those values (double-buffered QW) |
+//   workgroups beyond ceil(max size / per_wg) leave
 // A device barrier costs ~2 us for 8 workgroups, 3.5 us for 32, 10 us for 128 (tools/ubench_sync.hip): hence the
-// shrinking grid, down to ONE workgroup whose barriers are plain __syncthreads.  Only workgroup 0 polls host
-// memory; the others take the challenge from a device-memory slot.  Every wait is bounded (abort flag + wall-clock
-// timeout), so all waves always leave.  hipLaunchCooperativeKernel guarantees that all workgroups are resident.
+// shrinking grid, down to ONE workgroup whose barriers are plain __syncthreads and whose state lives in LDS.  Only
+// workgroup 0 polls host memory; the others take the challenge from a device-memory slot.  Every wait is bounded
+// (abort flag + wall-clock timeout), so all waves always leave.  hipLaunchCooperativeKernel guarantees that all
+// workgroups are resident.
 struct ScGridSync {  // device memory, zeroed before every launch
   u32 count, gen, abort, arrive;
   u64 chal[2];
