@@ -229,6 +229,18 @@ class LfGpu:
         self._ck(self.L.lfgpu_fp128_rs_encode_rows(self.h, nrow, n, m, omega, omega_order, C.c_void_p(d_ptr),
                                                    m if ld is None else ld))
 
+    # --- inner_product_vector + layout_Aext on the device (reference lib/ligero/ligero_param.h:382-430)
+    def ligero_inner_product_rows(self, field, w, r, ld, nrows, d_dense, ndense, scale, idx, val, d_rows):
+        """rows[i][r + j] = scale * dense[i*w + j] (flat positions < ndense), then rows[pos(idx)] += val; the first
+        r + w columns of all nrows rows are cleared first.  idx: strictly increasing flat indices (host)."""
+        import numpy as np
+        sc = np.ascontiguousarray(scale, dtype=np.uint64)
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        val = np.ascontiguousarray(val, dtype=np.uint64)
+        self._ck(self.L.lfgpu_ligero_inner_product_rows(self.h, field, w, r, ld, nrows, C.c_void_p(d_dense), ndense,
+                                                        C.c_void_p(sc.ctypes.data), C.c_void_p(idx.ctypes.data),
+                                                        C.c_void_p(val.ctypes.data), len(idx), C.c_void_p(d_rows)))
+
     # --- K5+K6 MerkleCommitment::commit (reference lib/merkle/merkle_commitment.h:50-64)
     def column_commit(self, field, nrow, ld, col0, ncols, d_T, d_nonces, d_layers):
         root = (C.c_uint8 * 32)()

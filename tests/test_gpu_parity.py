@@ -561,3 +561,46 @@ def test_eval_quad_and_bind_g(G, field, logv, logw, nterms, n_assert):
     assert (G.from_dev(dh, np.uint32, (L["n"], 2))[:nb] == ha[:na]).all()
     assert (G.from_dev(dv, np.uint64, (L["n"], 2))[:nb] == va[:na]).all()
     q.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field", [GF, FP])
+@pytest.mark.parametrize("w,r,ld,nrows,ndense,nsparse", [
+    (7, 3, 16, 5, 0, 0),        # nothing but the clear
+    (7, 3, 16, 5, 35, 0),       # dense block fills every row
+    (7, 0, 7, 5, 11, 9),        # no randomness columns, rows back to back, dense ends mid-row
+    (64, 13, 200, 9, 300, 40),
+    (910, 455, 8192, 3, 2000, 500),  # the flatsha-32 row shape; more sparse terms than one staging slot holds
+])
+def test_ligero_inner_product_rows(G, field, w, r, ld, nrows, ndense, nsparse):
+    """lfgpu_ligero_inner_product_rows against inner_product_vector + layout_Aext restated with the oracle's field
+    arithmetic (ligero_param.h:382-430): columns < r + w are overwritten, the columns beyond stay as they were."""
+    pkg, o = G.pkg, ol.oracle()
+    rng = np.random.default_rng(1000 * w + nsparse + field)
+    dense = ol.rand_elts(rng, max(ndense, 1), field)
+    scale = ol.rand_elts(rng, 1, field)[0]
+    idx = np.sort(rng.choice(nrows * w, size=nsparse, replace=False)).astype(np.uint64) if nsparse else np.zeros(0, np.uint64)
+    val = ol.rand_elts(rng, max(nsparse, 1), field)[:nsparse]
+    before = ol.rand_elts(rng, nrows * ld, field).reshape(nrows, ld, 2)
+    want = before.copy()
+    want[:, :r + w] = 0
+    for t in range(ndense):
+        want[t // w, r + t % w] = arr(o.lfo_mul(field, elt(scale), elt(dense[t])))
+    for t in range(nsparse):
+        i, j = int(idx[t]) // w, int(idx[t]) % w
+        want[i, r + j] = arr(o.lfo_add(field, elt(want[i, r + j]), elt(val[t])))
+    d_dense, d_rows = G.to_dev(dense), G.to_dev(before)
+    G.gpu().ligero_inner_product_rows(field, w, r, ld, nrows, d_dense.data_ptr(), ndense, scale, idx, val, d_rows.data_ptr())
+    got = G.from_dev(d_rows, np.uint64, (nrows, ld, 2))
+    assert (got == want).all()
+    if nsparse >= 2:  # refused: duplicate / decreasing indices, index out of range
+        bad = idx.copy()
+        bad[1] = bad[0]
+        with pytest.raises(pkg.LfGpuError):
+            G.gpu().ligero_inner_product_rows(field, w, r, ld, nrows, d_dense.data_ptr(), ndense, scale, bad, val, d_rows.data_ptr())
+        bad = idx.copy()
+        bad[-1] = nrows * w
+        with pytest.raises(pkg.LfGpuError):
+            G.gpu().ligero_inner_product_rows(field, w, r, ld, nrows, d_dense.data_ptr(), ndense, scale, bad, val, d_rows.data_ptr())
+    with pytest.raises(pkg.LfGpuError):  # r + w must fit the row
+        G.gpu().ligero_inner_product_rows(field, w, ld, ld, nrows, d_dense.data_ptr(), ndense, scale, idx, val, d_rows.data_ptr())
