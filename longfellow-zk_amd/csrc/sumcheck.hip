@@ -583,9 +583,8 @@ __global__ __launch_bounds__(SC_THREADS) void field_binop_kernel(int op, size_t 
 // workgroups are resident.
 struct ScGridSync {  // device memory, zeroed before every launch
   u32 count, gen, abort, arrive;
-  u64 chal[2];
-  u64 chal_seq;
-  u64 pad_[3];
+  u64 chal4[4];  // the challenge as the host's four tagged words
+  u64 pad_[2];
   u64 slots[4 * LF_SC_GRID_WGS];  // per workgroup {a0, a2}
 };
 struct ScGrid {
@@ -608,6 +607,7 @@ struct ScGrid {
   u32* counts;      // one word per workgroup
   u32* src;         // one word per HQUAD entry: where each bound entry comes from
   u32 tail_lds;     // 1: the launch reserved SC_TAIL_LDS_BYTES of dynamic LDS for the tail
+  u32 all_poll;     // 1: every workgroup polls the host for the challenge (A/B)
   u32 split_waves;  // 1: with one workgroup left, independent products go to different waves
   u32 per_wg;       // entries of the largest array per active workgroup (the grid shrinks to keep it)
 };
@@ -736,8 +736,8 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
 #ifdef LF_SC_PROF
   u64 pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   u64 tl = wall_clock64();
-#ifdef LF_SC_PROF_SMALL  // only the round-hands whose arrays hold <= 64 entries: the fixed cost of a round-hand
-#define SC_LAP(k) do { const u64 tn_ = wall_clock64(); if (nh <= 64 && nW[0] <= 64 && nW[1] <= 64) pt[k] += tn_ - tl; tl = tn_; } while (0)
+#ifdef LF_SC_PROF_LO  // only the round-hands whose largest array holds (LF_SC_PROF_LO, LF_SC_PROF_HI] entries
+#define SC_LAP(k) do { const u64 tn_ = wall_clock64(); const u32 bg_ = max(nh, max(nW[0], nW[1])); if (bg_ > LF_SC_PROF_LO && bg_ <= LF_SC_PROF_HI) pt[k] += tn_ - tl; tl = tn_; } while (0)
 #else
 #define SC_LAP(k) do { const u64 tn_ = wall_clock64(); pt[k] += tn_ - tl; tl = tn_; } while (0)
 #endif
@@ -956,45 +956,50 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       new_nh = G > 1 ? s_tot : my_end;
     }
     SC_LAP(5);
-    // ---- the challenge: workgroup 0 takes it from the host, the others from the device slot
-    if (tid == 0) {
+    // ---- the challenge.  The host writes it as four 64-bit words {tag = low half of the sequence number, 32 bits of
+    // the challenge}; 64-bit stores are atomic, so a read that finds the tag in all four words has the whole challenge
+    // and needs no second PCIe round trip for the payload after a flag.  Lanes 0-3 of wave 0 read one word each in ONE
+    // vector load (one request for the 32 bytes).  Workgroup 0 polls the host and hands the challenge to the others
+    // through a device slot (all_poll: every workgroup polls the host itself).
+    if (wave == 0) {
       const u64 t0 = wall_clock64();
-      u64 got = 0;
-      if (g == 0) {
-        for (;;) {  // uncached pinned host memory: relaxed polls, the challenge words are read after the sequence word
-          got = __hip_atomic_load((const u64*)&a.cmd[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (got == seq) break;
-          if (wall_clock64() - t0 > a.timeout_ticks) break;
-          __builtin_amdgcn_s_sleep(1);
+      const u64 tag = seq & 0xffffffffull;
+      const bool from_host = g == 0 || a.all_poll;
+      u64 got = 0, w = 0;
+      for (;;) {
+        if (from_host) {
+          if (lane < 4) w = __hip_atomic_load((const u64*)&a.cmd[4 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+          if (lane < 4) w = __hip_atomic_load(&gs->chal4[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (got == seq) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // orders the loads below after the poll (s_waitcnt only)
-          sh.cmd[0] = __hip_atomic_load((const u64*)&a.cmd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          sh.cmd[1] = __hip_atomic_load((const u64*)&a.cmd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (G > 1) {
-            __hip_atomic_store(&gs->chal[0], sh.cmd[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&gs->chal[1], sh.cmd[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&gs->chal_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(lane >= 4 || (w >> 32) == tag)) {
+          got = seq;
+          break;
+        }
+        int stop = 0;
+        if (lane == 0) {
+          if (G > 1 && __hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) stop = 1;
+          else if (wall_clock64() - t0 > (from_host ? 1 : 2) * a.timeout_ticks) {  // the host went away: release every workgroup and report
+            __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == 0) {
+              a.post[8] = 1;
+              __threadfence_system();
+              __hip_atomic_store((u64*)&a.post[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            stop = 1;
           }
-        } else {  // the host went away: release every workgroup and report
-          __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-          a.post[8] = 1;
-          __threadfence_system();
-          __hip_atomic_store((u64*)&a.post[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-      } else {
-        for (;;) {
-          got = __hip_atomic_load(&gs->chal_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (got == seq) break;
-          if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-          if (wall_clock64() - t0 > 2 * a.timeout_ticks) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        sh.cmd[0] = __hip_atomic_load(&gs->chal[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh.cmd[1] = __hip_atomic_load(&gs->chal[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__shfl(stop, 0, 64)) break;
+        __builtin_amdgcn_s_sleep(1);
       }
-      sh.cmd[2] = got;
+      if (got == seq && g == 0 && G > 1 && !a.all_poll && lane < 4)  // tagged words again: no flag, no fence
+        __hip_atomic_store(&gs->chal4[lane], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 c0 = __shfl(w, 0, 64), c1 = __shfl(w, 1, 64), c2 = __shfl(w, 2, 64), c3 = __shfl(w, 3, 64);
+      if (lane == 0) {
+        sh.cmd[0] = (c0 & 0xffffffffull) | (c1 << 32);
+        sh.cmd[1] = (c2 & 0xffffffffull) | (c3 << 32);
+        sh.cmd[2] = got;
+      }
     }
     __syncthreads();
     if (sh.cmd[2] != seq) return;  // uniform per workgroup; the barriers of the others see the abort flag
@@ -1269,6 +1274,8 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   }
   a.tail_lds = (u32)tail_ok;
   a.per_wg = per_wg;
+  static const int all_poll_env = getenv("LFGPU_SC_ALLPOLL") ? atoi(getenv("LFGPU_SC_ALLPOLL")) : 0;
+  a.all_poll = (u32)all_poll_env;
   static const int split_env = getenv("LFGPU_SC_SPLIT") ? atoi(getenv("LFGPU_SC_SPLIT")) : -1;
   a.split_waves = split_env >= 0 ? (u32)split_env : 1u;
   LF_HIP(c, hipLaunchCooperativeKernel(fn, dim3(G), dim3(SM_THREADS), args, tail_ok ? SC_TAIL_LDS_BYTES : 0, c->stream));
@@ -1279,9 +1286,16 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
 int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]) {
   if (r) {
     volatile u64* cmd = c->poll_h + 64;
+    const u64 seq = c->poll_next - 1, tag = (seq & 0xffffffffull) << 32;
+    // the grid kernel's form: four tagged words, valid as soon as all four carry the tag (any order, no flag)
+    __atomic_store_n((u64*)&cmd[4], tag | (r[0] & 0xffffffffull), __ATOMIC_RELAXED);
+    __atomic_store_n((u64*)&cmd[5], tag | (r[0] >> 32), __ATOMIC_RELAXED);
+    __atomic_store_n((u64*)&cmd[6], tag | (r[1] & 0xffffffffull), __ATOMIC_RELAXED);
+    __atomic_store_n((u64*)&cmd[7], tag | (r[1] >> 32), __ATOMIC_RELAXED);
+    // the single-workgroup kernels' form: payload, then the sequence number
     cmd[0] = r[0];
     cmd[1] = r[1];
-    __atomic_store_n((u64*)&cmd[2], c->poll_next - 1, __ATOMIC_RELEASE);
+    __atomic_store_n((u64*)&cmd[2], seq, __ATOMIC_RELEASE);
   }
   LF_TRY(sc_wait_post(c, c->poll_next));
   ++c->poll_next;
@@ -1291,7 +1305,7 @@ int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]) {
     static std::vector<std::pair<double, u64>> tr;
     static const bool on = getenv("LFGPU_SC_TRACE") != nullptr;
     if (on) {
-      tr.emplace_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(), c->poll_h[4]);
+      tr.emplace_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(), out[4]);
       if (c->poll_next == c->poll_seq + 1) {
         fprintf(stderr, "sc_trace:");
         for (size_t i = 1; i < tr.size(); ++i) fprintf(stderr, " %llu:%.1f", (unsigned long long)tr[i - 1].second, tr[i].first - tr[i - 1].first);
