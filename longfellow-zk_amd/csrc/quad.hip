@@ -532,7 +532,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   const double tv0 = verbose ? clk() : 0;
   LF_TRY(lfgpu_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], &nh));
   const double tv1 = verbose ? clk() : 0;
-  double t_large = 0, t_small_first = 0;
+  double t_large = 0, t_small_first = 0, t_cb = 0;
   size_t n_large = 0;
   const size_t nh0 = nh;
   int cur = 0;
@@ -651,7 +651,9 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
         evw[k][0] = ev[k].lo;
         evw[k][1] = ev[k].hi;
       }
+      const double tcb0 = verbose ? clk() : 0;
       round(user, (size_t)hand, rnd, evw, r);
+      if (verbose) t_cb += clk() - tcb0;
       g_out[(hand * logw + rnd) * 2] = r[0];
       g_out[(hand * logw + rnd) * 2 + 1] = r[1];
       sum = F.eval_lagrange(ev, elt_t{r[0], r[1]});
@@ -698,8 +700,8 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     LF_HIP(c, hipStreamSynchronize(c->stream));
   }
   if (verbose)
-    fprintf(stderr, "lfgpu sumcheck_layer: nterms %zu nh0 %zu nw %zu logw %zu | bind_g %.0f us | %zu large round-hands %.0f us | %zu small %.0f us\n",
-            nt, nh0, nw, logw, tv1 - tv0, n_large, t_large, 2 * logw - n_large, t_small_first ? clk() - t_small_first : 0.0);
+    fprintf(stderr, "lfgpu sumcheck_layer: nterms %zu nh0 %zu nw %zu logw %zu | bind_g %.0f us | %zu large round-hands %.0f us | %zu small %.0f us | caller's round callback %.1f us in all\n",
+            nt, nh0, nw, logw, tv1 - tv0, n_large, t_large, 2 * logw - n_large, t_small_first ? clk() - t_small_first : 0.0, t_cb);
   wc_out[0][0] = tmp[0];
   wc_out[0][1] = tmp[1];
   wc_out[1][0] = tmp[2];
