@@ -79,6 +79,14 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise LfGpuError("%s not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % LIB_PATH)
+    # PyTorch-ROCm ships its own HIP runtime (libamdhip64 under torch/lib).  When torch shares the process -- device
+    # tensors, streams, torch.distributed -- that runtime must be the one already loaded when liblfgpu.so is opened;
+    # loading the system runtime first and torch's afterwards leaves the process with two runtimes and lfgpu_init
+    # fails.  Stand-alone use (examples/zk_flatsha.cc) needs no torch and binds the system runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, sz, u64, ci = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
     pu64 = C.POINTER(C.c_uint64)
