@@ -92,6 +92,10 @@ struct lfgpu_quad;
 int lf_quad_bind_gh_all_enqueue(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
                                 const uint64_t beta[2], size_t logw, size_t nw, const void* h_H0, const void* h_H1, u64* d_acc);
 void lf_quad_bind_gh_all_fold(int field, const u64 w[4], uint64_t out[2]);
+// Quad::bind_g; n_out == nullptr enqueues only and leaves the HQUAD size in the device word lf_quad_bind_g_count(c)
+int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2], const uint64_t beta[2],
+                   void* d_hc_out, void* d_vc_out, size_t* n_out);
+const u32* lf_quad_bind_g_count(lfgpu_ctx* c);
 #define LF_GH_BATCH_MAX 96  // layers whose sums fit the device mailbox (32 bytes each from offset 512)
 
 // host-side field helpers (use the LF_HD arithmetic of fields.h compiled for the host)
@@ -128,7 +132,7 @@ int lf_sc_small_step(lfgpu_ctx* c, const ScSmall& a, u64 out[8]);
 int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_W_shared, void* wtmp);
 int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]);
 bool lf_sc_resident_ok(lfgpu_ctx* c);
-int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, void* W0, size_t nW0,
+int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, const u32* d_nh, void* W0, size_t nW0,
                      void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
                      size_t logw, void* d_state);
 #define LF_SC_GRID_WGS 128                         // most workgroups the shrinking-grid kernel starts with

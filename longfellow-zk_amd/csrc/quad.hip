@@ -356,9 +356,10 @@ extern "C" int lfgpu_raw_eq2(lfgpu_ctx* c, int field, size_t logn, size_t n, con
   return LFGPU_OK;
 }
 
-extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
-                                 const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out) {
-  if (!q || !alpha || !beta || !d_hc_out || !d_vc_out || !n_out || (logv && (!h_G0 || !h_G1))) return LFGPU_ERR_ARG;
+// n_out == nullptr: enqueue only (no read-back, no synchronisation)
+int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                   const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out) {
+  if (!q || !alpha || !beta || !d_hc_out || !d_vc_out || (logv && (!h_G0 || !h_G1))) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = q->c;
   if (logv > 40 || ((size_t)1 << logv) < q->nv) return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_g: 2^logv < nv");
   LF_HIP(c, hipSetDevice(c->device));
@@ -390,11 +391,19 @@ extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, c
                        (elt_t*)d_vc_out);
   }
   LF_HIP(c, hipGetLastError());
+  if (!n_out) return LFGPU_OK;  // enqueue only: the HQUAD size stays in the device mailbox (lf_quad_bind_g_count)
   LF_HIP(c, hipMemcpyAsync(c->mailbox_h, total, 4, hipMemcpyDeviceToHost, c->stream));
   LF_HIP(c, hipStreamSynchronize(c->stream));
   *n_out = *(const u32*)c->mailbox_h;
   return LFGPU_OK;
 }
+extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
+                                 const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out) {
+  if (!n_out) return LFGPU_ERR_ARG;
+  return lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, d_hc_out, d_vc_out, n_out);
+}
+// device word that holds the HQUAD size after an enqueue-only bind_g
+const u32* lf_quad_bind_g_count(lfgpu_ctx* c) { return (const u32*)((uint8_t*)c->mailbox_d + 192); }
 
 
 // ---- Quad::bind_gh_all (lib/sumcheck/quad.h:188-210): the verifier's combined bind, no expansion:
@@ -529,12 +538,8 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   size_t nh = 0;
   static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
   auto clk = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double tv0 = verbose ? clk() : 0;
-  LF_TRY(lfgpu_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], &nh));
-  const double tv1 = verbose ? clk() : 0;
   double t_large = 0, t_small_first = 0, t_cb = 0;
   size_t n_large = 0;
-  const size_t nh0 = nh;
   int cur = 0;
   const elt_t al{alpha[0], alpha[1]};
   elt_t sum = F.add(elt_t{wc_in[0][0], wc_in[0][1]}, F.mul(al, elt_t{wc_in[1][0], wc_in[1][1]}));
@@ -566,6 +571,15 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     return std::min<size_t>(std::max<size_t>(v, 1024), LF_SC_GRID_MAX);
   }();
   const size_t small_max = (sc_mode == 3 && use_resident) ? grid_max : LF_SC_SMALL_MAX;
+  // Quad::bind_g.  A layer that goes to the shrinking grid from its first round-hand needs the HQUAD size only on the
+  // device (the kernel reads it from the mailbox word): bind_g is then enqueued without read-back or synchronisation
+  // and the cooperative launch follows it on the stream.
+  const bool direct = sc_mode == 3 && use_resident && nt <= small_max && nw <= small_max;
+  const double tv0 = verbose ? clk() : 0;
+  LF_TRY(lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], direct ? nullptr : &nh));
+  if (direct) nh = nt;  // upper bound for the host's bookkeeping
+  const double tv1 = verbose ? clk() : 0;
+  const size_t nh0 = nh;
   bool resident = false, have_r = false;
   u64 last_r[2] = {0, 0};
   bool small = false, pending = false;  // pending: the binds of (phand, pr) ride in the next fused step
@@ -610,8 +624,8 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
       if (small && use_resident) {
         if (!resident && sc_mode == 3) {  // hand the rest of the layer to the shrinking grid
           uint8_t* wb = (uint8_t*)wtmp;
-          LF_TRY(lf_sc_grid_begin(c, field, hc[cur], vc[cur], hc[1 - cur], vc[1 - cur], nh, WH[0], nW[0], WH[1], nW[1], wb, wb + half,
-                                  wb + 2 * half, wb + 3 * half, qw, 2 * rnd + hand, logw, grid_state));
+          LF_TRY(lf_sc_grid_begin(c, field, hc[cur], vc[cur], hc[1 - cur], vc[1 - cur], nh, (direct && rnd == 0 && hand == 0) ? lf_quad_bind_g_count(c) : nullptr,
+                                  WH[0], nW[0], WH[1], nW[1], wb, wb + half, wb + 2 * half, wb + 3 * half, qw, 2 * rnd + hand, logw, grid_state));
         } else if (!resident) {  // ... or to the resident workgroup
           ScSmall a{};
           a.field = field;

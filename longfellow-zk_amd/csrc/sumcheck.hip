@@ -594,6 +594,7 @@ struct ScGrid {
   uint2* hcB;       // the other half of the ping-pong
   elt_t* vcB;
   u32 nh;
+  const u32* d_nh;  // non-null: the HQUAD size is read from this device word (bind_g enqueued just before)
   elt_t* W[2];      // hand arrays at entry
   u32 nW[2];
   elt_t* Wb[2][2];  // bind destinations per hand (ping-pong), (nw+1)/2 elements each
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
   const elt_t* vc = a.vcA;
   uint2* hc_o = a.hcB;
   elt_t* vc_o = a.vcB;
-  u32 nh = a.nh;
+  u32 nh = a.d_nh ? *a.d_nh : a.nh;
   const elt_t* W[2] = {a.W[0], a.W[1]};
   u32 nW[2] = {a.nW[0], a.nW[1]};
   u32 wsel[2] = {a.W[0] == a.Wb[0][0] ? 1u : 0u, a.W[1] == a.Wb[1][0] ? 1u : 0u};
@@ -1225,7 +1226,7 @@ int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_
 }
 // round-hands [rh0, 2*logw) of a layer as one cooperative launch on ceil(max size / 1024) workgroups;
 // d_state: LF_SC_GRID_STATE_BYTES of device scratch (ScGridSync + the per-workgroup counts)
-int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, void* W0, size_t nW0,
+int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, const u32* d_nh, void* W0, size_t nW0,
                      void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
                      size_t logw, void* d_state) {
   const size_t big = std::max(nh, std::max(nW0, nW1));
@@ -1244,7 +1245,8 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   ScGrid a{};
   a.field = field;
   a.hcA = (uint2*)hc_cur; a.vcA = (elt_t*)vc_cur; a.hcB = (uint2*)hc_oth; a.vcB = (elt_t*)vc_oth;
-  a.nh = (u32)nh;
+  a.nh = (u32)nh;  // with d_nh: an upper bound (grid size), the kernel takes the count from the device word
+  a.d_nh = d_nh;
   a.W[0] = (elt_t*)W0; a.W[1] = (elt_t*)W1;
   a.nW[0] = (u32)nW0; a.nW[1] = (u32)nW1;
   a.Wb[0][0] = (elt_t*)Wb00; a.Wb[0][1] = (elt_t*)Wb01; a.Wb[1][0] = (elt_t*)Wb10; a.Wb[1][1] = (elt_t*)Wb11;
