@@ -137,7 +137,7 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
                      size_t logw, void* d_state);
 #define LF_SC_GRID_WGS 128                         // most workgroups the shrinking-grid kernel starts with
 #define LF_SC_GRID_MAX (256 * 1024)             // largest HQUAD / hand array it takes
-#define LF_SC_GRID_STATE_BYTES (64 + 32 * LF_SC_GRID_WGS + 4 * LF_SC_GRID_WGS + 64 + 36 * LF_SC_GRID_MAX)
+#define LF_SC_GRID_STATE_BYTES (64 + 1024 + 32 * LF_SC_GRID_WGS + 4 * LF_SC_GRID_WGS + 64 + 36 * LF_SC_GRID_MAX)
 #define LF_SC_SMALL_MAX 8192  // largest HQUAD / hand array the single-workgroup step takes
 
 struct lfgpu_quad;

@@ -585,6 +585,8 @@ struct ScGridSync {  // device memory, zeroed before every launch
   u32 count, gen, abort, arrive;
   u64 chal4[4];  // the challenge as the host's four tagged words
   u64 pad_[2];
+  u32 l1_bar[8 * 16];  // first-level arrival counters of the barrier, one cache line each (see sc_arrive)
+  u32 l1_arr[8 * 16];  // ... of the sums' arrival ticket
   u64 slots[4 * LF_SC_GRID_WGS];  // per workgroup {a0, a2}
 };
 struct ScGrid {
@@ -609,14 +611,30 @@ struct ScGrid {
   u32* src;         // one word per HQUAD entry: where each bound entry comes from
   u32 tail_lds;     // 1: the launch reserved SC_TAIL_LDS_BYTES of dynamic LDS for the tail
   u32 all_poll;     // 1: every workgroup polls the host for the challenge (A/B)
+  u32 two_level;    // 1: two-level arrival tickets (A/B)
   u32 split_waves;  // 1: with one workgroup left, independent products go to different waves
   u32 per_wg;       // entries of the largest array per active workgroup (the grid shrinks to keep it)
 };
 #define SC_TAIL 1024u
 #define SC_TAIL_LDS_BYTES (2 * SC_TAIL * 8 + 2 * SC_TAIL * 16 + 4 * SC_TAIL * 16 + SC_TAIL * 32 + SC_TAIL * 4)
 
+// Two-level arrival ticket.  Device-scope atomics on ONE address serialise (~80 ns each, tools/ubench_sync.hip), so
+// workgroups g, g + 8, g + 16, ... share one of eight first-level counters (eight addresses take their atomics in
+// parallel) and the last arrival of each group takes a ticket of the second level: G/8 + 8 serialised atomics instead
+// of G.  True for the one workgroup that arrives last overall; both levels are acquire-release, so what every
+// workgroup wrote before arriving is visible to it.  The counters reset themselves.
+__device__ __forceinline__ bool sc_arrive(u32* lvl1, u32* lvl2, u32 G, u32 g, bool two_level) {
+  const u32 grp = two_level ? (g & 7) : 0, ngrp = two_level ? (G < 8 ? G : 8) : 1, members = two_level ? ((G - grp + 7) >> 3) : G;
+  u32* c1 = lvl1 + grp * 16;
+  if (__hip_atomic_fetch_add(c1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != members - 1) return false;
+  __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__hip_atomic_fetch_add(lvl2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != ngrp - 1) return false;
+  __hip_atomic_store(lvl2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
 // barrier among the first `G` workgroups; false = aborted (every caller then returns)
-__device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen, u64 timeout_ticks) {
+__device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen, u64 timeout_ticks, bool two_level = true) {
   __shared__ u32 s_abort;
   if (G == 1) {
     __threadfence_block();
@@ -629,9 +647,7 @@ __device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen,
     // invalidate of this XCD that the barrier's latency would pay for nothing
     u32 ab = 0;
     const u64 t0 = wall_clock64();
-    const u32 t = __hip_atomic_fetch_add(&gs->count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == G - 1) {
-      __hip_atomic_store(&gs->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sc_arrive(gs->l1_bar, &gs->count, G, blockIdx.x, two_level)) {
       __hip_atomic_fetch_add(&gs->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       while (__hip_atomic_load(&gs->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
@@ -716,7 +732,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
     for (u32 i = gtid; i < qwords * nW[h0]; i += GT) QW[i] = 0;
     for (u32 i = gtid; i < qwords * nW[1 - h0]; i += GT) QWn[i] = 0;
   }
-  if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
+  if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks, a.two_level != 0)) return;
   {  // first evaluation of the hand-off: QW[h[hand]] += v * Wother[h[1-hand]] over the whole HQUAD
     const int hand = (int)(a.rh0 & 1);
     const u32 GT = G * SM_THREADS;
@@ -749,7 +765,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
   // bind both structures AND accumulate the next evaluation's QW from the values just produced.
   for (u32 rh = a.rh0; rh < a.rh1; ++rh, ++seq) {
     const int hand = (int)(rh & 1);
-    if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;  // QW of this evaluation is complete
+    if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks, a.two_level != 0)) return;  // QW of this evaluation is complete
     SC_LAP(0);
     {  // shrink: one workgroup per 1024 entries of the largest array; the others are done
       u32 big = nh > nW[0] ? nh : nW[0];
@@ -857,9 +873,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         if (tid == 0) {
           u64* sl = &gs->slots[4 * g];
           sl[0] = a0.lo; sl[1] = a0.hi; sl[2] = a2.lo; sl[3] = a2.hi;
-          const u32 t = __hip_atomic_fetch_add(&gs->arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);  // releases the slot
-          s_last = t == G - 1 ? 1u : 0u;
-          if (s_last) __hip_atomic_store(&gs->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_last = sc_arrive(gs->l1_arr, &gs->arrive, G, g, a.two_level != 0) ? 1u : 0u;  // releases the slot
         }
         __syncthreads();
         poster = false;
@@ -913,7 +927,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         __syncthreads();
         if (tid == 0) a.counts[g] = sh.carry;
         SC_LAP(3);
-        if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks)) return;
+        if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks, a.two_level != 0)) return;
         SC_LAP(4);
         if (tid < G) {
           const u32 cnt = a.counts[tid];
@@ -1263,7 +1277,7 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   a.counts = (u32*)((uint8_t*)d_state + sizeof(ScGridSync));
   a.src = (u32*)((uint8_t*)d_state + LF_SC_GRID_STATE_BYTES - 36 * LF_SC_GRID_MAX);
   a.QW2 = (u64*)((uint8_t*)d_state + LF_SC_GRID_STATE_BYTES - 32 * LF_SC_GRID_MAX);
-  LF_HIP(c, hipMemsetAsync(d_state, 0, 64, c->stream));  // counters, abort flag, challenge slot
+  LF_HIP(c, hipMemsetAsync(d_state, 0, 64 + 1024, c->stream));  // counters (both levels), abort flag, challenge slot
   void* args[] = {&a};
   const void* fn = field == LFGPU_FIELD_GF2_128 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
   static int tail_ok = -1;  // dynamic LDS for the tail (112 KiB) needs the attribute once per kernel
@@ -1278,6 +1292,8 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   a.per_wg = per_wg;
   static const int all_poll_env = getenv("LFGPU_SC_ALLPOLL") ? atoi(getenv("LFGPU_SC_ALLPOLL")) : 0;
   a.all_poll = (u32)all_poll_env;
+  static const int two_level_env = getenv("LFGPU_SC_TWOLEVEL") ? atoi(getenv("LFGPU_SC_TWOLEVEL")) : 1;
+  a.two_level = (u32)two_level_env;
   static const int split_env = getenv("LFGPU_SC_SPLIT") ? atoi(getenv("LFGPU_SC_SPLIT")) : -1;
   a.split_waves = split_env >= 0 ? (u32)split_env : 1u;
   LF_HIP(c, hipLaunchCooperativeKernel(fn, dim3(G), dim3(SM_THREADS), args, tail_ok ? SC_TAIL_LDS_BYTES : 0, c->stream));
