@@ -92,10 +92,9 @@ struct lfgpu_quad;
 int lf_quad_bind_gh_all_enqueue(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
                                 const uint64_t beta[2], size_t logw, size_t nw, const void* h_H0, const void* h_H1, u64* d_acc);
 void lf_quad_bind_gh_all_fold(int field, const u64 w[4], uint64_t out[2]);
-// Quad::bind_g; n_out == nullptr enqueues only and leaves the HQUAD size in the device word lf_quad_bind_g_count(c)
+// Quad::bind_g, enqueue only (nothing is read back: the HQUAD size is computed once at lfgpu_quad_upload)
 int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2], const uint64_t beta[2],
                    void* d_hc_out, void* d_vc_out, size_t* n_out);
-const u32* lf_quad_bind_g_count(lfgpu_ctx* c);
 #define LF_GH_BATCH_MAX 96  // layers whose sums fit the device mailbox (32 bytes each from offset 512)
 
 // host-side field helpers (use the LF_HD arithmetic of fields.h compiled for the host)

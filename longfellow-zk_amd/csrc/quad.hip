@@ -31,6 +31,11 @@ struct lfgpu_quad {
   corner4* d_bygate;  // sorted by g (stable)
   u32* d_goff;        // nv + 1 offsets into d_bygate
   elt_t* d_kvec;      // nk constants
+  // the run structure of the canonical order (which terms share a hand pair) depends on the circuit only: block offsets of
+  // the run heads and the HQUAD size of Quad::bind_g are computed once at upload
+  u32* d_runoff;      // per block of QD_THREADS terms: number of run heads before it
+  u32* d_nh;          // device copy of nh0
+  size_t nh0;
 };
 
 // ---- K11: V[g] = sum_{terms of g} kvec[vi] * W[h1] * W[h0]; assert-zero terms must vanish
@@ -246,6 +251,8 @@ extern "C" int lfgpu_quad_free(lfgpu_quad* q) {
   if (q->d_bygate) (void)hipFree(q->d_bygate);
   if (q->d_goff) (void)hipFree(q->d_goff);
   if (q->d_kvec) (void)hipFree(q->d_kvec);
+  if (q->d_runoff) (void)hipFree(q->d_runoff);
+  if (q->d_nh) (void)hipFree(q->d_nh);
   delete q;
   return LFGPU_OK;
 }
@@ -279,6 +286,8 @@ extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32
   q->d_morton = q->d_bygate = nullptr;
   q->d_goff = nullptr;
   q->d_kvec = nullptr;
+  q->d_runoff = q->d_nh = nullptr;
+  q->nh0 = 0;
   bool ok = hipMalloc((void**)&q->d_morton, n * 16) == hipSuccess && hipMalloc((void**)&q->d_bygate, n * 16) == hipSuccess &&
             hipMalloc((void**)&q->d_goff, (nv + 1) * 4) == hipSuccess && hipMalloc((void**)&q->d_kvec, nk * 16) == hipSuccess;
   ok = ok && hipMemcpy(q->d_morton, mort.data(), n * 16, hipMemcpyHostToDevice) == hipSuccess &&
@@ -288,6 +297,22 @@ extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32
   if (!ok) {
     lfgpu_quad_free(q);
     return lf_fail(c, LFGPU_ERR_NOMEM, "quad_upload: device allocation / copy failed");
+  }
+  {  // run heads: counts per block -> exclusive offsets + total
+    const u32 nb = (u32)((n + QD_THREADS - 1) / QD_THREADS);
+    u32 total = 0;
+    ok = hipMalloc((void**)&q->d_runoff, (size_t)nb * 4) == hipSuccess && hipMalloc((void**)&q->d_nh, 4) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(bindg_count_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton, q->d_runoff);
+      hipLaunchKernelGGL(bindg_scan_kernel, dim3(1), dim3(1024), 0, c->stream, nb, q->d_runoff, q->d_nh);
+      ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&total, q->d_nh, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+           hipStreamSynchronize(c->stream) == hipSuccess;
+    }
+    if (!ok) {
+      lfgpu_quad_free(q);
+      return lf_fail(c, LFGPU_ERR_NOMEM, "quad_upload: run structure");
+    }
+    q->nh0 = total;
   }
   *out = q;
   return LFGPU_OK;
@@ -356,7 +381,8 @@ extern "C" int lfgpu_raw_eq2(lfgpu_ctx* c, int field, size_t logn, size_t n, con
   return LFGPU_OK;
 }
 
-// n_out == nullptr: enqueue only (no read-back, no synchronisation)
+// Enqueue only: the outputs are ordered on the context's stream; the HQUAD size is a property of the circuit (nh0,
+// computed at upload), so nothing is read back.
 int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
                    const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out) {
   if (!q || !alpha || !beta || !d_hc_out || !d_vc_out || (logv && (!h_G0 || !h_G1))) return LFGPU_ERR_ARG;
@@ -367,34 +393,27 @@ int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G
   const size_t n = q->n;
   const u32 nb = (u32)((n + QD_THREADS - 1) / QD_THREADS);
   void* sc = nullptr;
-  LF_TRY(lf_scratch3(c, q->nv * 16 + (size_t)nb * 4 + 256, &sc));
+  LF_TRY(lf_scratch3(c, q->nv * 16 + 256, &sc));
   elt_t* d_eq = (elt_t*)sc;
-  u32* counts = (u32*)(d_eq + q->nv);
-  u32* total = (u32*)((uint8_t*)c->mailbox_d + 192);
   elt_t be{beta[0], beta[1]};
   LF_TRY(lfgpu_raw_eq2(c, field, logv, q->nv, h_G0, h_G1, alpha, d_eq));
-  hipLaunchKernelGGL(bindg_count_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton, counts);
-  hipLaunchKernelGGL(bindg_scan_kernel, dim3(1), dim3(1024), 0, c->stream, nb, counts, total);
   if (field == LFGPU_FIELD_GF2_128) {
-    LF_HIP(c, hipMemsetAsync(d_vc_out, 0, n * 16, c->stream));  // upper bound on the HQuad size
+    LF_HIP(c, hipMemsetAsync(d_vc_out, 0, q->nh0 * 16, c->stream));
     hipLaunchKernelGGL(bindg_emit_gf_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
-                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)counts, (uint2*)d_hc_out, (u64*)d_vc_out);
+                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)q->d_runoff, (uint2*)d_hc_out, (u64*)d_vc_out);
   } else {
     // Fp128 has no 128-bit atomic add: integer limb accumulators + one reduction per run
     if (n >> 32) return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_g: more than 2^32 terms");
     void* accv = nullptr;
-    LF_TRY(lf_scratch2(c, n * 32 + 64, &accv));
-    LF_HIP(c, hipMemsetAsync(accv, 0, n * 32, c->stream));
+    LF_TRY(lf_scratch2(c, q->nh0 * 32 + 64, &accv));
+    LF_HIP(c, hipMemsetAsync(accv, 0, q->nh0 * 32, c->stream));
     hipLaunchKernelGGL(bindg_emit_fp_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
-                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)counts, (uint2*)d_hc_out, (u64*)accv);
-    hipLaunchKernelGGL(fp_limb_normalize4_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, (const u32*)total, (const u64*)accv,
-                       (elt_t*)d_vc_out);
+                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)q->d_runoff, (uint2*)d_hc_out, (u64*)accv);
+    hipLaunchKernelGGL(fp_limb_normalize4_kernel, dim3((u32)((q->nh0 + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), 0, c->stream,
+                       (const u32*)q->d_nh, (const u64*)accv, (elt_t*)d_vc_out);
   }
   LF_HIP(c, hipGetLastError());
-  if (!n_out) return LFGPU_OK;  // enqueue only: the HQUAD size stays in the device mailbox (lf_quad_bind_g_count)
-  LF_HIP(c, hipMemcpyAsync(c->mailbox_h, total, 4, hipMemcpyDeviceToHost, c->stream));
-  LF_HIP(c, hipStreamSynchronize(c->stream));
-  *n_out = *(const u32*)c->mailbox_h;
+  if (n_out) *n_out = q->nh0;
   return LFGPU_OK;
 }
 extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
@@ -402,8 +421,6 @@ extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, c
   if (!n_out) return LFGPU_ERR_ARG;
   return lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, d_hc_out, d_vc_out, n_out);
 }
-// device word that holds the HQUAD size after an enqueue-only bind_g
-const u32* lf_quad_bind_g_count(lfgpu_ctx* c) { return (const u32*)((uint8_t*)c->mailbox_d + 192); }
 
 
 // ---- Quad::bind_gh_all (lib/sumcheck/quad.h:188-210): the verifier's combined bind, no expansion:
@@ -571,13 +588,9 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     return std::min<size_t>(std::max<size_t>(v, 1024), LF_SC_GRID_MAX);
   }();
   const size_t small_max = (sc_mode == 3 && use_resident) ? grid_max : LF_SC_SMALL_MAX;
-  // Quad::bind_g.  A layer that goes to the shrinking grid from its first round-hand needs the HQUAD size only on the
-  // device (the kernel reads it from the mailbox word): bind_g is then enqueued without read-back or synchronisation
-  // and the cooperative launch follows it on the stream.
-  const bool direct = sc_mode == 3 && use_resident && nt <= small_max && nw <= small_max;
+  // Quad::bind_g: enqueued on the stream, nothing read back (the HQUAD size is a circuit constant)
   const double tv0 = verbose ? clk() : 0;
-  LF_TRY(lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], direct ? nullptr : &nh));
-  if (direct) nh = nt;  // upper bound for the host's bookkeeping
+  LF_TRY(lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], &nh));
   const double tv1 = verbose ? clk() : 0;
   const size_t nh0 = nh;
   bool resident = false, have_r = false;
@@ -624,7 +637,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
       if (small && use_resident) {
         if (!resident && sc_mode == 3) {  // hand the rest of the layer to the shrinking grid
           uint8_t* wb = (uint8_t*)wtmp;
-          LF_TRY(lf_sc_grid_begin(c, field, hc[cur], vc[cur], hc[1 - cur], vc[1 - cur], nh, (direct && rnd == 0 && hand == 0) ? lf_quad_bind_g_count(c) : nullptr,
+          LF_TRY(lf_sc_grid_begin(c, field, hc[cur], vc[cur], hc[1 - cur], vc[1 - cur], nh, nullptr,
                                   WH[0], nW[0], WH[1], nW[1], wb, wb + half, wb + 2 * half, wb + 3 * half, qw, 2 * rnd + hand, logw, grid_state));
         } else if (!resident) {  // ... or to the resident workgroup
           ScSmall a{};
