@@ -139,6 +139,8 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
 #define LF_SC_GRID_STATE_BYTES (64 + 1024 + 32 * LF_SC_GRID_WGS + 4 * LF_SC_GRID_WGS + 64 + 36 * LF_SC_GRID_MAX)
 #define LF_SC_SMALL_MAX 8192  // largest HQUAD / hand array the single-workgroup step takes
 
+int lf_hquad_bind_h_cached(lfgpu_ctx* c, int field, size_t n, const void* d_hc, const void* d_vc, const uint64_t r[2], int hand,
+                           void* d_hc_out, void* d_vc_out, const u32* d_off_cached, u32** d_off_keep, size_t* n_out);  // sumcheck.hip
 struct lfgpu_quad;
 int lf_eval_quad_async(lfgpu_quad* q, const void* d_W, void* d_V, int* d_fail);  // quad.hip
 

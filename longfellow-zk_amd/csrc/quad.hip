@@ -36,6 +36,13 @@ struct lfgpu_quad {
   u32* d_runoff;      // per block of QD_THREADS terms: number of run heads before it
   u32* d_nh;          // device copy of nh0
   size_t nh0;
+  // the same holds for every HQuad::bind_h of the layer's sumcheck: filled by the first proof for the round-hands that
+  // run on the multi-kernel path (per-block output offsets + the size after the bind), reused by every later proof
+  struct BindShape {
+    u32* d_off;
+    size_t n_in, n_out;
+  };
+  std::vector<BindShape> bind_shape;  // indexed by round-hand
 };
 
 // ---- K11: V[g] = sum_{terms of g} kvec[vi] * W[h1] * W[h0]; assert-zero terms must vanish
@@ -253,6 +260,8 @@ extern "C" int lfgpu_quad_free(lfgpu_quad* q) {
   if (q->d_kvec) (void)hipFree(q->d_kvec);
   if (q->d_runoff) (void)hipFree(q->d_runoff);
   if (q->d_nh) (void)hipFree(q->d_nh);
+  for (auto& b : q->bind_shape)
+    if (b.d_off) (void)hipFree(b.d_off);
   delete q;
   return LFGPU_OK;
 }
@@ -703,7 +712,20 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
         LF_TRY(lfgpu_dense_bind(c, field, nW[hand], r, WH[hand], WH[hand]));
       }
       nW[hand] = (nW[hand] + 1) / 2;
-      LF_TRY(lfgpu_hquad_bind_h(c, field, nh, hc[cur], vc[cur], r, hand, hc[1 - cur], vc[1 - cur], &nh));
+      {  // HQuad::bind_h: the merge structure of this round-hand is a circuit constant, kept from the first proof on
+        const size_t rh = 2 * rnd + hand;
+        if (q->bind_shape.size() < 2 * logw) q->bind_shape.resize(2 * logw, lfgpu_quad::BindShape{nullptr, 0, 0});
+        lfgpu_quad::BindShape& bs = q->bind_shape[rh];
+        if (bs.d_off && bs.n_in == nh) {
+          LF_TRY(lf_hquad_bind_h_cached(c, field, nh, hc[cur], vc[cur], r, hand, hc[1 - cur], vc[1 - cur], bs.d_off, nullptr, nullptr));
+          nh = bs.n_out;
+        } else {
+          if (bs.d_off) (void)hipFree(bs.d_off);
+          bs = lfgpu_quad::BindShape{nullptr, nh, 0};
+          LF_TRY(lf_hquad_bind_h_cached(c, field, nh, hc[cur], vc[cur], r, hand, hc[1 - cur], vc[1 - cur], nullptr, &bs.d_off, &nh));
+          bs.n_out = nh;
+        }
+      }
       cur = 1 - cur;
       if (verbose) {
         t_large += clk() - tr0;

@@ -1444,6 +1444,35 @@ extern "C" int lfgpu_hquad_bind_h(lfgpu_ctx* c, int field, size_t n, const void*
   return LFGPU_OK;
 }
 
+// HQuad::bind_h for a caller that keeps the merge structure: which entries merge depends on the corner indices only
+// (hquad.h:90-123), i.e. on the circuit and the position in the layer, never on the challenges.
+//   d_off_cached == nullptr: count + scan + emit as lfgpu_hquad_bind_h; *d_off_keep (if asked for) receives a
+//                            persistent copy of the per-block output offsets, *n_out the new size (one synchronisation);
+//   d_off_cached != nullptr: emit only with those offsets -- no count, no scan, nothing read back.
+int lf_hquad_bind_h_cached(lfgpu_ctx* c, int field, size_t n, const void* d_hc, const void* d_vc, const uint64_t r[2], int hand,
+                           void* d_hc_out, void* d_vc_out, const u32* d_off_cached, u32** d_off_keep, size_t* n_out) {
+  if (n == 0) return lf_fail(c, LFGPU_ERR_ARG, "hquad_bind_h_cached: empty");
+  const u32 nb = (u32)((n + SC_THREADS - 1) / SC_THREADS);
+  const elt_t rr{r[0], r[1]};
+  hand = hand ? 1 : 0;
+  if (d_off_cached) {
+    DISPATCH_FIELD(field, hquad_emit_kernel, dim3(nb), dim3(SC_THREADS), n, (const uint2*)d_hc, (const elt_t*)d_vc, rr,
+                   hand, d_off_cached, (uint2*)d_hc_out, (elt_t*)d_vc_out);
+    LF_HIP(c, hipGetLastError());
+    return LFGPU_OK;
+  }
+  LF_TRY(lfgpu_hquad_bind_h(c, field, n, d_hc, d_vc, r, hand, d_hc_out, d_vc_out, n_out));
+  if (d_off_keep) {  // the offsets still stand in the scratch the call above used (nothing ran since)
+    void* sc = nullptr;
+    LF_TRY(lf_scratch2(c, (size_t)nb * 4 + 64, &sc));
+    u32* keep = nullptr;
+    if (hipMalloc((void**)&keep, (size_t)nb * 4) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "hquad_bind_h_cached: offsets");
+    LF_HIP(c, hipMemcpyAsync(keep, sc, (size_t)nb * 4, hipMemcpyDeviceToDevice, c->stream));
+    *d_off_keep = keep;
+  }
+  return LFGPU_OK;
+}
+
 extern "C" int lfgpu_rows_axpy(lfgpu_ctx* c, int field, size_t nrows, size_t n, void* d_y, const uint64_t* h_u,
                                const void* d_T, size_t ld) {
   if (!c || (n && !d_y) || (nrows && (!h_u || !d_T))) return lf_fail(c, LFGPU_ERR_ARG, "rows_axpy: null argument");
