@@ -32,8 +32,13 @@ res = {"nb": nb, "field": "Fp128" if FP else "GF2_128", "shape": {k: info[k] for
 
 # 1. parity: same RandomEngine and transcript seed as the reference run that made the fixtures
 ts = pkg.FsTranscript(b"test")
+torch.cuda.synchronize()
+t0 = time.perf_counter()
 zk.commit(W, lf.LcgRng(100).bytes, ts)
 assert zk.prove(W, ts)
+# the first proof on a freshly uploaded circuit also fills the per-circuit caches (bind shapes of the multi-kernel rounds,
+# scratch growth, kernel module loads) and draws its randomness through a Python callback: not the steady state
+res["gpu_first_proof_ms_python_rng"] = round((time.perf_counter() - t0) * 1e3, 3)
 wire = zk.wire()
 assert len(wire) == info["zk_wire_bytes"] and hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"], "proof differs from the reference"
 ts.close()
