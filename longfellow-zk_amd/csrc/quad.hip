@@ -15,9 +15,11 @@
 #include <numeric>
 
 #include "ctx.h"
+#include "runfold.h"
 #include <chrono>
 
 #define QD_THREADS 256
+#define BG_THREADS 1024  // Quad::bind_g kernels: long runs fold inside the block (runfold.h)
 
 struct __attribute__((aligned(16))) corner4 {
   u32 g, h0, h1, vi;
@@ -33,7 +35,7 @@ struct lfgpu_quad {
   elt_t* d_kvec;      // nk constants
   // the run structure of the canonical order (which terms share a hand pair) depends on the circuit only: block offsets of
   // the run heads and the HQUAD size of Quad::bind_g are computed once at upload
-  u32* d_runoff;      // per block of QD_THREADS terms: number of run heads before it
+  u32* d_runoff;      // per block of BG_THREADS terms: number of run heads before it
   u32* d_nh;          // device copy of nh0
   size_t nh0;
   // the same holds for every HQuad::bind_h of the layer's sumcheck: filled by the first proof for the round-hands that
@@ -120,12 +122,12 @@ __device__ __forceinline__ bool is_head(const corner4* t, size_t i) {
   if (i == 0) return true;
   return t[i].h0 != t[i - 1].h0 || t[i].h1 != t[i - 1].h1;
 }
-__global__ __launch_bounds__(QD_THREADS) void bindg_count_kernel(size_t n, const corner4* __restrict__ t,
+__global__ __launch_bounds__(BG_THREADS) void bindg_count_kernel(size_t n, const corner4* __restrict__ t,
                                                                  u32* __restrict__ block_counts) {
   __shared__ u32 cnt;
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
-  size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x;
+  size_t i = (size_t)blockIdx.x * BG_THREADS + threadIdx.x;
   bool head = i < n && is_head(t, i);
   u64 mask = __ballot(head);
   if ((threadIdx.x & 63) == 0) atomicAdd(&cnt, (u32)__popcll(mask));
@@ -162,13 +164,13 @@ __global__ __launch_bounds__(1024) void bindg_scan_kernel(u32 nblocks, u32* __re
 // term computes its own product, a wave folds equal-run neighbours with shuffles (runs are contiguous
 // in canonical order), and the last lane of each run fragment issues one pair of 64-bit atomic XORs --
 // exact and order-independent because addition in GF(2^128) is XOR.  d_vc_out must be zeroed first.
-__global__ __launch_bounds__(QD_THREADS) void bindg_emit_gf_kernel(size_t n, const corner4* __restrict__ t,
+__global__ __launch_bounds__(BG_THREADS) void bindg_emit_gf_kernel(size_t n, const corner4* __restrict__ t,
                                                                    const elt_t* __restrict__ kvec,
                                                                    const elt_t* __restrict__ eq, elt_t beta,
                                                                    const u32* __restrict__ block_off,
                                                                    uint2* __restrict__ hc_out, u64* __restrict__ vc_out) {
-  __shared__ u32 wave_off[QD_THREADS / 64];
-  const size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x;
+  __shared__ u32 wave_off[BG_THREADS / 64];
+  const size_t i = (size_t)blockIdx.x * BG_THREADS + threadIdx.x;
   const bool valid = i < n;
   const bool head = valid && is_head(t, i);
   const u64 mask = __ballot(head);
@@ -188,34 +190,18 @@ __global__ __launch_bounds__(QD_THREADS) void bindg_emit_gf_kernel(size_t n, con
     pv = gf_mul(v, ld16(&eq[c0.g]));
   }
   if (head) hc_out[ri] = make_uint2(c0.h0, c0.h1);
-  // segmented suffix fold inside the wave: lane keeps the XOR of its run's terms at lanes >= itself
-  const u32 key = valid ? ri : 0xffffffffu;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const u64 olo = __shfl_down(pv.lo, off, 64), ohi = __shfl_down(pv.hi, off, 64);
-    const u32 okey = __shfl_down(key, off, 64);
-    if (lane + off < 64 && okey == key) {
-      pv.lo ^= olo;
-      pv.hi ^= ohi;
-    }
-  }
-  // the first lane of each run fragment in the wave now holds the fragment's sum
-  const u32 pkey = __shfl_up(key, 1, 64);
-  if (valid && (lane == 0 || pkey != key)) {
-    atomicXor(&vc_out[2 * (size_t)ri], pv.lo);
-    atomicXor(&vc_out[2 * (size_t)ri + 1], pv.hi);
-  }
+  gf_run_fold_commit<BG_THREADS>(valid ? ri : 0xffffffffu, pv, vc_out);  // one atomic pair per run and block
 }
 
 // Fp128 variant: same per-term parallelism; the run sums are accumulated as plain integers in four
 // 64-bit limb accumulators per run (residues add as integers; < 2^32 terms per run) and reduced once.
-__global__ __launch_bounds__(QD_THREADS) void bindg_emit_fp_kernel(size_t n, const corner4* __restrict__ t,
+__global__ __launch_bounds__(BG_THREADS) void bindg_emit_fp_kernel(size_t n, const corner4* __restrict__ t,
                                                                    const elt_t* __restrict__ kvec,
                                                                    const elt_t* __restrict__ eq, elt_t beta,
                                                                    const u32* __restrict__ block_off,
                                                                    uint2* __restrict__ hc_out, u64* __restrict__ acc) {
-  __shared__ u32 wave_off[QD_THREADS / 64];
-  const size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x;
+  __shared__ u32 wave_off[BG_THREADS / 64];
+  const size_t i = (size_t)blockIdx.x * BG_THREADS + threadIdx.x;
   const bool valid = i < n;
   const bool head = valid && is_head(t, i);
   const u64 mask = __ballot(head);
@@ -308,11 +294,11 @@ extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32
     return lf_fail(c, LFGPU_ERR_NOMEM, "quad_upload: device allocation / copy failed");
   }
   {  // run heads: counts per block -> exclusive offsets + total
-    const u32 nb = (u32)((n + QD_THREADS - 1) / QD_THREADS);
+    const u32 nb = (u32)((n + BG_THREADS - 1) / BG_THREADS);
     u32 total = 0;
     ok = hipMalloc((void**)&q->d_runoff, (size_t)nb * 4) == hipSuccess && hipMalloc((void**)&q->d_nh, 4) == hipSuccess;
     if (ok) {
-      hipLaunchKernelGGL(bindg_count_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton, q->d_runoff);
+      hipLaunchKernelGGL(bindg_count_kernel, dim3(nb), dim3(BG_THREADS), 0, c->stream, n, (const corner4*)q->d_morton, q->d_runoff);
       hipLaunchKernelGGL(bindg_scan_kernel, dim3(1), dim3(1024), 0, c->stream, nb, q->d_runoff, q->d_nh);
       ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&total, q->d_nh, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
            hipStreamSynchronize(c->stream) == hipSuccess;
@@ -400,7 +386,7 @@ int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G
   LF_HIP(c, hipSetDevice(c->device));
   const int field = q->field;
   const size_t n = q->n;
-  const u32 nb = (u32)((n + QD_THREADS - 1) / QD_THREADS);
+  const u32 nb = (u32)((n + BG_THREADS - 1) / BG_THREADS);
   void* sc = nullptr;
   LF_TRY(lf_scratch3(c, q->nv * 16 + 256, &sc));
   elt_t* d_eq = (elt_t*)sc;
@@ -408,7 +394,7 @@ int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G
   LF_TRY(lfgpu_raw_eq2(c, field, logv, q->nv, h_G0, h_G1, alpha, d_eq));
   if (field == LFGPU_FIELD_GF2_128) {
     LF_HIP(c, hipMemsetAsync(d_vc_out, 0, q->nh0 * 16, c->stream));
-    hipLaunchKernelGGL(bindg_emit_gf_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
+    hipLaunchKernelGGL(bindg_emit_gf_kernel, dim3(nb), dim3(BG_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
                        (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)q->d_runoff, (uint2*)d_hc_out, (u64*)d_vc_out);
   } else {
     // Fp128 has no 128-bit atomic add: integer limb accumulators + one reduction per run
@@ -416,7 +402,7 @@ int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G
     void* accv = nullptr;
     LF_TRY(lf_scratch2(c, q->nh0 * 32 + 64, &accv));
     LF_HIP(c, hipMemsetAsync(accv, 0, q->nh0 * 32, c->stream));
-    hipLaunchKernelGGL(bindg_emit_fp_kernel, dim3(nb), dim3(QD_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
+    hipLaunchKernelGGL(bindg_emit_fp_kernel, dim3(nb), dim3(BG_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
                        (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)q->d_runoff, (uint2*)d_hc_out, (u64*)accv);
     hipLaunchKernelGGL(fp_limb_normalize4_kernel, dim3((u32)((q->nh0 + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), 0, c->stream,
                        (const u32*)q->d_nh, (const u64*)accv, (elt_t*)d_vc_out);

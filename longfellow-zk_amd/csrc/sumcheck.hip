@@ -9,6 +9,7 @@
 // The Fiat-Shamir transcript stays on the host, so each round returns two field
 // elements through a pinned mailbox and receives one challenge.
 #include "ctx.h"
+#include "runfold.h"
 #include <chrono>
 #include <utility>
 #include <vector>
@@ -82,38 +83,19 @@ __global__ __launch_bounds__(SC_THREADS) void sumcheck_final_kernel(u32 nblocks,
 // term are exact and order-independent.  One wire (the constant 1) is the target of up to 2*10^5 terms of a
 // flatsha256 layer and its terms are mostly adjacent in canonical order, so equal-target neighbours are first
 // folded inside the wave with shuffles; only the first lane of each run of equal targets issues atomics.
-__global__ __launch_bounds__(SC_THREADS) void qw_scatter_gf_kernel(size_t n, const uint2* __restrict__ hc,
-                                                                   const elt_t* __restrict__ vc, int hand,
-                                                                   const elt_t* __restrict__ Wo, u64* __restrict__ QW) {
-  const size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
-  const u32 lane = threadIdx.x & 63;
-  const bool valid = i < n;
+#define SCAT_THREADS 1024  // the fold of equal-target runs spans the block (runfold.h)
+__global__ __launch_bounds__(SCAT_THREADS) void qw_scatter_gf_kernel(size_t n, const uint2* __restrict__ hc,
+                                                                     const elt_t* __restrict__ vc, int hand,
+                                                                     const elt_t* __restrict__ Wo, u64* __restrict__ QW) {
+  const size_t i = (size_t)blockIdx.x * SCAT_THREADS + threadIdx.x;
   u32 key = 0xffffffffu;
   elt_t t = elt_zero();
-  if (valid) {
+  if (i < n) {
     uint2 h = hc[i];
     key = hand ? h.y : h.x;
     t = gf_mul(ld16(&vc[i]), ld16(&Wo[hand ? h.x : h.y]));
   }
-  // runs of CONTIGUOUS equal targets: run id = number of run heads at or before the lane (monotone), so
-  // "same run id" implies every lane in between has the same target and the suffix fold below is exact
-  const u32 pkey = __shfl_up(key, 1, 64);
-  const bool head = lane == 0 || pkey != key;
-  const u64 hmask = __ballot(head);
-  const u32 rid = (u32)__popcll(hmask & ((2ull << lane) - 1));
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const u64 olo = __shfl_down(t.lo, off, 64), ohi = __shfl_down(t.hi, off, 64);
-    const u32 orid = __shfl_down(rid, off, 64);
-    if (lane + off < 64 && orid == rid) {
-      t.lo ^= olo;
-      t.hi ^= ohi;
-    }
-  }
-  if (valid && head) {
-    atomicXor(&QW[2 * (size_t)key], t.lo);
-    atomicXor(&QW[2 * (size_t)key + 1], t.hi);
-  }
+  gf_run_fold_commit<SCAT_THREADS>(key, t, QW);  // runs of CONTIGUOUS equal targets: one atomic pair per run and block
 }
 
 // Fp128 has no 128-bit atomic, but residues add as plain integers: every product v*W (a canonical residue
@@ -1394,8 +1376,8 @@ extern "C" int lfgpu_qw_scatter(lfgpu_ctx* c, int field, size_t n, const void* d
   }
   LF_HIP(c, hipMemsetAsync(d_QW, 0, nqw * 16, c->stream));
   if (n) {
-    u32 nb = (u32)((n + SC_THREADS - 1) / SC_THREADS);
-    hipLaunchKernelGGL(qw_scatter_gf_kernel, dim3(nb), dim3(SC_THREADS), 0, c->stream, n, (const uint2*)d_hc,
+    u32 nb = (u32)((n + SCAT_THREADS - 1) / SCAT_THREADS);
+    hipLaunchKernelGGL(qw_scatter_gf_kernel, dim3(nb), dim3(SCAT_THREADS), 0, c->stream, n, (const uint2*)d_hc,
                        (const elt_t*)d_vc, hand ? 1 : 0, (const elt_t*)d_Wother, (u64*)d_QW);
     LF_HIP(c, hipGetLastError());
   }
