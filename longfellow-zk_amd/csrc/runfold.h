@@ -76,5 +76,6 @@ __device__ __forceinline__ void gf_run_fold_commit(u32 key, elt_t t, u64* __rest
     }
     flush();
   }
+  __syncthreads();  // the LDS words are free again: the caller may be in a loop
 }
 #endif
