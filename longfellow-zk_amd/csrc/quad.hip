@@ -93,18 +93,28 @@ __global__ __launch_bounds__(QD_THREADS) void raw_eq2_kernel(u32 logn, u32 n, co
 template <int F>
 __global__ __launch_bounds__(QD_THREADS) void eq_tables_kernel(u32 logn, u32 lb, const elt_t* __restrict__ G /*G0|G1|1-G0|1-G1*/, elt_t alpha,
                                                                elt_t one, elt_t* __restrict__ tab) {
+  // four lanes per entry, each multiplies every fourth factor, two shuffle steps combine them: the kernel is a chain of
+  // dependent products (its tables are tiny), so the depth -- ceil(bits / 4) + 2 instead of bits -- is its run time
   const u32 hb = logn - lb, nlo = 1u << lb, nhi = 1u << hb;
-  const u32 t = blockIdx.x * QD_THREADS + threadIdx.x;
-  if (t >= 2 * (nlo + nhi)) return;
-  const u32 which = t < nlo ? 0 : t < nlo + nhi ? 1 : t < 2 * nlo + nhi ? 2 : 3;  // LO0, HI0, LO1, HI1
-  const u32 j = which == 0 ? t : which == 1 ? t - nlo : which == 2 ? t - nlo - nhi : t - 2 * nlo - nhi;
+  const u32 tid = blockIdx.x * QD_THREADS + threadIdx.x, t = tid >> 2, part = tid & 3;
+  const bool live = t < 2 * (nlo + nhi);  // whole quads are live or idle together (the entry count is even)
+  const u32 tt = live ? t : 0;
+  const u32 which = tt < nlo ? 0 : tt < nlo + nhi ? 1 : tt < 2 * nlo + nhi ? 2 : 3;  // LO0, HI0, LO1, HI1
+  const u32 j = which == 0 ? tt : which == 1 ? tt - nlo : which == 2 ? tt - nlo - nhi : tt - 2 * nlo - nhi;
   const u32 bits = (which & 1) ? hb : lb, shift = (which & 1) ? lb : 0, g = which >> 1;  // g: 0 -> G0, 1 -> G1
-  elt_t e = which == 3 ? alpha : one;
-  for (u32 l = 0; l < bits; ++l) {
+  elt_t e = (which == 3 && part == 0) ? alpha : one;
+  for (u32 l = part; l < bits; l += 4) {
     const u32 bit = (j >> l) & 1;
     e = Fld<F>::mul(e, ld16(&G[(bit ? g * logn : (2 + g) * logn) + shift + l]));
   }
-  st16(&tab[t], e);
+#pragma unroll
+  for (int x = 1; x <= 2; x <<= 1) {
+    elt_t o;
+    o.lo = __shfl_xor(e.lo, x, 64);
+    o.hi = __shfl_xor(e.hi, x, 64);
+    e = Fld<F>::mul(e, o);
+  }
+  if (live && part == 0) st16(&tab[t], e);
 }
 template <int F>
 __global__ __launch_bounds__(QD_THREADS) void raw_eq2_split_kernel(u32 logn, u32 lb, u32 n, const elt_t* __restrict__ tab, elt_t* __restrict__ eq) {
@@ -367,7 +377,7 @@ extern "C" int lfgpu_raw_eq2(lfgpu_ctx* c, int field, size_t logn, size_t n, con
     QD_DISPATCH(field, raw_eq2_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, (u32)n,
                 (const elt_t*)d_G, al, one, (elt_t*)d_eq);
   } else {
-    QD_DISPATCH(field, eq_tables_kernel, dim3((u32)((ntab + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, lb, (const elt_t*)d_G, al,
+    QD_DISPATCH(field, eq_tables_kernel, dim3((u32)((4 * ntab + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, lb, (const elt_t*)d_G, al,
                 one, d_tab);
     QD_DISPATCH(field, raw_eq2_split_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, lb, (u32)n,
                 (const elt_t*)d_tab, (elt_t*)d_eq);
