@@ -433,13 +433,14 @@ extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, c
 // Three EQ tables by raw_eq2_kernel, then one pass over the corners with a block-reduced sum; the device-wide fold
 // of the block sums uses XOR words (GF2_128) / 32-bit-limb integer accumulators (Fp128), so it is exact and
 // independent of arrival order.
+#define BGH_THREADS 1024  // few, large blocks: every block ends with one atomic pair on the same accumulator words
 template <int F>
-__global__ __launch_bounds__(QD_THREADS) void bind_gh_all_kernel(size_t n, const corner4* __restrict__ t, const elt_t* __restrict__ kvec,
+__global__ __launch_bounds__(BGH_THREADS) void bind_gh_all_kernel(size_t n, const corner4* __restrict__ t, const elt_t* __restrict__ kvec,
                                                                  const elt_t* __restrict__ eqg, const elt_t* __restrict__ eqh0,
                                                                  const elt_t* __restrict__ eqh1, elt_t beta, u64* __restrict__ acc) {
-  __shared__ elt_t sh[QD_THREADS / 64];
+  __shared__ elt_t sh[BGH_THREADS / 64];
   elt_t s = elt_zero();
-  for (size_t i = (size_t)blockIdx.x * QD_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * QD_THREADS) {
+  for (size_t i = (size_t)blockIdx.x * BGH_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * BGH_THREADS) {
     const corner4 cr = t[i];
     elt_t v = ld16(&kvec[cr.vi]);
     if ((v.lo | v.hi) == 0) v = beta;  // prep_v: assert-zero terms carry beta (quad.h:213-220)
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(QD_THREADS) void bind_gh_all_kernel(size_t n, const
   if (lane == 0) sh[wave] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (u32 w = 1; w < QD_THREADS / 64; ++w) s = Fld<F>::add(s, sh[w]);
+    for (u32 w = 1; w < BGH_THREADS / 64; ++w) s = Fld<F>::add(s, sh[w]);
     if (F == FIELD_GF2_128) {
       atomicXor(&acc[0], s.lo);
       atomicXor(&acc[1], s.hi);
@@ -491,10 +492,10 @@ int lf_quad_bind_gh_all_enqueue(lfgpu_quad* q, size_t logv, const void* h_G0, co
   LF_TRY(lfgpu_raw_eq2(c, field, logw, nw, h_H1, h_H1, zero, d_eqh1));
   LF_HIP(c, hipMemsetAsync(d_acc, 0, 32, c->stream));
   const elt_t be{beta[0], beta[1]};
-  u32 nb = (u32)((q->n + QD_THREADS - 1) / QD_THREADS);
-  if (nb > 2048) nb = 2048;
+  u32 nb = (u32)((q->n + BGH_THREADS - 1) / BGH_THREADS);
+  if (nb > 512) nb = 512;
   if (nb == 0) nb = 1;
-  QD_DISPATCH(field, bind_gh_all_kernel, dim3(nb), dim3(QD_THREADS), q->n, (const corner4*)q->d_morton, (const elt_t*)q->d_kvec,
+  QD_DISPATCH(field, bind_gh_all_kernel, dim3(nb), dim3(BGH_THREADS), q->n, (const corner4*)q->d_morton, (const elt_t*)q->d_kvec,
               (const elt_t*)d_eqg, (const elt_t*)d_eqh0, (const elt_t*)d_eqh1, be, d_acc);
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
