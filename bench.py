@@ -176,12 +176,28 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare with --gpus N: become the launcher.  Nothing in this process has touched the GPU (torch is not even
+        # imported yet); the N ranks are children of torch.distributed.run, one per GPU, and their single JSON line
+        # (printed by rank 0) passes through.
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print("bench: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d (the ranks that exist)" % (args.gpus, world, world), file=sys.stderr)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -102,6 +102,11 @@ int lfgpu_fp128_rs_encode_rows(lfgpu_ctx* ctx, size_t nrow, size_t n, size_t m, 
  * device for lfgpu_merkle_open.  root_out: 32 host bytes. */
 int lfgpu_column_commit(lfgpu_ctx* ctx, int field, size_t nrow, size_t ld, size_t col0, size_t ncols,
                         const void* d_T, const void* d_nonces, void* d_layers, uint8_t root_out[32]);
+/* The leaf half of the above alone (enqueue only, nothing read back): d_leaves[j] = leaf digest of column col0 + j,
+ * j < ncols, 32 bytes each.  Multi-GPU commit: after the column re-partition a rank hashes the columns it
+ * owns, the digests are all-gathered into the leaf level of d_layers and lfgpu_merkle_build_tree finishes on every rank. */
+int lfgpu_column_leaves(lfgpu_ctx* ctx, int field, size_t nrow, size_t ld, size_t col0, size_t ncols,
+                        const void* d_T, const void* d_nonces, void* d_leaves);
 /* MerkleTree::build_tree alone: d_layers[ncols..2*ncols) hold the leaves. */
 int lfgpu_merkle_build_tree(lfgpu_ctx* ctx, size_t n, void* d_layers, uint8_t root_out[32]);
 /* MerkleTree::generate_compressed_proof (lib/merkle/merkle_tree.h:122-143):
@@ -219,6 +224,30 @@ typedef struct lfgpu_ligero_prover lfgpu_ligero_prover;
 int lfgpu_ligero_commit(lfgpu_ctx* ctx, int field, int subfield_log_bits, const lfgpu_ligero_param* p,
                         const void* h_W, size_t subfield_boundary, const size_t* h_lqc, lfgpu_rng_fn rng,
                         void* rng_user, uint8_t root_out[32], lfgpu_ligero_prover** out);
+/* LigeroProver::commit split for a row slab [row_lo, row_hi) of the tableau -- the multi-GPU form (rows are independent
+ * up to the RandomEngine's draw order, lib/ligero/ligero_prover.h:171-270).
+ *  lfgpu_ligero_layout_rows: HOST ONLY (no context, no device).  Performs every RandomEngine draw of commit in the
+ *    reference's order -- blinding rows, witness-row pads, quadratic-row pads, then the block_ext Merkle nonces -- and
+ *    writes the un-encoded image of the slab's rows to h_rows [(row_hi-row_lo)][dblock] (rows outside the slab are drawn
+ *    and dropped).  Ranks that are handed the same byte stream (one engine's output broadcast, or one seed) therefore hold
+ *    consistent slabs of one tableau.  h_nonces: block_ext * 32 bytes, or NULL.
+ *  lfgpu_ligero_encode_rows: uploads h_rows and RS-extends each row to block_enc into d_slab [(row_hi-row_lo)][block_enc]
+ *    (rows IDOT / IQUAD carry dblock values, the others block).
+ * lfgpu_ligero_commit is exactly layout_rows + encode_rows on [0, nrow) followed by lfgpu_column_commit. */
+int lfgpu_ligero_layout_rows(int field, int subfield_log_bits, const lfgpu_ligero_param* p, const void* h_W,
+                             size_t subfield_boundary, const size_t* h_lqc, lfgpu_rng_fn rng, void* rng_user,
+                             size_t row_lo, size_t row_hi, void* h_rows, uint8_t* h_nonces);
+int lfgpu_ligero_encode_rows(lfgpu_ctx* ctx, int field, int subfield_log_bits, const lfgpu_ligero_param* p,
+                             size_t row_lo, size_t row_hi, const void* h_rows, void* d_slab);
+/* A prover object over a slab that was laid out and encoded with the two calls above (not owning d_slab / d_layers).
+ * The prove entry points below then return the slab's PARTIAL results: rows the slab does not hold contribute zero to
+ * y_ldt / y_dot / y_quad (the caller folds the ranks' vectors with the field's addition and checks the W part of y_quad),
+ * lfgpu_ligero_open returns the slab's rows of req.  The quadratic rows [iq, nrow) must lie in ONE slab (a triple is
+ * multiplied element-wise).  d_layers (whole heap, 2*block_ext*32 bytes) and h_nonces (block_ext*32) are only needed for
+ * lfgpu_ligero_open and may be NULL. */
+int lfgpu_ligero_prover_from_slab(lfgpu_ctx* ctx, int field, int subfield_log_bits, const lfgpu_ligero_param* p,
+                                  size_t row_lo, size_t row_hi, void* d_slab, void* d_layers, const uint8_t* h_nonces,
+                                  lfgpu_ligero_prover** out);
 /* low_degree_proof (:281-291): y[block] = T[ildt] + sum_i u_ldt[i] T[iw+i] */
 int lfgpu_ligero_low_degree_proof(lfgpu_ligero_prover* pr, const void* h_u_ldt, void* h_y);
 /* dot_proof (:293-309): y[dblock] = T[idot] + sum_i RS(block->dblock)([0^r | A_i]) (.) T[iw+i] */

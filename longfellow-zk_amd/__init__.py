@@ -24,11 +24,11 @@ FP128_P = 2**128 - 2**108 + 1
 ABI_SYMBOLS = [
     "lfgpu_init", "lfgpu_shutdown", "lfgpu_last_error", "lfgpu_set_stream", "lfgpu_sync", "lfgpu_malloc",
     "lfgpu_free", "lfgpu_memcpy_h2d", "lfgpu_memcpy_d2h", "lfgpu_fp128_fft", "lfgpu_gf2128_lch14_fft",
-    "lfgpu_gf2128_rs_encode_rows", "lfgpu_gf2128_rs_encode_tableau", "lfgpu_fp128_rs_encode_rows", "lfgpu_column_commit", "lfgpu_merkle_build_tree",
+    "lfgpu_gf2128_rs_encode_rows", "lfgpu_gf2128_rs_encode_tableau", "lfgpu_fp128_rs_encode_rows", "lfgpu_column_commit", "lfgpu_column_leaves", "lfgpu_merkle_build_tree",
     "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
     "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_field_binop", "lfgpu_fp128_fft_host", "lfgpu_gf2128_lch14_fft_host",
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
-    "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
+    "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_layout_rows", "lfgpu_ligero_encode_rows", "lfgpu_ligero_prover_from_slab", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
     "lfgpu_ligero_inner_product_rows", "lfgpu_ligero_dot_proof_sparse",
     "lfgpu_ligero_quadratic_proof", "lfgpu_ligero_open", "lfgpu_ligero_tableau", "lfgpu_ligero_free",
     "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g", "lfgpu_sumcheck_layer", "lfgpu_raw_eq2", "lfgpu_quad_bind_gh_all",
@@ -100,6 +100,7 @@ def load_library():
         "lfgpu_gf2128_rs_encode_tableau": [vp, ci, sz, sz, sz, sz, sz, sz, vp, sz],
         "lfgpu_fp128_rs_encode_rows": [vp, sz, sz, sz, pu64, u64, vp, sz],
         "lfgpu_column_commit": [vp, ci, sz, sz, sz, sz, vp, vp, vp, vp],
+        "lfgpu_column_leaves": [vp, ci, sz, sz, sz, sz, vp, vp, vp],
         "lfgpu_merkle_build_tree": [vp, sz, vp, vp],
         "lfgpu_merkle_open": [vp, sz, vp, vp, sz, vp, sz, C.POINTER(sz)],
         "lfgpu_sumcheck_partials": [vp, ci, sz, vp, vp, pu64, pu64],
@@ -115,6 +116,9 @@ def load_library():
         "lfgpu_column_commit_host": [vp, ci, sz, sz, sz, sz, vp, vp, vp, vp],
         "lfgpu_ligero_param_init": [C.POINTER(LigeroParam), ci, ci, sz, sz, sz, sz, sz],
         "lfgpu_ligero_commit": [vp, ci, ci, C.POINTER(LigeroParam), vp, sz, vp, RNG_FN, vp, vp, C.POINTER(vp)],
+        "lfgpu_ligero_layout_rows": [ci, ci, C.POINTER(LigeroParam), vp, sz, vp, RNG_FN, vp, sz, sz, vp, vp],
+        "lfgpu_ligero_encode_rows": [vp, ci, ci, C.POINTER(LigeroParam), sz, sz, vp, vp],
+        "lfgpu_ligero_prover_from_slab": [vp, ci, ci, C.POINTER(LigeroParam), sz, sz, vp, vp, vp, C.POINTER(vp)],
         "lfgpu_ligero_low_degree_proof": [vp, vp, vp],
         "lfgpu_ligero_dot_proof": [vp, vp, vp],
         "lfgpu_ligero_inner_product_rows": [vp, ci, sz, sz, sz, sz, vp, sz, vp, vp, vp, sz, vp],
@@ -292,6 +296,14 @@ class LfGpu:
                                            C.c_void_p(d_hc_out), C.c_void_p(d_vc_out), C.byref(n_out)))
         return n_out.value
 
+    # --- Eqs::raw_eq2 (reference lib/arrays/eqs.h:46-80)
+    def raw_eq2(self, field, logn, n, G0, G1, alpha, d_eq):
+        """eq[i] = EQ(G0, i) + alpha EQ(G1, i), i < n; G0 / G1: numpy uint64[logn][2] host arrays"""
+        import numpy as np
+        G0, G1 = np.ascontiguousarray(G0, dtype=np.uint64), np.ascontiguousarray(G1, dtype=np.uint64)
+        self._ck(self.L.lfgpu_raw_eq2(self.h, field, logn, n, C.c_void_p(G0.ctypes.data), C.c_void_p(G1.ctypes.data),
+                                      _u64x2(alpha), C.c_void_p(d_eq)))
+
     def field_binop(self, field, op, n, d_a, d_b, d_out):
         """element-wise Field::addf/subf/mulf (op 0/1/2)"""
         self._ck(self.L.lfgpu_field_binop(self.h, field, op, n, C.c_void_p(d_a), C.c_void_p(d_b), C.c_void_p(d_out)))
@@ -401,12 +413,13 @@ class LigeroProver:
                                                              C.c_void_p(y0.ctypes.data), C.c_void_p(y2.ctypes.data)))
         return y0, y2
 
-    def open(self, idx):
-        """compute_req + MerkleCommitment::open -> (req[nrow][nreq], nonces[nreq], path digests)"""
+    def open(self, idx, rows=None):
+        """compute_req + MerkleCommitment::open -> (req[nrow][nreq], nonces[nreq], path digests); a slab prover
+        (parallel.GpuEngine.slab_prover) returns its own `rows` rows of req"""
         import numpy as np
         p = self.p
         idx_a = (C.c_size_t * p.nreq)(*idx)
-        req = np.zeros((p.nrow, p.nreq, 2), dtype=np.uint64)
+        req = np.zeros((p.nrow if rows is None else rows, p.nreq, 2), dtype=np.uint64)
         nonces = np.zeros((p.nreq, 32), dtype=np.uint8)
         cap = p.nreq * p.mc_pathlen + 1
         path = np.zeros((cap, 32), dtype=np.uint8)

@@ -29,6 +29,7 @@ static int grow(lfgpu_ctx* c, void** buf, size_t* cap, size_t bytes, void** out)
 int lf_scratch(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch, &c->scratch_bytes, bytes, out); }
 int lf_scratch2(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch2, &c->scratch2_bytes, bytes, out); }
 int lf_scratch3(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch3, &c->scratch3_bytes, bytes, out); }
+int lf_scratch4(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch4, &c->scratch4_bytes, bytes, out); }
 
 int lf_stage_upload(lfgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
   const unsigned slot = c->stage_next & 3;
@@ -99,10 +100,9 @@ elt_t h_fp_inv(elt_t x) {  // x^(p-2)
 }
 
 // GF2_128<k> ctor + LCH14 ctor constants (lib/gf2k/gf2_128.h:97-116,369-391; lch14.h:45-77)
-const GfHostCtx* lf_gf_ctx(lfgpu_ctx* c, int k) {
-  if (k != 4 && k != 5) return nullptr;
-  GfHostCtx* g = &c->gf[k - 4];
-  if (g->init) return g;
+bool lf_gf_ctx_build(GfHostCtx* g, int k) {
+  if (k != 4 && k != 5) return false;
+  if (g->init) return true;
   g->k = k;
   g->sub_bits = 1u << k;
   elt_t r{2, 0};
@@ -124,7 +124,12 @@ const GfHostCtx* lf_gf_ctx(lfgpu_ctx* c, int k) {
     for (unsigned j = 0; j < sb; ++j) g->w_hat[i][j] = gf_mul(sc, g->w_hat[i][j]);
   }
   g->init = true;
-  return g;
+  return true;
+}
+const GfHostCtx* lf_gf_ctx(lfgpu_ctx* c, int k) {
+  if (k != 4 && k != 5) return nullptr;
+  GfHostCtx* g = &c->gf[k - 4];
+  return lf_gf_ctx_build(g, k) ? g : nullptr;
 }
 // LCH14::twiddle (lch14.h:81-89)
 elt_t h_lch14_twiddle(const GfHostCtx* g, unsigned i, u64 u) {
@@ -178,6 +183,7 @@ int lfgpu_shutdown(lfgpu_ctx* c) {
   if (c->scratch) hipFree(c->scratch);
   if (c->scratch2) hipFree(c->scratch2);
   if (c->scratch3) hipFree(c->scratch3);
+  if (c->scratch4) hipFree(c->scratch4);
   if (c->lig_T) hipFree(c->lig_T);
   if (c->lig_L) hipFree(c->lig_L);
   if (c->zk_eq) hipFree(c->zk_eq);

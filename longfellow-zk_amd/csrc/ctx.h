@@ -32,6 +32,8 @@ struct lfgpu_ctx {
   size_t scratch2_bytes = 0;
   void* scratch3 = nullptr;  // Ligero-level temporaries (never used by the kernels' own launchers)
   size_t scratch3_bytes = 0;
+  void* scratch4 = nullptr;  // caller-level tableaux that must survive RS / FFT / gather helpers (the verifier's A rows)
+  size_t scratch4_bytes = 0;
   // cached device tables keyed by a string
   std::map<std::string, void*> tables;
   // cached host-side POD plans (e.g. RS op-list descriptors) keyed by a string
@@ -81,6 +83,10 @@ int lf_fail(lfgpu_ctx* c, int code, const char* fmt, ...);
 int lf_scratch(lfgpu_ctx* c, size_t bytes, void** out);
 int lf_scratch2(lfgpu_ctx* c, size_t bytes, void** out);
 int lf_scratch3(lfgpu_ctx* c, size_t bytes, void** out);
+// Ownership: `scratch` = FFT pass buffers (fft.hip, lch_bs.hip), Merkle staging and the sumcheck layer state; `scratch2` = RS
+// work rows, small per-call tables (indices, partial sums); `scratch3` = Ligero-level temporaries; `scratch4` = a caller's
+// tableau that is handed to the RS / FFT / gather helpers and therefore must not alias any of the three above.
+int lf_scratch4(lfgpu_ctx* c, size_t bytes, void** out);
 // upload (and cache under `key`) a host table; returns device pointer
 int lf_table(lfgpu_ctx* c, const std::string& key, const void* host, size_t bytes, void** out);
 bool lf_table_lookup(lfgpu_ctx* c, const std::string& key, void** out);
@@ -107,6 +113,7 @@ bool h_fp_fits(elt_t raw);      // raw < p
 int lf_rs_rows(lfgpu_ctx* c, int field, int k, size_t nrow, size_t n, size_t m, elt_t* d, size_t ld);
 int lf_gf_rs_rows_mixed(lfgpu_ctx* c, int k, size_t nrow, size_t n1, size_t n2, size_t lo2, size_t hi2, size_t m, elt_t* d_T, size_t ld);
 const GfHostCtx* lf_gf_ctx(lfgpu_ctx* c, int k);
+bool lf_gf_ctx_build(GfHostCtx* g, int k);  // the same constants without a context (host-only entry points)
 elt_t h_lch14_twiddle(const GfHostCtx* g, unsigned i, u64 u);
 
 // fused single-workgroup sumcheck step (sumcheck.hip): [bind of the previous round-hand] -> [QW scatter + the two

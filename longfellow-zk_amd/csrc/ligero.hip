@@ -9,6 +9,8 @@
 // not depend on computed data), the un-encoded rows are assembled in one host buffer and
 // uploaded once; the GPU then RS-encodes every row (K3/K4) and commits the columns
 // (K5/K6).  The tableau stays in HBM for the prove-side row combinations (K12).
+#include <algorithm>
+
 #include "ctx.h"
 
 struct lfgpu_ligero_prover {
@@ -19,6 +21,12 @@ struct lfgpu_ligero_prover {
   uint8_t* d_layers;      // [2*block_ext][32]
   size_t T_bytes = 0, L_bytes = 0;
   std::vector<uint8_t> nonces;  // block_ext * 32 (host copy for open)
+  // rows [row_lo, row_hi) of the tableau live in d_T (a slab of a multi-GPU commit; [0, nrow) on one GPU).  The prove
+  // functions then return this slab's PARTIAL sums (rows it does not hold contribute zero); the caller folds the ranks.
+  size_t row_lo = 0, row_hi = 0;
+  bool owns = true;  // d_T / d_layers are freed (stashed) by lfgpu_ligero_free
+  bool has(size_t i) const { return i >= row_lo && i < row_hi; }
+  elt_t* row(size_t i) const { return d_T + (i - row_lo) * p.block_enc; }
 };
 
 static size_t ceildiv(size_t a, size_t b) { return (a + b - 1) / b; }
@@ -177,67 +185,148 @@ int lf_rs_rows(lfgpu_ctx* c, int field, int k, size_t nrow, size_t n, size_t m, 
   return lfgpu_fp128_rs_encode_rows(c, nrow, n, m, om, (uint64_t)1 << 32, d, ld);
 }
 
-extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_ligero_param* pp, const void* h_W,
-                                   size_t subfield_boundary, const size_t* h_lqc, lfgpu_rng_fn rng, void* user,
-                                   uint8_t root_out[32], lfgpu_ligero_prover** out) {
-  if (!c || !pp || !rng || !root_out || !out || (pp->nw && !h_W) || (pp->nq && !h_lqc))
-    return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit: null argument");
-  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128) return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit: field");
-  const GfHostCtx* g = nullptr;
-  if (field == LFGPU_FIELD_GF2_128) {
-    g = lf_gf_ctx(c, k);
-    if (!g) return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit: subfield_log_bits must be 4 or 5");
-  }
-  const lfgpu_ligero_param& p = *pp;
-  const elt_t* W = (const elt_t*)h_W;
-  const size_t ld = p.block_enc;
-  LF_HIP(c, hipSetDevice(c->device));
+// The host half of LigeroProver::commit (ligero_prover.h:171-270 + merkle_commitment.h:52-54): every RandomEngine draw in
+// the reference's order; the un-encoded image (first dblock columns) of rows [row_lo, row_hi) goes to H
+// ([(row_hi - row_lo)][dblock]); rows outside the slab are drawn into a spare row and dropped, so that ranks which replay
+// the same byte stream hold consistent slabs of ONE tableau.  nonces (block_ext * 32 bytes) may be null: the draw still
+// happens.  Returns LFGPU_OK / LFGPU_ERR_ARG / LFGPU_ERR_ASSERT with a message in err (256 bytes).
+static int ligero_layout_host(int field, int k, const GfHostCtx* g, const lfgpu_ligero_param& p, const elt_t* W, size_t subfield_boundary,
+                              const size_t* h_lqc, lfgpu_rng_fn rng, void* user, size_t row_lo, size_t row_hi, elt_t* H, uint8_t* nonces,
+                              char* err) {
   Sampler S{field, k, g, rng, user};
   const elt_t zero{0, 0};
-
-  // host image of the un-encoded rows: only the first dblock columns are ever non-trivial
   const size_t hw = p.dblock;
-  std::vector<elt_t> H(p.nrow * hw, zero);
-  auto at = [&](size_t i, size_t j) -> elt_t& { return H[i * hw + j]; };
+  std::vector<elt_t> spare(hw);
+  auto row = [&](size_t i) -> elt_t* {
+    if (i >= row_lo && i < row_hi) return H + (i - row_lo) * hw;
+    return spare.data();
+  };
+  auto own = [&](size_t i) { return i >= row_lo && i < row_hi; };
+  for (size_t i = row_lo; i < row_hi; ++i) std::fill(row(i), row(i) + hw, zero);
   // layout_blinding_rows (ligero_prover.h:171-205)
-  S.elts(&at(p.ildt, 0), p.block);
-  S.elts(&at(p.idot, 0), p.dblock);
+  S.elts(row(p.ildt), p.block);
   {
+    elt_t* d = row(p.idot);
+    S.elts(d, p.dblock);
     elt_t sum = zero;
-    for (size_t j = 0; j < p.w; ++j) sum = h_add(field, sum, at(p.idot, p.r + j));
-    at(p.idot, p.r) = h_sub(field, at(p.idot, p.r), sum);
+    for (size_t j = 0; j < p.w; ++j) sum = h_add(field, sum, d[p.r + j]);
+    d[p.r] = h_sub(field, d[p.r], sum);
   }
-  S.elts(&at(p.iquad, 0), p.dblock);
-  for (size_t j = 0; j < p.w; ++j) at(p.iquad, p.r + j) = zero;
+  {
+    elt_t* q = row(p.iquad);
+    S.elts(q, p.dblock);
+    for (size_t j = 0; j < p.w; ++j) q[p.r + j] = zero;
+  }
   // layout_witness_rows (:207-231)
   for (size_t i = 0; i < p.nwrow; ++i) {
-    bool subfield_only = ((i + 1) * p.w <= subfield_boundary);
+    elt_t* t = row(i + p.iw);
+    const bool subfield_only = ((i + 1) * p.w <= subfield_boundary);
     if (subfield_only) {
-      for (size_t j = 0; j < p.r; ++j) at(i + p.iw, j) = S.subfield_elt();
+      for (size_t j = 0; j < p.r; ++j) t[j] = S.subfield_elt();
     } else {
-      S.elts(&at(i + p.iw, 0), p.r);
+      S.elts(t, p.r);
     }
-    size_t max_col = std::min(p.w, p.nw - i * p.w);
-    for (size_t j = 0; j < max_col; ++j) at(i + p.iw, p.r + j) = W[i * p.w + j];
+    if (!own(i + p.iw)) continue;
+    const size_t max_col = std::min(p.w, p.nw - i * p.w);
+    for (size_t j = 0; j < max_col; ++j) t[p.r + j] = W[i * p.w + j];
   }
   // layout_quadratic_rows (:233-270)
   const size_t iqx = p.iq, iqy = iqx + p.nqtriples, iqz = iqy + p.nqtriples;
   for (size_t i = 0; i < p.nqtriples; ++i) {
-    S.elts(&at(iqx + i, 0), p.r);
-    S.elts(&at(iqy + i, 0), p.r);
-    S.elts(&at(iqz + i, 0), p.r);
+    S.elts(row(iqx + i), p.r);
+    S.elts(row(iqy + i), p.r);
+    S.elts(row(iqz + i), p.r);
     for (size_t j = 0; j < p.w && j + i * p.w < p.nq; ++j) {
       const size_t* l = &h_lqc[3 * (j + i * p.w)];
-      if (l[0] >= p.nw || l[1] >= p.nw || l[2] >= p.nw) return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit: lqc index >= nw");
-      elt_t prod = h_mul(field, W[l[0]], W[l[1]]);
-      if (!(prod.lo == W[l[2]].lo && prod.hi == W[l[2]].hi))
-        return lf_fail(c, LFGPU_ERR_ASSERT, "ligero_commit: invalid quadratic constraints (ligero_prover.h:259-260)");
-      at(iqx + i, j + p.r) = W[l[0]];
-      at(iqy + i, j + p.r) = W[l[1]];
-      at(iqz + i, j + p.r) = W[l[2]];
+      if (l[0] >= p.nw || l[1] >= p.nw || l[2] >= p.nw) {
+        snprintf(err, 256, "ligero_commit: lqc index >= nw");
+        return LFGPU_ERR_ARG;
+      }
+      const elt_t prod = h_mul(field, W[l[0]], W[l[1]]);
+      if (!(prod.lo == W[l[2]].lo && prod.hi == W[l[2]].hi)) {
+        snprintf(err, 256, "ligero_commit: invalid quadratic constraints (ligero_prover.h:259-260)");
+        return LFGPU_ERR_ASSERT;
+      }
+      if (own(iqx + i)) row(iqx + i)[j + p.r] = W[l[0]];
+      if (own(iqy + i)) row(iqy + i)[j + p.r] = W[l[1]];
+      if (own(iqz + i)) row(iqz + i)[j + p.r] = W[l[2]];
     }
   }
-  // MerkleCommitment::commit draws one 32-byte nonce per leaf, after the layout (merkle_commitment.h:52-54)
+  // MerkleCommitment::commit draws one 32-byte nonce per leaf, after the layout (merkle_commitment.h:52-54): one draw of
+  // 32 * block_ext bytes is the same stream for every byte-stream engine
+  if (nonces) {
+    rng(user, nonces, 32 * p.block_ext);
+  } else {
+    std::vector<uint8_t> drop(32 * p.block_ext);
+    rng(user, drop.data(), drop.size());
+  }
+  return LFGPU_OK;
+}
+
+static bool ligero_args_ok(int field, int k, const lfgpu_ligero_param* pp, const void* h_W, const size_t* h_lqc, lfgpu_rng_fn rng) {
+  if (!pp || !rng || (pp->nw && !h_W) || (pp->nq && !h_lqc)) return false;
+  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128) return false;
+  if (field == LFGPU_FIELD_GF2_128 && k != 4 && k != 5) return false;
+  return true;
+}
+
+// Multi-GPU commit, host half (no device needed): see include/lfgpu.h
+extern "C" int lfgpu_ligero_layout_rows(int field, int k, const lfgpu_ligero_param* pp, const void* h_W, size_t subfield_boundary,
+                                        const size_t* h_lqc, lfgpu_rng_fn rng, void* user, size_t row_lo, size_t row_hi, void* h_rows,
+                                        uint8_t* h_nonces) {
+  if (!ligero_args_ok(field, k, pp, h_W, h_lqc, rng) || row_lo > row_hi || row_hi > pp->nrow || (row_hi > row_lo && !h_rows)) return LFGPU_ERR_ARG;
+  GfHostCtx g;
+  if (field == LFGPU_FIELD_GF2_128 && !lf_gf_ctx_build(&g, k)) return LFGPU_ERR_ARG;
+  char err[256];
+  return ligero_layout_host(field, k, &g, *pp, (const elt_t*)h_W, subfield_boundary, h_lqc, rng, user, row_lo, row_hi, (elt_t*)h_rows, h_nonces, err);
+}
+
+// rows [row_lo, row_hi) of the tableau: upload the un-encoded image and RS-extend every row to block_enc
+// (rows IDOT / IQUAD carry dblock values, every other row block: ligero_prover.h:175,184,203,210,237)
+static int ligero_encode_slab(lfgpu_ctx* c, int field, int k, const lfgpu_ligero_param& p, size_t row_lo, size_t row_hi, const elt_t* H, elt_t* d_slab) {
+  const size_t nr = row_hi - row_lo, ld = p.block_enc, hw = p.dblock;
+  if (nr == 0) return LFGPU_OK;
+  LF_HIP(c, hipMemcpy2DAsync(d_slab, ld * 16, H, hw * 16, hw * 16, nr, hipMemcpyHostToDevice, c->stream));
+  // the rows with dblock values form one contiguous global range [idot, iquad + 1); clip it to the slab
+  const size_t g_lo = std::min(p.idot, p.iquad), g_hi = std::max(p.idot, p.iquad) + 1;
+  const bool contiguous = g_hi - g_lo == 2;
+  const size_t lo2 = std::min(std::max(g_lo, row_lo), row_hi) - row_lo, hi2 = std::min(std::max(g_hi, row_lo), row_hi) - row_lo;
+  int rc = field == LFGPU_FIELD_GF2_128 && contiguous
+               ? lf_gf_rs_rows_mixed(c, k, nr, p.block, p.dblock, lo2, hi2, p.block_enc, d_slab, ld)
+               : LFGPU_ERR_UNSUPPORTED;
+  if (rc == LFGPU_ERR_UNSUPPORTED) {  // rows larger than the LDS-resident kernel / Fp128: group by group
+    if (!contiguous) return lf_fail(c, LFGPU_ERR_ARG, "ligero: IDOT and IQUAD rows must be adjacent");
+    LF_TRY(lf_rs_rows(c, field, k, lo2, p.block, p.block_enc, d_slab, ld));
+    LF_TRY(lf_rs_rows(c, field, k, hi2 - lo2, p.dblock, p.block_enc, d_slab + lo2 * ld, ld));
+    LF_TRY(lf_rs_rows(c, field, k, nr - hi2, p.block, p.block_enc, d_slab + hi2 * ld, ld));
+    rc = LFGPU_OK;
+  }
+  return rc;
+}
+
+extern "C" int lfgpu_ligero_encode_rows(lfgpu_ctx* c, int field, int k, const lfgpu_ligero_param* pp, size_t row_lo, size_t row_hi,
+                                        const void* h_rows, void* d_slab) {
+  if (!c || !pp || row_lo > row_hi || row_hi > pp->nrow || (row_hi > row_lo && (!h_rows || !d_slab)))
+    return lf_fail(c, LFGPU_ERR_ARG, "ligero_encode_rows: bad argument");
+  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128) return lf_fail(c, LFGPU_ERR_ARG, "ligero_encode_rows: field");
+  if (field == LFGPU_FIELD_GF2_128 && !lf_gf_ctx(c, k)) return lf_fail(c, LFGPU_ERR_ARG, "ligero_encode_rows: subfield_log_bits must be 4 or 5");
+  LF_HIP(c, hipSetDevice(c->device));
+  LF_TRY(ligero_encode_slab(c, field, k, *pp, row_lo, row_hi, (const elt_t*)h_rows, (elt_t*)d_slab));
+  LF_HIP(c, hipStreamSynchronize(c->stream));  // h_rows is the caller's: the upload must be over before we return
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_ligero_param* pp, const void* h_W,
+                                   size_t subfield_boundary, const size_t* h_lqc, lfgpu_rng_fn rng, void* user,
+                                   uint8_t root_out[32], lfgpu_ligero_prover** out) {
+  if (!c || !root_out || !out || !ligero_args_ok(field, k, pp, h_W, h_lqc, rng))
+    return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit: bad argument (null pointer, field or subfield_log_bits)");
+  const GfHostCtx* g = nullptr;
+  if (field == LFGPU_FIELD_GF2_128) g = lf_gf_ctx(c, k);
+  const lfgpu_ligero_param& p = *pp;
+  const size_t ld = p.block_enc;
+  LF_HIP(c, hipSetDevice(c->device));
+
   lfgpu_ligero_prover* pr = new lfgpu_ligero_prover();
   pr->c = c;
   pr->field = field;
@@ -246,12 +335,19 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
   pr->d_T = nullptr;
   pr->d_layers = nullptr;
   pr->nonces.resize(p.block_ext * 32);
-  rng(user, pr->nonces.data(), 32 * p.block_ext);  // one 32-byte draw per leaf, in leaf order (byte-stream engine)
-
   auto fail = [&](int rc) {
     lfgpu_ligero_free(pr);
     return rc;
   };
+  // host image of the un-encoded rows (only the first dblock columns are ever non-trivial) + the nonces: the single-GPU
+  // commit is the slab [0, nrow) of the sharded one
+  std::vector<elt_t> H(p.nrow * p.dblock);
+  {
+    char err[256] = {0};
+    const int rc = ligero_layout_host(field, k, g, p, (const elt_t*)h_W, subfield_boundary, h_lqc, rng, user, 0, p.nrow, H.data(),
+                                      pr->nonces.data(), err);
+    if (rc) return fail(lf_fail(c, rc, "%s", err));
+  }
   const size_t tb = p.nrow * ld * 16, lb = 2 * p.block_ext * 32;
   if (c->lig_T && c->lig_T_bytes == tb) {  // buffers of the last freed prover with the same shape
     pr->d_T = (elt_t*)c->lig_T;
@@ -267,23 +363,14 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
   }
   pr->T_bytes = tb;
   pr->L_bytes = lb;
+  pr->row_lo = 0;
+  pr->row_hi = p.nrow;
   void* d_non = nullptr;
   int rc = lf_scratch3(c, p.block_ext * 32, &d_non);
   if (rc) return fail(rc);
-  if (hipMemcpy2DAsync(pr->d_T, ld * 16, H.data(), hw * 16, hw * 16, p.nrow, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipMemcpyAsync(d_non, pr->nonces.data(), p.block_ext * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+  if (hipMemcpyAsync(d_non, pr->nonces.data(), p.block_ext * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess)
     return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit: upload failed"));
-  // rows 0 (ILDT) and all witness/quadratic rows: block -> block_enc; rows 1,2: dblock -> block_enc
-  rc = field == LFGPU_FIELD_GF2_128 && p.ildt == 0 && p.idot == 1 && p.iquad == 2 && p.iw == 3
-           ? lf_gf_rs_rows_mixed(c, k, p.nrow, p.block, p.dblock, p.idot, p.iquad + 1, p.block_enc, pr->d_T, ld)
-           : LFGPU_ERR_UNSUPPORTED;
-  if (rc == LFGPU_ERR_UNSUPPORTED) {  // general shapes / Fp128: group by group
-    if ((rc = lf_rs_rows(c, field, k, 1, p.block, p.block_enc, pr->d_T + p.ildt * ld, ld))) return fail(rc);
-    if ((rc = lf_rs_rows(c, field, k, 2, p.dblock, p.block_enc, pr->d_T + p.idot * ld, ld))) return fail(rc);
-    if ((rc = lf_rs_rows(c, field, k, p.nwqrow, p.block, p.block_enc, pr->d_T + p.iw * ld, ld))) return fail(rc);
-  } else if (rc) {
-    return fail(rc);
-  }
+  if ((rc = ligero_encode_slab(c, field, k, p, 0, p.nrow, H.data(), pr->d_T))) return fail(rc);
   if ((rc = lfgpu_column_commit(c, field, p.nrow, ld, p.dblock, p.block_ext, pr->d_T, d_non, pr->d_layers, root_out)))
     return fail(rc);
   *out = pr;
@@ -305,8 +392,10 @@ extern "C" int lfgpu_ligero_free(lfgpu_ligero_prover* pr) {
       (void)hipFree(p);
     }
   };
-  stash(pr->d_T, pr->T_bytes, &c->lig_T, &c->lig_T_bytes);
-  stash(pr->d_layers, pr->L_bytes, &c->lig_L, &c->lig_L_bytes);
+  if (pr->owns) {
+    stash(pr->d_T, pr->T_bytes, &c->lig_T, &c->lig_T_bytes);
+    stash(pr->d_layers, pr->L_bytes, &c->lig_L, &c->lig_L_bytes);
+  }
   delete pr;
   return LFGPU_OK;
 }
@@ -367,6 +456,14 @@ __global__ void layout_aext_kernel(u32 r, u32 w, size_t lda, const elt_t* __rest
       hipLaunchKernelGGL(KERNEL<FIELD_FP128>, grid, block, 0, c->stream, __VA_ARGS__);   \
   } while (0)
 
+// witness / quadratic rows [a_lo, a_hi) (indices relative to iw) that this prover's slab holds
+static void owned_wq_rows(const lfgpu_ligero_prover* pr, size_t* a_lo, size_t* a_hi) {
+  const lfgpu_ligero_param& p = pr->p;
+  const size_t lo = std::min(std::max(pr->row_lo, p.iw), p.iw + p.nwqrow), hi = std::min(std::max(pr->row_hi, p.iw), p.iw + p.nwqrow);
+  *a_lo = lo - p.iw;
+  *a_hi = std::max(hi, lo) - p.iw;
+}
+
 extern "C" int lfgpu_ligero_low_degree_proof(lfgpu_ligero_prover* pr, const void* h_u, void* h_y) {
   if (!pr || !h_u || !h_y) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = pr->c;
@@ -374,8 +471,14 @@ extern "C" int lfgpu_ligero_low_degree_proof(lfgpu_ligero_prover* pr, const void
   LF_HIP(c, hipSetDevice(c->device));
   void* dy = nullptr;
   LF_TRY(lf_scratch3(c, p.block * 16, &dy));
-  LF_HIP(c, hipMemcpyAsync(dy, pr->d_T + p.ildt * p.block_enc, p.block * 16, hipMemcpyDeviceToDevice, c->stream));
-  LF_TRY(lfgpu_rows_axpy(c, pr->field, p.nwqrow, p.block, dy, (const uint64_t*)h_u, pr->d_T + p.iw * p.block_enc, p.block_enc));
+  if (pr->has(p.ildt))
+    LF_HIP(c, hipMemcpyAsync(dy, pr->row(p.ildt), p.block * 16, hipMemcpyDeviceToDevice, c->stream));
+  else
+    LF_HIP(c, hipMemsetAsync(dy, 0, p.block * 16, c->stream));
+  size_t a_lo, a_hi;
+  owned_wq_rows(pr, &a_lo, &a_hi);
+  if (a_hi > a_lo)
+    LF_TRY(lfgpu_rows_axpy(c, pr->field, a_hi - a_lo, p.block, dy, (const uint64_t*)h_u + 2 * a_lo, pr->row(p.iw + a_lo), p.block_enc));
   return lfgpu_memcpy_d2h(c, h_y, dy, p.block * 16);
 }
 
@@ -439,15 +542,24 @@ extern "C" int lfgpu_ligero_inner_product_rows(lfgpu_ctx* c, int field, size_t w
   return LFGPU_OK;
 }
 
-// dot_proof once the rows [0^r | A_i | 0...] stand in dAext (lda = dblock): extend, combine, read back
+// dot_proof once the rows [0^r | A_i | 0...] stand in dAext (lda = dblock; all nwqrow rows, of which the slab's are
+// used): extend, combine, read back
 static int dot_proof_finish(lfgpu_ligero_prover* pr, elt_t* dAext, elt_t* dy, void* h_y) {
   lfgpu_ctx* c = pr->c;
   const lfgpu_ligero_param& p = pr->p;
   const size_t lda = p.dblock;
-  LF_TRY(lf_rs_rows(c, pr->field, pr->k, p.nwqrow, p.block, p.dblock, dAext, lda));
-  LIG_DISPATCH(pr->field, rows_vaxpy_kernel, dim3((u32)((p.dblock + 63) / 64)), dim3(1024), (u32)p.nwqrow, p.dblock,
-               (const elt_t*)(pr->d_T + p.idot * p.block_enc), (const elt_t*)dAext, lda,
-               (const elt_t*)(pr->d_T + p.iw * p.block_enc), p.block_enc, dy);
+  size_t a_lo, a_hi;
+  owned_wq_rows(pr, &a_lo, &a_hi);
+  const elt_t* T0 = nullptr;
+  if (pr->has(p.idot)) {
+    T0 = pr->row(p.idot);
+  } else {  // a zero row behind dy (the callers reserve 2 * dblock)
+    LF_HIP(c, hipMemsetAsync(dy + p.dblock, 0, p.dblock * 16, c->stream));
+    T0 = dy + p.dblock;
+  }
+  if (a_hi > a_lo) LF_TRY(lf_rs_rows(c, pr->field, pr->k, a_hi - a_lo, p.block, p.dblock, dAext + a_lo * lda, lda));
+  LIG_DISPATCH(pr->field, rows_vaxpy_kernel, dim3((u32)((p.dblock + 63) / 64)), dim3(1024), (u32)(a_hi - a_lo), p.dblock, T0,
+               (const elt_t*)(dAext + a_lo * lda), lda, (const elt_t*)(a_hi > a_lo ? pr->row(p.iw + a_lo) : pr->d_T), p.block_enc, dy);
   LF_HIP(c, hipGetLastError());
   return lfgpu_memcpy_d2h(c, h_y, dy, p.dblock * 16);
 }
@@ -459,7 +571,7 @@ extern "C" int lfgpu_ligero_dot_proof(lfgpu_ligero_prover* pr, const void* h_A, 
   LF_HIP(c, hipSetDevice(c->device));
   const size_t lda = p.dblock;
   void* sc = nullptr;
-  LF_TRY(lf_scratch3(c, (p.nwqrow * p.w + p.nwqrow * lda + p.dblock) * 16 + 64, &sc));
+  LF_TRY(lf_scratch3(c, (p.nwqrow * p.w + p.nwqrow * lda + 2 * p.dblock) * 16 + 64, &sc));
   elt_t* dA = (elt_t*)sc;
   elt_t* dAext = dA + p.nwqrow * p.w;
   elt_t* dy = dAext + p.nwqrow * lda;
@@ -478,11 +590,11 @@ extern "C" int lfgpu_ligero_dot_proof_sparse(lfgpu_ligero_prover* pr, const void
   LF_HIP(c, hipSetDevice(c->device));
   const size_t lda = p.dblock;
   void* sc = nullptr;
-  LF_TRY(lf_scratch3(c, (p.nwqrow * lda + p.dblock) * 16 + 64, &sc));
+  LF_TRY(lf_scratch3(c, (p.nwqrow * lda + 2 * p.dblock) * 16 + 64, &sc));
   if (d_dense && ndense) {  // the dense block must not live in the scratch this call is about to overwrite
     const uint8_t* lo = (const uint8_t*)sc;
     const uint8_t* d = (const uint8_t*)d_dense;
-    if (d + ndense * 16 > lo && d < lo + (p.nwqrow * lda + p.dblock) * 16) return lf_fail(c, LFGPU_ERR_ARG, "ligero_dot_proof_sparse: dense block aliases scratch");
+    if (d + ndense * 16 > lo && d < lo + (p.nwqrow * lda + 2 * p.dblock) * 16) return lf_fail(c, LFGPU_ERR_ARG, "ligero_dot_proof_sparse: dense block aliases scratch");
   }
   elt_t* dAext = (elt_t*)sc;
   elt_t* dy = dAext + p.nwqrow * lda;
@@ -496,24 +608,60 @@ extern "C" int lfgpu_ligero_quadratic_proof(lfgpu_ligero_prover* pr, const void*
   lfgpu_ctx* c = pr->c;
   const lfgpu_ligero_param& p = pr->p;
   LF_HIP(c, hipSetDevice(c->device));
+  // a triple (x_i, y_i, z_i) is multiplied element-wise, so a slab must hold all quadratic rows or none of them
+  const size_t q_lo = p.iq, q_hi = p.iq + 3 * p.nqtriples;
+  const bool all_q = p.nqtriples == 0 || (pr->row_lo <= q_lo && q_hi <= pr->row_hi);
+  const bool no_q = pr->row_hi <= q_lo || pr->row_lo >= q_hi;
+  if (!all_q && !no_q) return lf_fail(c, LFGPU_ERR_ARG, "quadratic_proof: the slab splits the quadratic rows (shard so that one rank holds [iq, nrow))");
+  const size_t nt = all_q ? p.nqtriples : 0;
   void* sc = nullptr;
-  LF_TRY(lf_scratch3(c, (p.nqtriples + p.dblock) * 16 + 64, &sc));
+  LF_TRY(lf_scratch3(c, (p.nqtriples + 2 * p.dblock) * 16 + 64, &sc));
   elt_t* du = (elt_t*)sc;
   elt_t* dy = du + p.nqtriples + 1;
-  if (p.nqtriples) LF_HIP(c, hipMemcpyAsync(du, h_u_quad, p.nqtriples * 16, hipMemcpyHostToDevice, c->stream));
+  elt_t* dz = dy + p.dblock;
+  if (nt) LF_HIP(c, hipMemcpyAsync(du, h_u_quad, p.nqtriples * 16, hipMemcpyHostToDevice, c->stream));
   const size_t ld = p.block_enc;
-  const elt_t* X = pr->d_T + p.iq * ld;
+  const elt_t* Tq = nullptr;
+  if (pr->has(p.iquad)) {
+    Tq = pr->row(p.iquad);
+  } else {
+    LF_HIP(c, hipMemsetAsync(dz, 0, p.dblock * 16, c->stream));
+    Tq = dz;
+  }
+  const elt_t* X = nt ? pr->row(p.iq) : pr->d_T;
   const elt_t* Y = X + p.nqtriples * ld;
   const elt_t* Z = Y + p.nqtriples * ld;
-  LIG_DISPATCH(pr->field, quad_combo_kernel, dim3((u32)((p.dblock + 255) / 256)), dim3(256), (u32)p.nqtriples, p.dblock,
-               (const elt_t*)(pr->d_T + p.iquad * ld), (const elt_t*)du, X, Y, Z, ld, dy);
+  LIG_DISPATCH(pr->field, quad_combo_kernel, dim3((u32)((p.dblock + 255) / 256)), dim3(256), (u32)nt, p.dblock, Tq, (const elt_t*)du, X, Y, Z, ld, dy);
   LF_HIP(c, hipGetLastError());
   std::vector<elt_t> y(p.dblock);
   LF_TRY(lfgpu_memcpy_d2h(c, y.data(), dy, p.dblock * 16));
-  for (size_t j = 0; j < p.w; ++j)  // sanity check of the reference (:335-337)
-    if (y[p.r + j].lo | y[p.r + j].hi) return lf_fail(c, LFGPU_ERR_ASSERT, "quadratic_proof: W part is nonzero");
+  if (pr->row_lo == 0 && pr->row_hi == p.nrow)  // sanity check of the reference (:335-337); partial sums are checked after the fold
+    for (size_t j = 0; j < p.w; ++j)
+      if (y[p.r + j].lo | y[p.r + j].hi) return lf_fail(c, LFGPU_ERR_ASSERT, "quadratic_proof: W part is nonzero");
   memcpy(h_y0, y.data(), p.r * 16);
   memcpy(h_y2, y.data() + p.block, (p.dblock - p.block) * 16);
+  return LFGPU_OK;
+}
+
+// a prover over rows [row_lo, row_hi) that the caller has laid out and encoded (lfgpu_ligero_encode_rows) in d_slab;
+// d_layers / h_nonces: the Merkle heap and nonces of the whole commitment (for lfgpu_ligero_open), may be null
+extern "C" int lfgpu_ligero_prover_from_slab(lfgpu_ctx* c, int field, int k, const lfgpu_ligero_param* pp, size_t row_lo, size_t row_hi,
+                                             void* d_slab, void* d_layers, const uint8_t* h_nonces, lfgpu_ligero_prover** out) {
+  if (!c || !pp || !out || row_lo > row_hi || row_hi > pp->nrow || (row_hi > row_lo && !d_slab))
+    return lf_fail(c, LFGPU_ERR_ARG, "ligero_prover_from_slab: bad argument");
+  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128) return lf_fail(c, LFGPU_ERR_ARG, "ligero_prover_from_slab: field");
+  lfgpu_ligero_prover* pr = new lfgpu_ligero_prover();
+  pr->c = c;
+  pr->field = field;
+  pr->k = k;
+  pr->p = *pp;
+  pr->d_T = (elt_t*)d_slab;
+  pr->d_layers = (uint8_t*)d_layers;
+  pr->row_lo = row_lo;
+  pr->row_hi = row_hi;
+  pr->owns = false;
+  if (h_nonces) pr->nonces.assign(h_nonces, h_nonces + 32 * pp->block_ext);
+  *out = pr;
   return LFGPU_OK;
 }
 
@@ -524,10 +672,15 @@ extern "C" int lfgpu_ligero_open(lfgpu_ligero_prover* pr, const size_t* idx, voi
   const lfgpu_ligero_param& p = pr->p;
   for (size_t i = 0; i < p.nreq; ++i)
     if (idx[i] >= p.block_ext) return lf_fail(c, LFGPU_ERR_ARG, "ligero_open: index out of range");
-  void* dreq = nullptr;
-  LF_TRY(lf_scratch3(c, p.nrow * p.nreq * 16, &dreq));
-  LF_TRY(lfgpu_gather_columns(c, p.nrow, p.block_enc, p.dblock, pr->d_T, idx, p.nreq, dreq));
-  LF_TRY(lfgpu_memcpy_d2h(c, h_req, dreq, p.nrow * p.nreq * 16));
+  if (pr->nonces.size() != 32 * p.block_ext || !pr->d_layers) return lf_fail(c, LFGPU_ERR_ARG, "ligero_open: this prover holds no commitment");
+  // a slab returns its own rows of req ((row_hi - row_lo) x nreq, in row order)
+  const size_t nr = pr->row_hi - pr->row_lo;
+  if (nr) {
+    void* dreq = nullptr;
+    LF_TRY(lf_scratch3(c, nr * p.nreq * 16, &dreq));
+    LF_TRY(lfgpu_gather_columns(c, nr, p.block_enc, p.dblock, pr->d_T, idx, p.nreq, dreq));
+    LF_TRY(lfgpu_memcpy_d2h(c, h_req, dreq, nr * p.nreq * 16));
+  }
   for (size_t i = 0; i < p.nreq; ++i) memcpy(h_nonces + 32 * i, &pr->nonces[32 * idx[i]], 32);
   return lfgpu_merkle_open(c, p.block_ext, pr->d_layers, idx, p.nreq, h_path, path_cap, npath);
 }

@@ -13,11 +13,12 @@
 #define SHA_THREADS 256
 
 // leaf_j = SHA256(nonce_j[32] || canon(T[0][col0+j]) || ... || canon(T[nrow-1][col0+j]))
+// digest j lands at out[out0 + j] (out0 = ncols: the leaf level of the heap; 0: a plain leaf array)
 template <int F>
 __global__ __launch_bounds__(SHA_THREADS) void column_leaves_kernel(u32 nrow, size_t ld, size_t col0, u32 ncols,
                                                                      const elt_t* __restrict__ T,
                                                                      const uint4* __restrict__ nonces,
-                                                                     uint4* __restrict__ layers) {
+                                                                     uint4* __restrict__ layers, size_t out0) {
   u32 j = blockIdx.x * SHA_THREADS + threadIdx.x;
   if (j >= ncols) return;
   const elt_t* col = T + col0 + j;
@@ -54,8 +55,8 @@ __global__ __launch_bounds__(SHA_THREADS) void column_leaves_kernel(u32 nrow, si
   }
   uint4 o0 = make_uint4(bswap32(st.h[0]), bswap32(st.h[1]), bswap32(st.h[2]), bswap32(st.h[3]));
   uint4 o1 = make_uint4(bswap32(st.h[4]), bswap32(st.h[5]), bswap32(st.h[6]), bswap32(st.h[7]));
-  layers[2 * ((size_t)ncols + j)] = o0;
-  layers[2 * ((size_t)ncols + j) + 1] = o1;
+  layers[2 * (out0 + j)] = o0;
+  layers[2 * (out0 + j) + 1] = o1;
 }
 
 // node i = SHA256(node 2i || node 2i+1)
@@ -136,25 +137,37 @@ extern "C" int lfgpu_merkle_build_tree(lfgpu_ctx* c, size_t n, void* d_layers, u
   return read_root(c, n, d_layers, root_out);
 }
 
-extern "C" int lfgpu_column_commit(lfgpu_ctx* c, int field, size_t nrow, size_t ld, size_t col0, size_t ncols,
-                                   const void* d_T, const void* d_nonces, void* d_layers, uint8_t root_out[32]) {
-  if (!c || !d_T || !d_nonces || !d_layers || !root_out || ncols == 0)
-    return lf_fail(c, LFGPU_ERR_ARG, "column_commit: bad argument");
-  if (col0 + ncols > ld) return lf_fail(c, LFGPU_ERR_ARG, "column_commit: col0 + ncols > ld");
-  if (nrow > 0x0fffffffu || ncols > 0x7fffffffu) return lf_fail(c, LFGPU_ERR_ARG, "column_commit: too large");
+static int column_leaves(lfgpu_ctx* c, const char* who, int field, size_t nrow, size_t ld, size_t col0, size_t ncols, const void* d_T,
+                         const void* d_nonces, void* d_out, size_t out0) {
+  if (!c || !d_T || !d_nonces || !d_out || ncols == 0) return lf_fail(c, LFGPU_ERR_ARG, "%s: bad argument", who);
+  if (col0 + ncols > ld) return lf_fail(c, LFGPU_ERR_ARG, "%s: col0 + ncols > ld", who);
+  if (nrow > 0x0fffffffu || ncols > 0x7fffffffu) return lf_fail(c, LFGPU_ERR_ARG, "%s: too large", who);
   LF_HIP(c, hipSetDevice(c->device));
   u32 nb = (u32)((ncols + SHA_THREADS - 1) / SHA_THREADS);
   if (field == LFGPU_FIELD_GF2_128)
     hipLaunchKernelGGL(column_leaves_kernel<FIELD_GF2_128>, dim3(nb), dim3(SHA_THREADS), 0, c->stream, (u32)nrow, ld,
-                       col0, (u32)ncols, (const elt_t*)d_T, (const uint4*)d_nonces, (uint4*)d_layers);
+                       col0, (u32)ncols, (const elt_t*)d_T, (const uint4*)d_nonces, (uint4*)d_out, out0);
   else if (field == LFGPU_FIELD_FP128)
     hipLaunchKernelGGL(column_leaves_kernel<FIELD_FP128>, dim3(nb), dim3(SHA_THREADS), 0, c->stream, (u32)nrow, ld,
-                       col0, (u32)ncols, (const elt_t*)d_T, (const uint4*)d_nonces, (uint4*)d_layers);
+                       col0, (u32)ncols, (const elt_t*)d_T, (const uint4*)d_nonces, (uint4*)d_out, out0);
   else
-    return lf_fail(c, LFGPU_ERR_ARG, "column_commit: unknown field %d", field);
+    return lf_fail(c, LFGPU_ERR_ARG, "%s: unknown field %d", who, field);
   LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_column_commit(lfgpu_ctx* c, int field, size_t nrow, size_t ld, size_t col0, size_t ncols,
+                                   const void* d_T, const void* d_nonces, void* d_layers, uint8_t root_out[32]) {
+  if (!root_out) return lf_fail(c, LFGPU_ERR_ARG, "column_commit: bad argument");
+  LF_TRY(column_leaves(c, "column_commit", field, nrow, ld, col0, ncols, d_T, d_nonces, d_layers, ncols));
   LF_TRY(build_tree(c, ncols, d_layers));
   return read_root(c, ncols, d_layers, root_out);
+}
+
+// the leaf half alone (multi-GPU commit: a rank hashes the columns it owns); enqueue only
+extern "C" int lfgpu_column_leaves(lfgpu_ctx* c, int field, size_t nrow, size_t ld, size_t col0, size_t ncols,
+                                   const void* d_T, const void* d_nonces, void* d_leaves) {
+  return column_leaves(c, "column_leaves", field, nrow, ld, col0, ncols, d_T, d_nonces, d_leaves, 0);
 }
 
 // MerkleTree::generate_compressed_proof (merkle_tree.h:63-84,122-143): the index walk is

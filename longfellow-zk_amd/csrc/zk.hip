@@ -1163,7 +1163,8 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   inner_product_sparse(F, p, cs, alphal, lqc, alphaq, a_idx, a_val);
   const size_t nrows_dev = p.nwqrow + 3, ld = p.block_enc;
   void* dT = nullptr;
-  LF_TRY(lf_scratch(c, (nrows_dev * ld + (size_t)nrows_dev * p.nreq) * 16 + 256, &dT));
+  // scratch4: the RS extension below runs its FFT passes through `scratch` / `scratch2` (fft.hip, lch_bs.hip, rs.hip)
+  LF_TRY(lf_scratch4(c, (nrows_dev * ld + (size_t)nrows_dev * p.nreq) * 16 + 256, &dT));
   elt_t* d_T = (elt_t*)dT;
   elt_t* d_req = d_T + nrows_dev * ld;
   {  // only the first dblock columns of a row are inputs: clear them on the device, then strided copies

@@ -1,6 +1,8 @@
-"""N > 1 path on CPU: world_size 2, gloo.  The collectives and the re-partitioning logic of
-longfellow-zk_amd/parallel.py are exercised with the oracle as the injected compute, and the
-result must equal the single-process oracle (root / folded partial sums)."""
+"""N > 1 path on CPU: world_size 2 (and 3), gloo.  The product's multi-GPU orchestration
+(longfellow-zk_amd/parallel.py: ShardedLigeroProver, sharded_column_commit, allgather_fold_partials) and the product's
+host layout (lfgpu_ligero_layout_rows, host-only C++) run unchanged; only the device compute is swapped for an engine
+backed by the oracle (tests/sharded_util.py).  Results must equal the one-rank run and, for GF2_128, the commitment
+root of the reference's own C++ Ligero vector."""
 import ctypes as C
 import os
 import socket
@@ -28,33 +30,28 @@ def _worker(rank, world, port, field, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from __graft_entry__ import load_package
-    load_package()
+    pkg = load_package()
     import importlib
     par = importlib.import_module("longfellow_zk_amd.parallel")
+    import sharded_util as su
     o = ol.oracle()
     try:
-        # --- shared synthetic statement (same seed on every rank)
+        solo = None
+        for r in range(world):  # new_group is collective: every rank creates every one-rank group
+            g = dist.new_group([r])
+            if r == rank:
+                solo = g
+        # --- sharded LigeroProver: commit (layout -> encode -> all_to_all -> leaves -> all_gather -> tree) + prove
+        res = su.run_rank(pkg, par, su.OracleEngine(field), field, None, solo)
+        assert res["spans"][0][0] == 0 and res["spans"][-1][1] == res["p"].nrow
+        # --- the column commit alone on a ragged shape
         rng = np.random.default_rng(123)
         nrow, ld, col0, ncols = 11, 96, 29, 67
         T = ol.rand_elts(rng, nrow * ld, field).reshape(nrow, ld, 2)
         nonces = rng.integers(0, 256, size=(ncols, 32), dtype=np.uint8)
         r0, rn = par.row_shard(nrow, rank, world)
         slab = torch.from_numpy(T[r0:r0 + rn].copy().view(np.uint8).reshape(rn, ld * 16))
-
-        def hash_leaves(cols, nz):
-            a = np.ascontiguousarray(cols.numpy()).view(np.uint64).reshape(nrow, -1, 2)
-            n = a.shape[1]
-            out = np.zeros((n, 32), dtype=np.uint8)
-            o.lfo_column_leaves(field, nrow, n, 0, n, P(np.ascontiguousarray(a)), P(np.ascontiguousarray(nz.numpy())), P(out))
-            return torch.from_numpy(out)
-
-        def build_tree(leaves):
-            lv = np.ascontiguousarray(leaves.numpy())
-            lay = np.zeros((2 * len(lv), 32), dtype=np.uint8)
-            o.lfo_merkle_build_tree(len(lv), P(lv), P(lay))
-            return lay[1].tobytes()
-
-        root = par.sharded_column_commit(slab, nrow, col0, ncols, torch.from_numpy(nonces), hash_leaves, build_tree)
+        root, _layers = par.sharded_column_commit(su.OracleEngine(field), slab, nrow, ld, col0, ncols, torch.from_numpy(nonces))
         want = np.zeros(32, dtype=np.uint8)
         o.lfo_column_commit(field, nrow, ld, col0, ncols, P(T), P(nonces), P(want), None)
         assert root == want.tobytes(), "sharded root differs"
@@ -74,29 +71,29 @@ def _worker(rank, world, port, field, q):
         assert s0 == (w0.l[0], w0.l[1]) and s2 == (w2.l[0], w2.l[1]), "folded partials differ"
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
-        q.put((rank, "FAIL: %r" % (e,)))
+        import traceback
+        q.put((rank, "FAIL: %r\n%s" % (e, traceback.format_exc())))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("field", [GF, FP])
-def test_world2_gloo(field):
-    world = 2
+@pytest.mark.parametrize("field,world", [(GF, 2), (FP, 2), (GF, 3)])
+def test_world_gloo(field, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, field, q)) for r in range(world)]
     for p_ in procs:
         p_.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p_ in procs:
         p_.join(timeout=60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
 def test_row_shard_partition():
     from __graft_entry__ import load_package
-    load_package()
+    pkg = load_package()
     import importlib
     par = importlib.import_module("longfellow_zk_amd.parallel")
     for n in (0, 1, 7, 150, 1024):
@@ -105,3 +102,32 @@ def test_row_shard_partition():
             assert spans[0][0] == 0 and sum(c for _, c in spans) == n
             for (s0, c0), (s1, _) in zip(spans, spans[1:]):
                 assert s0 + c0 == s1
+    # Ligero slabs: contiguous, cover [0, nrow), and the quadratic rows [iq, nrow) sit on the last rank
+    for (nw, nq, be) in ((1000, 50, 4096), (700, 40, 512), (100, 3, 256), (5000, 2000, 1024)):
+        p = pkg.ligero_param(GF, nw, nq, 4, 12, be)
+        for w in (1, 2, 3, 8):
+            spans = [par.ligero_row_shard(p, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == p.nrow
+            for (_, h0), (l1, _) in zip(spans, spans[1:]):
+                assert h0 == l1
+            assert spans[-1][0] <= p.iq
+
+
+def test_layout_rows_host_slabs_match_whole():
+    """lfgpu_ligero_layout_rows (host only): slabs cut out of the stream equal the rows of the whole layout, and the
+    draw count does not depend on the slab"""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    import importlib
+    par = importlib.import_module("longfellow_zk_amd.parallel")
+    import ligero_fixture as lf
+    import sharded_util as su
+    for field in (GF, FP):
+        p, W, sfb, lqc, seed, _ = su.statement(pkg, field)
+        lib = pkg.load_library()
+        r0 = lf.LcgRng(seed)
+        whole, nz = par.layout_rows(lib, field, 4, p, W, sfb, lqc, r0.bytes, 0, p.nrow)
+        for lo, hi in ((0, 0), (0, 3), (2, 5), (p.iq, p.nrow), (p.nrow - 1, p.nrow)):
+            r1 = lf.LcgRng(seed)
+            part, nz1 = par.layout_rows(lib, field, 4, p, W, sfb, lqc, r1.bytes, lo, hi)
+            assert (part == whole[lo:hi]).all() and nz1 == nz and r1.state == r0.state

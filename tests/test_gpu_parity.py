@@ -97,6 +97,21 @@ def test_fp128_fft_roundtrip_full_size(G):
         assert (got[i] == arr(o.lfo_fp_mul(elt(a[i]), nn))).all()
 
 
+def test_fp128_fft_full_row_2pow20_vs_oracle(G):
+    """one whole BASELINE-sized row (n = 2^20, the two-pass plan) compared element by element with the oracle's fftb"""
+    o = ol.oracle()
+    n = 1 << 20
+    a = np.zeros((2, n, 2), dtype=np.uint64)
+    for r in range(2):
+        o.lfo_fp_bogorng_fill(1234569 + r, n, P(a[r]))
+    want = a.copy()
+    for r in range(2):
+        o.lfo_fp_fftb(P(want[r]), n, o.lfo_fp_omega32(), 1 << 32)
+    d = G.to_dev(a)
+    G.gpu().fp128_fft(d.data_ptr(), 2, n)
+    assert (G.from_dev(d, np.uint64, (2, n, 2)) == want).all()
+
+
 # ---------------------------------------------------------------- K2 LCH14 FFT
 @pytest.mark.parametrize("k,l,coset,rows", [(4, 1, 0, 3), (4, 4, 16, 2), (4, 10, 0, 3), (4, 10, 5 << 10, 9), (4, 13, 0, 2),
                                             (4, 14, 0, 2), (4, 16, 0, 1), (5, 17, 3 << 17, 1), (5, 11, 1 << 11, 4)])
@@ -200,7 +215,8 @@ def test_gf2128_rs_encode_tableau_equals_row_groups(G, k, nrow, n1, n2, lo2, hi2
     assert (G.from_dev(d, np.uint64, T.shape) == want).all()
 
 
-@pytest.mark.parametrize("n,m,nrow", [(1, 4, 2), (3, 8, 2), (21, 128, 4), (100, 257, 3), (455, 4096, 2)])
+@pytest.mark.parametrize("n,m,nrow", [(1, 4, 2), (3, 8, 2), (21, 128, 4), (100, 257, 3), (455, 4096, 2), (910, 8192, 3),
+                                      (10922, 1 << 16, 2), (5000, 1 << 16, 1), (174762, 1 << 20, 1)])
 def test_fp128_rs_encode_rows(G, n, m, nrow):
     o = ol.oracle()
     T = np.zeros((nrow, m, 2), dtype=np.uint64)
@@ -211,6 +227,24 @@ def test_fp128_rs_encode_rows(G, n, m, nrow):
     d = G.to_dev(T)
     G.gpu().fp128_rs_encode_rows(d.data_ptr(), nrow, n, m)
     assert (G.from_dev(d, np.uint64, T.shape) == want).all()
+
+
+# ---------------------------------------------------------------- K10 Eqs::raw_eq2
+@pytest.mark.parametrize("field", [GF, FP])
+@pytest.mark.parametrize("logn,n", [(0, 1), (1, 2), (3, 5), (7, 128), (11, 1500), (17, 111000), (20, 1 << 20)])
+def test_raw_eq2(G, field, logn, n):
+    """lfgpu_raw_eq2 == Eqs::raw_eq2 (lib/arrays/eqs.h:46-80): called directly (the ZK driver and bind_g reach it
+    through other entry points), ragged n < 2^logn included"""
+    import torch
+    o = ol.oracle()
+    rng = np.random.default_rng(100 * logn + field)
+    G0, G1 = ol.rand_elts(rng, max(logn, 1), field), ol.rand_elts(rng, max(logn, 1), field)
+    alpha = ol.rand_elts(rng, 1, field)[0]
+    want = np.zeros((n, 2), dtype=np.uint64)
+    o.lfo_raw_eq2(field, logn, n, P(G0), P(G1), elt(alpha), P(want))
+    d = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+    G.gpu().raw_eq2(field, logn, n, G0, G1, alpha, d.data_ptr())
+    assert (G.from_dev(d, np.uint64, (n, 2)) == want).all()
 
 
 # ---------------------------------------------------------------- K5 / K6 Merkle

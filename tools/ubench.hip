@@ -8,22 +8,59 @@
 #define ITERS 4096
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
+// Every op is pinned with `asm volatile` on four independent dependence chains per lane: the round-1 version expressed
+// OP 0/3/4 in C and the compiler folded the loops (impossible 140-650 T lane-ops/s lines in profiles/r01).
+#define A4(INS, SRC)                                             \
+  asm volatile(INS " %0, %0, " SRC "\n\t" INS " %1, %1, " SRC "\n\t" INS " %2, %2, " SRC "\n\t" INS " %3, %3, " SRC \
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)          \
+               : "v"(b))
 template <int OP>
 __global__ __launch_bounds__(256) void k(u32* out, u32 seed) {
   u32 a0 = threadIdx.x * 2654435761u + seed, a1 = a0 ^ 0x9e3779b9u, a2 = a0 + 77u, a3 = a1 * 3u;
   u32 b = seed | 1u;
   u64 c0 = a0, c1 = a1, c2 = a2, c3 = a3;
+  double f0 = 1.0 + a0 * 1e-10, f1 = 1.0 + a1 * 1e-10, f2 = 1.0 + a2 * 1e-10, f3 = 1.0 + a3 * 1e-10, fb = 1.0 + seed * 1e-12, fc = 1e-9;
+  float g0 = 1.0f + a0 * 1e-10f, g1 = 1.0f + a1 * 1e-10f, g2 = 1.0f + a2 * 1e-10f, g3 = 1.0f + a3 * 1e-10f, gb = 1.0f + seed * 1e-9f, gc = 1e-6f;
+#pragma unroll 8
   for (int i = 0; i < ITERS; ++i) {
-    if (OP == 0) { a0 = a0 * b; a1 = a1 * b; a2 = a2 * b; a3 = a3 * b; }                       // v_mul_lo_u32
-    if (OP == 1) { a0 = __umulhi(a0, b); a1 = __umulhi(a1, b); a2 = __umulhi(a2, b); a3 = __umulhi(a3, b); a0 |= 0x80000001u; a1 |= 0x80000001u; a2 |= 0x80000001u; a3 |= 0x80000001u; }
-    if (OP == 2) { c0 = (u64)(u32)c0 * b + c0; c1 = (u64)(u32)c1 * b + c1; c2 = (u64)(u32)c2 * b + c2; c3 = (u64)(u32)c3 * b + c3; }  // v_mad_u64_u32
-    if (OP == 3) { a0 = __umul24(a0, b); a1 = __umul24(a1, b); a2 = __umul24(a2, b); a3 = __umul24(a3, b); }  // v_mul_u32_u24
-    if (OP == 4) { a0 ^= a1; a1 ^= a2; a2 ^= a3; a3 ^= a0; }                                      // v_xor
-    if (OP == 5) { a0 = (a0 << 3) ^ a1; a1 = (a1 << 5) ^ a2; a2 = (a2 << 7) ^ a3; a3 = (a3 << 9) ^ a0; }  // shift+xor
-    if (OP == 6) { a0 = a0 + a1 + a2; a1 = a1 + a2 + a3; a2 = a2 + a3 + a0; a3 = a3 + a0 + a1; }   // v_add3
-    if (OP == 7) { a0 = __builtin_amdgcn_alignbit(a0, a1, 7); a1 = __builtin_amdgcn_alignbit(a1, a2, 9); a2 = __builtin_amdgcn_alignbit(a2, a3, 11); a3 = __builtin_amdgcn_alignbit(a3, a0, 13); }
+    if (OP == 0) A4("v_mul_lo_u32", "%4");
+    if (OP == 1) A4("v_mul_hi_u32", "%4");
+    if (OP == 2)
+      asm volatile("v_mad_u64_u32 %0, vcc, %4, %4, %0\n\tv_mad_u64_u32 %1, vcc, %4, %4, %1\n\tv_mad_u64_u32 %2, vcc, %4, %4, %2\n\tv_mad_u64_u32 %3, vcc, %4, %4, %3"
+                   : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(b) : "vcc");
+    if (OP == 3) A4("v_mul_u32_u24", "%4");
+    if (OP == 4) A4("v_xor_b32", "%4");
+    if (OP == 5) A4("v_mul_hi_u32_u24", "%4");
+    if (OP == 6)
+      asm volatile("v_add3_u32 %0, %0, %4, %1\n\tv_add3_u32 %1, %1, %4, %2\n\tv_add3_u32 %2, %2, %4, %3\n\tv_add3_u32 %3, %3, %4, %0"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+    if (OP == 7)
+      asm volatile("v_alignbit_b32 %0, %0, %1, 7\n\tv_alignbit_b32 %1, %1, %2, 9\n\tv_alignbit_b32 %2, %2, %3, 11\n\tv_alignbit_b32 %3, %3, %0, 13"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+    if (OP == 8)  // 64-bit add as the carry pair: 2 instructions per add
+      asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc\n\tv_add_co_u32 %2, vcc, %2, %0\n\tv_addc_co_u32 %3, vcc, %3, %1, vcc"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc");
+    if (OP == 9)  // gfx940+: 64-bit shift-add in one instruction (no carry out)
+      asm volatile("v_lshl_add_u64 %0, %0, 0, %4\n\tv_lshl_add_u64 %1, %1, 0, %4\n\tv_lshl_add_u64 %2, %2, 0, %4\n\tv_lshl_add_u64 %3, %3, 0, %4"
+                   : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(c0 | 1));
+    if (OP == 10)
+      asm volatile("v_fma_f64 %0, %0, %4, %5\n\tv_fma_f64 %1, %1, %4, %5\n\tv_fma_f64 %2, %2, %4, %5\n\tv_fma_f64 %3, %3, %4, %5"
+                   : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fb), "v"(fc));
+    if (OP == 11)
+      asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5"
+                   : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3) : "v"(gb), "v"(gc));
+    if (OP == 12)
+      asm volatile("v_mad_u32_u24 %0, %0, %4, %1\n\tv_mad_u32_u24 %1, %1, %4, %2\n\tv_mad_u32_u24 %2, %2, %4, %3\n\tv_mad_u32_u24 %3, %3, %4, %0"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+    if (OP == 13)
+      asm volatile("v_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %4\n\tv_add_f64 %2, %2, %4\n\tv_add_f64 %3, %3, %4"
+                   : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fc));
+    if (OP == 14)  // v_mad_u64_u32 with the accumulate chain only through the 64-bit addend (the schoolbook-row shape)
+      asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %6, %1\n\tv_mad_u64_u32 %2, vcc, %4, %7, %2\n\tv_mad_u64_u32 %3, vcc, %4, %8, %3"
+                   : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(b), "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");
   }
-  out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ (u32)c0 ^ (u32)c1 ^ (u32)c2 ^ (u32)c3 ^ (u32)(c0 >> 32);
+  out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ (u32)c0 ^ (u32)c1 ^ (u32)c2 ^ (u32)c3 ^ (u32)(c0 >> 32) ^ (u32)(c1 >> 32) ^
+                                        (u32)__double_as_longlong(f0 + f1 + f2 + f3) ^ __float_as_uint(g0 + g1 + g2 + g3);
 }
 
 template <int F>
@@ -83,13 +120,20 @@ void runf(const char* name) {
 
 int main() {
   run<4>("v_xor_b32", 4);
-  run<5>("shl+xor (2 ops)", 8);
   run<6>("v_add3_u32", 4);
   run<7>("v_alignbit_b32", 4);
+  run<8>("v_add_co+v_addc_co (2 instr)", 4);
+  run<9>("v_lshl_add_u64", 4);
   run<3>("v_mul_u32_u24", 4);
+  run<5>("v_mul_hi_u32_u24", 4);
+  run<12>("v_mad_u32_u24", 4);
   run<0>("v_mul_lo_u32", 4);
-  run<1>("v_mul_hi_u32 (+or)", 4);
-  run<2>("v_mad_u64_u32", 4);
+  run<1>("v_mul_hi_u32", 4);
+  run<2>("v_mad_u64_u32 (b*b+acc)", 4);
+  run<14>("v_mad_u64_u32 (a*b+acc)", 4);
+  run<11>("v_fma_f32", 4);
+  run<10>("v_fma_f64", 4);
+  run<13>("v_add_f64", 4);
   runf<FIELD_FP128>("fp128 montgomery mul");
   runf<FIELD_GF2_128>("gf2_128 mul (kronecker)");
   return 0;
