@@ -569,21 +569,14 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   void* WH[2] = {d_W, d_W};
   size_t nW[2] = {nw, nw};
   // LFGPU_SC_MODE: how the rounds are driven once the HQUAD and both hand arrays are small enough
-  //   grid (default)  one cooperative launch on a grid that shrinks with the data (<= LF_SC_GRID_MAX entries)
+  //   grid (default)  one launch of co-resident workgroups on a grid that shrinks with the data (<= LF_SC_GRID_MAX entries)
   //   resident        one single-workgroup launch for the rest of the layer (<= LF_SC_SMALL_MAX entries)
   //   launch          one fused single-workgroup kernel per round-hand (<= LF_SC_SMALL_MAX entries)
   //   off             the multi-kernel path throughout
   // Larger rounds always take the multi-kernel path (whole-GPU kernels, 2 stream synchronisations per round-hand).
   static const int sc_mode = [] {
     const char* e = getenv("LFGPU_SC_MODE");
-    if (!e) {
-      // rocprofv3 (ROCm 7.2) crashes in its own finalisation when the traced process ran kernels that stay resident
-      // across host round trips (results and stats are written first, the proofs are correct): under the profiler
-      // default to one fused launch per round-hand, which it handles.  LFGPU_SC_MODE overrides.
-      const char* pre = getenv("LD_PRELOAD");
-      const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || (pre && strstr(pre, "rocprofiler"));
-      return profiled ? 1 : 3;
-    }
+    if (!e) return 3;
     return !strcmp(e, "off") ? 0 : !strcmp(e, "launch") ? 1 : !strcmp(e, "resident") ? 2 : 3;
   }();
   const bool no_fuse = sc_mode == 0;

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(SC_THREADS) void field_binop_kernel(int op, size_t 
   } while (0)
 
 
-// ---- the rest of a layer in ONE cooperative launch on a grid that shrinks with the data.
+// ---- the rest of a layer in ONE launch on a grid that shrinks with the data.
 // A workgroup's share of the products runs on one CU and a GF(2^128) product is ~510 instruction-equivalents, so the
 // phases are issue-bound per CU long before the chip is busy: the layer runs on one 1024-thread workgroup per
 // `per_wg` entries (512 for GF(2^128), 1024 for Fp128), work dealt in 64-entry chunks round-robin over the
@@ -561,8 +561,13 @@ __global__ __launch_bounds__(SC_THREADS) void field_binop_kernel(int op, size_t 
 // A device barrier costs ~2 us for 8 workgroups, 3.5 us for 32, 10 us for 128 (tools/ubench_sync.hip): hence the
 // shrinking grid, down to ONE workgroup whose barriers are plain __syncthreads and whose state lives in LDS.  Only
 // workgroup 0 polls host memory; the others take the challenge from a device-memory slot.  Every wait is bounded
-// (abort flag + wall-clock timeout), so all waves always leave.  hipLaunchCooperativeKernel guarantees that all
-// workgroups are resident.
+// (abort flag + wall-clock timeout), so all waves always leave.
+// Residency: the launch is an ORDINARY one (hipLaunchCooperativeKernel makes every rocprofv3 --kernel-trace run of
+// ROCm 7.2 segfault at process exit, inside the HIP runtime's own finaliser -- tools/coop_exit_repro.hip shows it with a
+// one-thread kernel and nothing of this library loaded; profiles/r02/rocprof_exit_crash.md).  The grid has at most
+// LF_SC_GRID_WGS <= #CU workgroups, the host checks with the occupancy API that one workgroup fits a CU, and the stream is
+// in order, so when the dispatch starts every workgroup is placed at once; should another queue hold CUs, its kernels
+// end and the rest of the grid follows (a barrier that waits longer than the timeout aborts the layer with an error).
 struct ScGridSync {  // device memory, zeroed before every launch
   u32 count, gen, abort, arrive;
   u64 chal4[4];  // the challenge as the host's four tagged words
@@ -1167,18 +1172,11 @@ bool lf_sc_resident_ok(lfgpu_ctx* c) {
   const u64 seq = c->poll_seq + 1;
   c->poll_seq += 2;
   volatile u64* cmd = c->poll_h + 64;
-  // launched the way the layer kernel is (cooperative): tools that hold such a dispatch back until it has finished
-  // (rocprofv3 --kernel-trace does) make the first post invisible while the kernel runs, and the test fails cleanly
-  {
-    u64 a_seq = seq, a_to = 200ull * c->wall_khz /*0.2 s*/;
-    volatile u64* a_post = c->poll_h;
-    const volatile u64* a_cmd = cmd;
-    void* args[] = {&a_seq, &a_to, &a_post, &a_cmd};
-    if (hipLaunchCooperativeKernel((const void*)sc_handshake_test_kernel, dim3(1), dim3(64), args, 0, c->stream) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-  }
+  // a tool that holds a dispatch back until it has finished makes the first post invisible while the kernel runs: the
+  // test then fails cleanly and the per-launch driver is used
+  hipLaunchKernelGGL(sc_handshake_test_kernel, dim3(1), dim3(64), 0, c->stream, seq, 200ull * c->wall_khz /*0.2 s*/, c->poll_h,
+                     (const volatile u64*)cmd);
+  if (hipGetLastError() != hipSuccess) return false;
   bool seen = false;  // the first post must arrive while the kernel is still waiting for us
   for (u64 spins = 0; spins < (1ull << 34); ++spins) {
     if (__atomic_load_n((const u64*)&c->poll_h[5], __ATOMIC_ACQUIRE) == seq) {
@@ -1220,7 +1218,7 @@ int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
 }
-// round-hands [rh0, 2*logw) of a layer as one cooperative launch on ceil(max size / 1024) workgroups;
+// round-hands [rh0, 2*logw) of a layer as one launch on ceil(max size / per_wg) co-resident workgroups;
 // d_state: LF_SC_GRID_STATE_BYTES of device scratch (ScGridSync + the per-workgroup counts)
 int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, const u32* d_nh, void* W0, size_t nW0,
                      void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
@@ -1278,7 +1276,13 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   a.two_level = (u32)two_level_env;
   static const int split_env = getenv("LFGPU_SC_SPLIT") ? atoi(getenv("LFGPU_SC_SPLIT")) : -1;
   a.split_waves = split_env >= 0 ? (u32)split_env : 1u;
-  LF_HIP(c, hipLaunchCooperativeKernel(fn, dim3(G), dim3(SM_THREADS), args, tail_ok ? SC_TAIL_LDS_BYTES : 0, c->stream));
+  {  // all G workgroups must be resident together (they synchronise through device memory)
+    static int per_cu[2] = {-1, -1};
+    int& pc = per_cu[field == LFGPU_FIELD_GF2_128 ? 0 : 1];
+    if (pc < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, SM_THREADS, tail_ok ? SC_TAIL_LDS_BYTES : 0) != hipSuccess) pc = 0;
+    if (pc < 1 || (long)G > (long)pc * c->num_cu) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "sc_grid_begin: %u workgroups cannot be co-resident", G);
+  }
+  LF_HIP(c, hipLaunchKernel(fn, dim3(G), dim3(SM_THREADS), args, tail_ok ? SC_TAIL_LDS_BYTES : 0, c->stream));
   return LFGPU_OK;
 }
 

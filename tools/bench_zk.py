@@ -96,7 +96,7 @@ if "--harness" in sys.argv:
     res["gpu_python_harness_total_ms"] = (t1 - t0) * 1e3
 
 gen = os.path.join(ROOT, "oracle", "_ref", "gen_flatsha_fp" if FP else "gen_flatsha")
-if os.path.exists(gen):
+if os.path.exists(gen) and "--no-cpu" not in sys.argv:
     with tempfile.TemporaryDirectory() as td_:
         r = json.loads(subprocess.check_output([gen, str(nb), os.path.join(td_, "x")]).decode())
     res["cpu_reference_ms"] = {"commit": r["ref_zk_commit_ms"], "prove": r["ref_zk_prove_ms"], "total": r["ref_zk_commit_ms"] + r["ref_zk_prove_ms"],
@@ -106,3 +106,11 @@ if os.path.exists(gen):
     if r.get("ref_zk_verify_ms"):
         res["verify_speedup_vs_cpu_reference"] = round(r["ref_zk_verify_ms"] / res["gpu_verify_ms"], 2)
 print(json.dumps(res))
+rng_t.close()
+if "--shutdown" in sys.argv:  # orderly teardown: prover, circuit, then the context (lfgpu_shutdown)
+    zk.close()
+    circ.close()
+    gpu.close()
+for a in sys.argv:
+    if a.startswith("--maps="):  # address map of the process, to resolve frames of a crash at exit
+        open(a[7:], "w").write(open("/proc/self/maps").read())
