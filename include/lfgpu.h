@@ -16,6 +16,7 @@
  *  - Field elements are the reference's in-memory Elt images, 16 bytes:
  *      field 4 (GF2_128): 2 x u64 LE, polynomial basis (lib/gf2k/gf2_128.h:64-89)
  *      field 6 (Fp128)  : 2 x u64 LE, Montgomery form R = 2^128 (lib/algebra/fp_generic.h:66-78)
+ *    field 1 (P256, Fp256Base) elements are 32 bytes: 4 x u64 LE, Montgomery form R = 2^256.
  *    so adapters can pass &tableau_[0] straight through.
  *  - Pointers named d_* are DEVICE pointers (HIP); h_* are host pointers.
  *    The *_host variants stage through device memory owned by the context.
@@ -42,6 +43,9 @@ extern "C" {
 
 #define LFGPU_FIELD_GF2_128 4 /* FieldID, lib/proto/circuit_io.h:24-36 */
 #define LFGPU_FIELD_FP128 6
+#define LFGPU_FIELD_P256 1 /* Fp256Base, the P-256 base field: 32-byte elements (lib/algebra/fp_p256.h); accepted by
+                              lfgpu_fp256_rs_encode_rows, lfgpu_column_commit / lfgpu_column_leaves and lfgpu_field_binop,
+                              where ld / n then count 32-byte elements */
 
 typedef struct lfgpu_ctx lfgpu_ctx;
 
@@ -89,6 +93,14 @@ int lfgpu_gf2128_rs_encode_tableau(lfgpu_ctx* ctx, int subfield_log_bits, size_t
                                    size_t hi2, size_t m, void* d_T, size_t ld);
 int lfgpu_fp128_rs_encode_rows(lfgpu_ctx* ctx, size_t nrow, size_t n, size_t m, const uint64_t omega[2],
                                uint64_t omega_order, void* d_T, size_t ld);
+
+/* The P-256 base field (BASELINE config 5, the mdoc signature circuit): replaces
+ * ReedSolomon<Fp256Base, FFTExtConvolutionFactory<Fp256Base, Fp2<Fp256Base>>>::interpolate
+ * (lib/algebra/reed_solomon.h:93-110 over convolution.h:129-191 / rfft.h:282-376; factory built at
+ * lib/circuits/mdoc/mdoc_zk.cc:485-487) on every row of a tableau of 32-byte elements; ld counts 32-byte elements.
+ * No omega argument: the interpolation does not depend on which 2^k-th root of unity carries the convolution (the
+ * device uses the reference's root of order 2^31, mdoc_zk.cc:82-88). */
+int lfgpu_fp256_rs_encode_rows(lfgpu_ctx* ctx, size_t nrow, size_t n, size_t m, void* d_T, size_t ld);
 
 /* ---- K5 + K6: Merkle column commitment ------------------------------------
  * Replaces MerkleCommitment::commit (lib/merkle/merkle_commitment.h:50-64) with

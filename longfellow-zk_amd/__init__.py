@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("LFGPU_LIB") or os.path.join(_HERE, "liblfgpu.so")  # 
 
 FIELD_GF2_128 = 4  # FieldID, reference lib/proto/circuit_io.h:24-36
 FIELD_FP128 = 6
+FIELD_P256 = 1  # Fp256Base, 32-byte elements
 
 # 2^32-order root of unity of Fp128 (reference lib/algebra/fp_p128.h:48-56), canonical value
 FP128_OMEGA32 = 164956748514267535023998284330560247862
@@ -24,7 +25,7 @@ FP128_P = 2**128 - 2**108 + 1
 ABI_SYMBOLS = [
     "lfgpu_init", "lfgpu_shutdown", "lfgpu_last_error", "lfgpu_set_stream", "lfgpu_sync", "lfgpu_malloc",
     "lfgpu_free", "lfgpu_memcpy_h2d", "lfgpu_memcpy_d2h", "lfgpu_fp128_fft", "lfgpu_gf2128_lch14_fft",
-    "lfgpu_gf2128_rs_encode_rows", "lfgpu_gf2128_rs_encode_tableau", "lfgpu_fp128_rs_encode_rows", "lfgpu_column_commit", "lfgpu_column_leaves", "lfgpu_merkle_build_tree",
+    "lfgpu_gf2128_rs_encode_rows", "lfgpu_gf2128_rs_encode_tableau", "lfgpu_fp128_rs_encode_rows", "lfgpu_fp256_rs_encode_rows", "lfgpu_column_commit", "lfgpu_column_leaves", "lfgpu_merkle_build_tree",
     "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
     "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_field_binop", "lfgpu_fp128_fft_host", "lfgpu_gf2128_lch14_fft_host",
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_column_commit_host",
@@ -99,6 +100,7 @@ def load_library():
         "lfgpu_gf2128_rs_encode_rows": [vp, ci, sz, sz, sz, vp, sz],
         "lfgpu_gf2128_rs_encode_tableau": [vp, ci, sz, sz, sz, sz, sz, sz, vp, sz],
         "lfgpu_fp128_rs_encode_rows": [vp, sz, sz, sz, pu64, u64, vp, sz],
+        "lfgpu_fp256_rs_encode_rows": [vp, sz, sz, sz, vp, sz],
         "lfgpu_column_commit": [vp, ci, sz, sz, sz, sz, vp, vp, vp, vp],
         "lfgpu_column_leaves": [vp, ci, sz, sz, sz, sz, vp, vp, vp],
         "lfgpu_merkle_build_tree": [vp, sz, vp, vp],
@@ -240,6 +242,10 @@ class LfGpu:
         omega = _u64x2(fp128_to_montgomery(FP128_OMEGA32) if omega is None else omega)
         self._ck(self.L.lfgpu_fp128_rs_encode_rows(self.h, nrow, n, m, omega, omega_order, C.c_void_p(d_ptr),
                                                    m if ld is None else ld))
+
+    # --- ReedSolomon<Fp256Base, FFTExtConvolution>::interpolate over rows of 32-byte elements (BASELINE config 5)
+    def fp256_rs_encode_rows(self, d_ptr, nrow, n, m, ld=None):
+        self._ck(self.L.lfgpu_fp256_rs_encode_rows(self.h, nrow, n, m, C.c_void_p(d_ptr), m if ld is None else ld))
 
     # --- inner_product_vector + layout_Aext on the device (reference lib/ligero/ligero_param.h:382-430)
     def ligero_inner_product_rows(self, field, w, r, ld, nrows, d_dense, ndense, scale, idx, val, d_rows):

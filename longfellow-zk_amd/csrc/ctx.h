@@ -151,6 +151,10 @@ int lf_hquad_bind_h_cached(lfgpu_ctx* c, int field, size_t n, const void* d_hc, 
 struct lfgpu_quad;
 int lf_eval_quad_async(lfgpu_quad* q, const void* d_W, void* d_V, int* d_fail);  // quad.hip
 
+// p256.hip (field id 1, 32-byte elements)
+int lf_column_leaves32(lfgpu_ctx* c, size_t nrow, size_t ld, size_t col0, size_t ncols, const void* d_T, const void* d_nonces, void* d_out, size_t out0);
+int lf_p256_binop(lfgpu_ctx* c, int op, size_t n, const void* d_a, const void* d_b, void* d_out);
+
 static inline unsigned lf_log2(size_t n) {
   unsigned l = 0;
   while (((size_t)1 << l) < n) ++l;

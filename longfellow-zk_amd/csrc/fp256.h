@@ -1,0 +1,161 @@
+// fp256.h -- the P-256 base field Fp256Base = FpGeneric<4, true, Fp256Reduce> (reference lib/algebra/fp_p256.h:32-63,
+// lib/algebra/fp_generic.h) and its quadratic extension Fp2<Fp256Base> (lib/algebra/fp2.h), host + device.
+//
+// Element = the reference's in-memory Elt image: 4 x u64 little-endian limbs of the Montgomery form x * 2^256 mod p,
+// 32 bytes.  p = 2^256 - 2^224 + 2^192 + 2^96 - 1, so p = -1 (mod 2^96): -p^-1 mod 2^32 = 1 and a reduction step needs no
+// multiplication -- with m = the low limb, m * p = m * 2^256 - m * 2^224 + m * 2^192 + m * 2^96 - m (fp_p256.h:43-62).
+#pragma once
+#include "fields.h"
+
+struct alignas(16) elt32_t {
+  u64 l[4];
+};
+struct alignas(16) fp2_t {  // Fp2<Fp256Base>::Elt {re, im}
+  elt32_t re, im;
+};
+
+#define FIELD_P256 1  // FieldID P256_ID (lib/proto/circuit_io.h:24-36)
+
+LF_HD inline elt32_t e32_zero() { return elt32_t{{0, 0, 0, 0}}; }
+LF_HD inline bool e32_eq(const elt32_t& a, const elt32_t& b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
+
+// p as 8 x u32 limbs
+#define P256_W0 0xFFFFFFFFu
+#define P256_W1 0xFFFFFFFFu
+#define P256_W2 0xFFFFFFFFu
+#define P256_W3 0x00000000u
+#define P256_W4 0x00000000u
+#define P256_W5 0x00000000u
+#define P256_W6 0x00000001u
+#define P256_W7 0xFFFFFFFFu
+
+namespace fp256_detail {
+LF_HD inline void to_w(const elt32_t& a, u32 (&w)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w[2 * i] = (u32)a.l[i];
+    w[2 * i + 1] = (u32)(a.l[i] >> 32);
+  }
+}
+LF_HD inline elt32_t from_w(const u32 (&w)[8]) {
+  elt32_t r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.l[i] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
+  return r;
+}
+LF_HD inline u32 pw(int i) {
+  return i == 0 ? P256_W0 : i == 1 ? P256_W1 : i == 2 ? P256_W2 : i == 3 ? P256_W3 : i == 4 ? P256_W4 : i == 5 ? P256_W5 : i == 6 ? P256_W6 : P256_W7;
+}
+// r = a - p if a >= p (a < 2p given with its carry-out bit `hi`)
+LF_HD inline void cond_sub_p(u32 (&t)[8], u32 hi) {
+  u32 d[8];
+  u64 br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u64 x = (u64)t[i] - pw(i) - br;
+    d[i] = (u32)x;
+    br = (x >> 32) & 1u;
+  }
+  const bool ge = hi != 0 || br == 0;  // a >= p
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = ge ? d[i] : t[i];
+}
+}  // namespace fp256_detail
+
+LF_HD inline elt32_t fp256_add(const elt32_t& a, const elt32_t& b) {
+  u32 x[8], y[8], t[8];
+  fp256_detail::to_w(a, x);
+  fp256_detail::to_w(b, y);
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (u64)x[i] + y[i];
+    t[i] = (u32)c;
+    c >>= 32;
+  }
+  fp256_detail::cond_sub_p(t, (u32)c);
+  return fp256_detail::from_w(t);
+}
+LF_HD inline elt32_t fp256_sub(const elt32_t& a, const elt32_t& b) {
+  u32 x[8], y[8], t[8];
+  fp256_detail::to_w(a, x);
+  fp256_detail::to_w(b, y);
+  u64 br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const u64 d = (u64)x[i] - y[i] - br;
+    t[i] = (u32)d;
+    br = (d >> 32) & 1u;
+  }
+  const u32 mask = 0u - (u32)br;  // borrow: add p back
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (u64)t[i] + (fp256_detail::pw(i) & mask);
+    t[i] = (u32)c;
+    c >>= 32;
+  }
+  return fp256_detail::from_w(t);
+}
+LF_HD inline elt32_t fp256_neg(const elt32_t& a) { return fp256_sub(e32_zero(), a); }
+
+// Montgomery product a * b / 2^256 mod p: operand scanning over 32-bit limbs, one multiplication-free reduction step per
+// limb (m = t[0]: t += m * p, then drop the zero limb).
+LF_HD inline elt32_t fp256_mul(const elt32_t& a, const elt32_t& b) {
+  u32 x[8], y[8];
+  fp256_detail::to_w(a, x);
+  fp256_detail::to_w(b, y);
+  u32 t[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    // t += x[i] * y
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      c += (u64)x[i] * y[j] + t[j];
+      t[j] = (u32)c;
+      c >>= 32;
+    }
+    c += t[8];
+    t[8] = (u32)c;
+    t[9] = (u32)(c >> 32);
+    // t += m * p with m = t[0]:  m*p = -m + m*2^96 + m*2^192 - m*2^224 + m*2^256
+    const u32 m = t[0];
+    // add m at limbs 3, 6, 8 and subtract m at limbs 0, 7 (signed carry chain)
+    long long s;
+    s = (long long)t[0] - m;  // = 0
+    s >>= 32;
+    s += t[1]; t[0] = (u32)s; s >>= 32;                       // shifted down by one limb as we go
+    s += t[2]; t[1] = (u32)s; s >>= 32;
+    s += (long long)t[3] + m; t[2] = (u32)s; s >>= 32;
+    s += t[4]; t[3] = (u32)s; s >>= 32;
+    s += t[5]; t[4] = (u32)s; s >>= 32;
+    s += (long long)t[6] + m; t[5] = (u32)s; s >>= 32;
+    s += (long long)t[7] - m; t[6] = (u32)s; s >>= 32;
+    s += (long long)t[8] + m; t[7] = (u32)s; s >>= 32;
+    s += t[9]; t[8] = (u32)s;
+    t[9] = 0;
+  }
+  u32 r[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = t[i];
+  fp256_detail::cond_sub_p(r, t[8]);
+  return fp256_detail::from_w(r);
+}
+
+// canonical value (to_bytes_field = from_montgomery, little-endian bytes): x * 1 / R
+LF_HD inline elt32_t fp256_canon(const elt32_t& a) { return fp256_mul(a, elt32_t{{1, 0, 0, 0}}); }
+
+// ---- Fp2<Fp256Base>, i^2 = -1 (lib/algebra/fp2.h:77-95: Karatsuba, 3 products)
+LF_HD inline fp2_t fp2_add(const fp2_t& a, const fp2_t& b) { return fp2_t{fp256_add(a.re, b.re), fp256_add(a.im, b.im)}; }
+LF_HD inline fp2_t fp2_sub(const fp2_t& a, const fp2_t& b) { return fp2_t{fp256_sub(a.re, b.re), fp256_sub(a.im, b.im)}; }
+LF_HD inline fp2_t fp2_mul(const fp2_t& a, const fp2_t& y) {
+  const elt32_t p0 = fp256_mul(a.re, y.re), p1 = fp256_mul(a.im, y.im);
+  const elt32_t a01 = fp256_add(a.re, a.im), y01 = fp256_add(y.re, y.im);
+  fp2_t r;
+  r.re = fp256_sub(p0, p1);
+  r.im = fp256_sub(fp256_sub(fp256_mul(a01, y01), p0), p1);
+  return r;
+}

@@ -150,6 +150,8 @@ static int column_leaves(lfgpu_ctx* c, const char* who, int field, size_t nrow, 
   else if (field == LFGPU_FIELD_FP128)
     hipLaunchKernelGGL(column_leaves_kernel<FIELD_FP128>, dim3(nb), dim3(SHA_THREADS), 0, c->stream, (u32)nrow, ld,
                        col0, (u32)ncols, (const elt_t*)d_T, (const uint4*)d_nonces, (uint4*)d_out, out0);
+  else if (field == LFGPU_FIELD_P256)
+    return lf_column_leaves32(c, nrow, ld, col0, ncols, d_T, d_nonces, d_out, out0);
   else
     return lf_fail(c, LFGPU_ERR_ARG, "%s: unknown field %d", who, field);
   LF_HIP(c, hipGetLastError());

@@ -1498,6 +1498,7 @@ extern "C" int lfgpu_field_binop(lfgpu_ctx* c, int field, int op, size_t n, cons
   if (!c || (n && (!d_a || !d_b || !d_out)) || op < 0 || op > 2) return lf_fail(c, LFGPU_ERR_ARG, "field_binop: bad argument");
   if (n == 0) return LFGPU_OK;
   LF_HIP(c, hipSetDevice(c->device));
+  if (field == LFGPU_FIELD_P256) return lf_p256_binop(c, op, n, d_a, d_b, d_out);
   u32 nb = (u32)((n + SC_THREADS - 1) / SC_THREADS);
   DISPATCH_FIELD(field, field_binop_kernel, dim3(nb), dim3(SC_THREADS), op, n, (const elt_t*)d_a, (const elt_t*)d_b,
                  (elt_t*)d_out);

@@ -145,6 +145,26 @@ void lfo_fp_bogorng_fill(uint64_t seed, size_t n, lfo_elt* out);
 /* deterministic GF(2^128) filler: splitmix64 stream */
 void lfo_gf_fill(uint64_t seed, size_t n, lfo_elt* out);
 
+/* ---- P-256 base field Fp256Base + RFFT<Fp2<Fp256Base>> Reed-Solomon + 32-byte column hash (lf_oracle_p256.c):
+ * BASELINE config 5's signature tableau (lib/algebra/{fp_p256.h,rfft.h,convolution.h:129-191,reed_solomon.h}) */
+typedef struct { uint64_t l[4]; } lfo_e32; /* Fp256Base::Elt image: Montgomery form, 4 x u64 LE */
+lfo_e32 lfo_p256_add(lfo_e32 a, lfo_e32 b);
+lfo_e32 lfo_p256_sub(lfo_e32 a, lfo_e32 b);
+lfo_e32 lfo_p256_mul(lfo_e32 a, lfo_e32 b);
+lfo_e32 lfo_p256_to_mont(lfo_e32 raw);
+lfo_e32 lfo_p256_from_mont(lfo_e32 x);
+lfo_e32 lfo_p256_of_scalar(uint64_t u);
+lfo_e32 lfo_p256_inv(lfo_e32 x);
+void lfo_p256_to_bytes(uint8_t out[32], lfo_e32 x);
+void lfo_p256_fill(uint64_t seed, size_t n, lfo_e32* out);
+void lfo_p256_omega(lfo_e32* re, lfo_e32* im); /* root of order 2^31 of Fp2 (mdoc_zk.cc:82-88) */
+void lfo_p256_r2hc(lfo_e32* A, size_t n);      /* RFFT::r2hc with that root */
+void lfo_p256_hc2r(lfo_e32* A, size_t n);
+void lfo_p256_rs_interpolate(size_t n, size_t m, lfo_e32* y);
+void lfo_column_leaves32(size_t nrow, size_t ld, size_t col0, size_t ncols, const lfo_e32* T, const uint8_t* nonces, uint8_t* leaves);
+void lfo_column_commit32(size_t nrow, size_t ld, size_t col0, size_t ncols, const lfo_e32* T, const uint8_t* nonces,
+                         uint8_t root_out[32], uint8_t* layers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,7 +24,10 @@
 #include "algebra/bogorng.h"
 #include "algebra/convolution.h"
 #include "algebra/fft.h"
+#include "algebra/fp2.h"
 #include "algebra/fp_p128.h"
+#include "algebra/fp_p256.h"
+#include "algebra/rfft.h"
 #include "algebra/poly.h"
 #include "algebra/reed_solomon.h"
 #include "arrays/affine.h"
@@ -371,3 +374,74 @@ static void raw_eq2_t(const Field& F, size_t logn, size_t n, const void* G0, con
 extern "C" void ref_raw_eq2(int field, size_t logn, size_t n, const void* G0, const void* G1, const void* alpha, void* out) {
   if (field == 4) raw_eq2_t(gf4(), logn, n, G0, G1, alpha, out); else raw_eq2_t(fp(), logn, n, G0, G1, alpha, out);
 }
+
+// ---------------------------------------------------------------- P-256 base field (BASELINE config 5: the mdoc
+// signature circuit's ZkProver<Fp256Base, ReedSolomonFactory<Fp256Base, FFTExtConvolutionFactory>>,
+// lib/circuits/mdoc/mdoc_zk.cc:70-88,485-500)
+namespace {
+using F256 = Fp256<true>;  // = Fp256Base (lib/ec/p256.h:42)
+using F256_2 = Fp2<F256>;
+static_assert(sizeof(F256::Elt) == 32, "Fp256Base Elt is 32 bytes");
+const F256& f256() {
+  static const F256 f;
+  return f;
+}
+const F256_2& f256_2() {
+  static const F256_2 f(f256());
+  return f;
+}
+F256_2::Elt omega31() {
+  return f256_2().of_string("112649224146410281873500457609690258373018840430489408729223714171582664680802",
+                            "84087994358540907695740461427818660560182168997182378749313018254450460212908");
+}
+F256::Elt ld32(const void* p) {
+  F256::Elt e;
+  memcpy(&e, p, 32);
+  return e;
+}
+void st32(void* p, const F256::Elt& e) { memcpy(p, &e, 32); }
+}  // namespace
+
+extern "C" {
+void ref_p256_mul(const void* a, const void* b, void* out) { st32(out, f256().mulf(ld32(a), ld32(b))); }
+void ref_p256_add(const void* a, const void* b, void* out) { st32(out, f256().addf(ld32(a), ld32(b))); }
+void ref_p256_sub(const void* a, const void* b, void* out) { st32(out, f256().subf(ld32(a), ld32(b))); }
+void ref_p256_inv(const void* a, void* out) { st32(out, f256().invertf(ld32(a))); }
+void ref_p256_of_scalar(uint64_t u, void* out) { st32(out, f256().of_scalar(u)); }
+void ref_p256_to_bytes(const void* a, uint8_t out[32]) { f256().to_bytes_field(out, ld32(a)); }
+void ref_p256_omega(void* re, void* im) {
+  auto w = omega31();
+  st32(re, w.re);
+  st32(im, w.im);
+}
+void ref_p256_rfft(int dir, size_t n, void* A) {  // dir 0: r2hc, 1: hc2r
+  auto* a = reinterpret_cast<F256::Elt*>(A);
+  if (dir == 0)
+    RFFT<F256_2>::r2hc(a, n, omega31(), uint64_t(1) << 31, f256_2());
+  else
+    RFFT<F256_2>::hc2r(a, n, omega31(), uint64_t(1) << 31, f256_2());
+}
+void ref_p256_rs_interpolate(size_t n, size_t m, void* y) {
+  using CF = FFTExtConvolutionFactory<F256, F256_2>;
+  CF cf(f256(), f256_2(), omega31(), uint64_t(1) << 31);
+  ReedSolomonFactory<F256, CF> rsf(cf, f256());
+  rsf.make(n, m)->interpolate(reinterpret_cast<F256::Elt*>(y));
+}
+void ref_p256_rs_encode_rows(size_t nrow, size_t n, size_t m, void* T, size_t ld_) {
+  using CF = FFTExtConvolutionFactory<F256, F256_2>;
+  CF cf(f256(), f256_2(), omega31(), uint64_t(1) << 31);
+  ReedSolomonFactory<F256, CF> rsf(cf, f256());
+  auto rs = rsf.make(n, m);
+  auto* t = reinterpret_cast<F256::Elt*>(T);
+  for (size_t r = 0; r < nrow; ++r) rs->interpolate(t + r * ld_);
+}
+void ref_p256_column_commit(size_t nrow, size_t ld_, size_t col0, size_t ncols, const void* tableau, const uint8_t* nonces,
+                            uint8_t* root_out) {
+  BufferRng rng(nonces, 32 * ncols);
+  MerkleCommitment mc(ncols);
+  const auto* T = reinterpret_cast<const F256::Elt*>(tableau);
+  auto upd = [&](size_t j, proofs::SHA256& sha) { LigeroCommon<F256>::column_hash(nrow, &T[j + col0], ld_, sha, f256()); };
+  Digest root = mc.commit(upd, rng);
+  memcpy(root_out, root.data, 32);
+}
+}  // extern "C"

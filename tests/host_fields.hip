@@ -88,3 +88,11 @@ extern "C" void hf_transpose32(u32* x) {
   bs_transpose32(y);
   for (int i = 0; i < 32; ++i) x[i] = y[i];
 }
+
+// ---- fp256.h (P-256 base field, 32-byte elements)
+#include "../longfellow-zk_amd/csrc/fp256.h"
+extern "C" void hf_p256_mul(const elt32_t* a, const elt32_t* b, elt32_t* o) { *o = fp256_mul(*a, *b); }
+extern "C" void hf_p256_add(const elt32_t* a, const elt32_t* b, elt32_t* o) { *o = fp256_add(*a, *b); }
+extern "C" void hf_p256_sub(const elt32_t* a, const elt32_t* b, elt32_t* o) { *o = fp256_sub(*a, *b); }
+extern "C" void hf_p256_canon(const elt32_t* a, elt32_t* o) { *o = fp256_canon(*a); }
+extern "C" void hf_p256_c2mul(const fp2_t* a, const fp2_t* b, fp2_t* o) { *o = fp2_mul(*a, *b); }

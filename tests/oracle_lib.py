@@ -19,6 +19,27 @@ class Elt(C.Structure):
     _fields_ = [("l", C.c_uint64 * 2)]
 
 
+class E32(C.Structure):
+    """lfo_e32: Fp256Base::Elt image (Montgomery form, 4 x u64 LE)"""
+    _fields_ = [("l", C.c_uint64 * 4)]
+
+
+P256 = 1  # FieldID P256_ID
+P256_P = 2**256 - 2**224 + 2**192 + 2**96 - 1
+
+
+def e32(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(4)
+    e = E32()
+    for i in range(4):
+        e.l[i] = int(a[i])
+    return e
+
+
+def arr32(e):
+    return np.array([e.l[i] for i in range(4)], dtype=np.uint64)
+
+
 class GfCtx(C.Structure):
     _fields_ = [("k", C.c_uint), ("sub_bits", C.c_uint), ("g", Elt), ("beta", Elt * 32),
                 ("w_hat", (Elt * 32) * 32)]
@@ -26,8 +47,8 @@ class GfCtx(C.Structure):
 
 def _build_oracle():
     so = os.path.join(ORACLE_DIR, "liblforacle.so")
-    src = os.path.join(ORACLE_DIR, "lf_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("lf_oracle.c", "lf_oracle_p256.c", "lf_oracle.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liblforacle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -58,6 +79,13 @@ def oracle():
     L = C.CDLL(_build_oracle())
     sz, u64, vp, ci = C.c_size_t, C.c_uint64, C.c_void_p, C.c_int
     sig = {
+        "lfo_p256_add": (E32, [E32, E32]), "lfo_p256_sub": (E32, [E32, E32]), "lfo_p256_mul": (E32, [E32, E32]),
+        "lfo_p256_to_mont": (E32, [E32]), "lfo_p256_from_mont": (E32, [E32]), "lfo_p256_of_scalar": (E32, [u64]),
+        "lfo_p256_inv": (E32, [E32]), "lfo_p256_to_bytes": (None, [vp, E32]), "lfo_p256_fill": (None, [u64, sz, vp]),
+        "lfo_p256_omega": (None, [vp, vp]), "lfo_p256_r2hc": (None, [vp, sz]), "lfo_p256_hc2r": (None, [vp, sz]),
+        "lfo_p256_rs_interpolate": (None, [sz, sz, vp]),
+        "lfo_column_leaves32": (None, [sz, sz, sz, sz, vp, vp, vp]),
+        "lfo_column_commit32": (None, [sz, sz, sz, sz, vp, vp, vp, vp]),
         "lfo_gf_mul": (Elt, [Elt, Elt]), "lfo_gf_mul_bitserial": (Elt, [Elt, Elt]), "lfo_gf_inv": (Elt, [Elt]),
         "lfo_gf_ctx_init": (None, [C.POINTER(GfCtx), C.c_uint]),
         "lfo_gf_of_scalar": (Elt, [C.POINTER(GfCtx), u64]),
@@ -148,6 +176,11 @@ def ref():
         "ref_eval_quad": (ci, [ci, sz, vp, vp, vp, vp, sz, vp, sz, sz, vp, vp]),
         "ref_quad_bind_g": (sz, [ci, sz, vp, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp]),
         "ref_raw_eq2": (None, [ci, sz, sz, vp, vp, vp, vp]),
+        "ref_p256_mul": (None, [vp, vp, vp]), "ref_p256_add": (None, [vp, vp, vp]), "ref_p256_sub": (None, [vp, vp, vp]),
+        "ref_p256_inv": (None, [vp, vp]), "ref_p256_of_scalar": (None, [u64, vp]), "ref_p256_to_bytes": (None, [vp, vp]),
+        "ref_p256_omega": (None, [vp, vp]), "ref_p256_rfft": (None, [ci, sz, vp]),
+        "ref_p256_rs_interpolate": (None, [sz, sz, vp]), "ref_p256_rs_encode_rows": (None, [sz, sz, sz, vp, sz]),
+        "ref_p256_column_commit": (None, [sz, sz, sz, sz, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -20,8 +20,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 def _lib():
-    hdr = os.path.join(ol.ROOT, "longfellow-zk_amd", "csrc", "fields.h")
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(ol.ROOT, "longfellow-zk_amd", "csrc", h) for h in ("fields.h", "fp256.h", "bitslice.h")]
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max([os.path.getmtime(SRC)] + [os.path.getmtime(h) for h in hdrs]):
         if not os.path.exists(HIPCC):
             pytest.skip("hipcc not available")
         subprocess.check_call([HIPCC, "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
@@ -129,3 +129,40 @@ def test_bitsliced_tower_multiply_matches_gf_mul(k, mode):
         L.hf_bs_mul(k, P(t), P(x), P(out), mode)
         for r in range(32):
             assert (out[r] == arr(o.lfo_gf_mul(elt(t), elt(x[r])))).all(), (trial, r)
+
+
+def test_p256_ops_match_oracle_and_big_integers():
+    """fp256.h (Fp256Base Montgomery arithmetic with the multiplication-free reduction step, fp_p256.h:43-62) on the host
+    against the oracle's generic CIOS and against Python integers, edge values included"""
+    L, o = _lib(), ol.oracle()
+    p, R = ol.P256_P, 1 << 256
+    rng = np.random.default_rng(256)
+
+    def to_arr(v):
+        return np.array([(v >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+
+    def to_int(a):
+        return sum(int(a[i]) << (64 * i) for i in range(4))
+
+    vals = [0, 1, 2, p - 1, p - 2, (1 << 96) - 1, 1 << 96, (1 << 192), (1 << 224) - 1, p >> 1, (p >> 1) + 1, 2**255, 2**32 - 1, 2**64 - 1, 2**64]
+    vals += [int.from_bytes(rng.bytes(32), "little") % p for _ in range(600)]
+    pairs = [(a, b) for a in vals[:15] for b in vals[:15]] + list(zip(vals[15:315], vals[315:615]))
+    Rinv = pow(R, -1, p)
+    for a, b in pairs:
+        xa, xb = to_arr(a), to_arr(b)
+        for name, want in (("mul", a * b * Rinv % p), ("add", (a + b) % p), ("sub", (a - b) % p)):
+            out = np.zeros(4, dtype=np.uint64)
+            getattr(L, "hf_p256_" + name)(P(xa), P(xb), P(out))
+            assert to_int(out) == want, (name, hex(a), hex(b))
+            assert (out == ol.arr32(getattr(o, "lfo_p256_" + name)(ol.e32(xa), ol.e32(xb)))).all()
+        out = np.zeros(4, dtype=np.uint64)
+        L.hf_p256_canon(P(xa), P(out))
+        assert to_int(out) == a * Rinv % p
+    # Fp2 product: (a + bi)(c + di) in Montgomery form
+    for _ in range(100):
+        a, b, c, d = (int.from_bytes(rng.bytes(32), "little") % p for _ in range(4))
+        x = np.concatenate([to_arr(a), to_arr(b)])
+        y = np.concatenate([to_arr(c), to_arr(d)])
+        out = np.zeros(8, dtype=np.uint64)
+        L.hf_p256_c2mul(P(x), P(y), P(out))
+        assert to_int(out[:4]) == (a * c - b * d) * Rinv % p and to_int(out[4:]) == (a * d + b * c) * Rinv % p

@@ -1,0 +1,126 @@
+"""P-256 base-field leg (BASELINE config 5) on the CPU: the oracle restatement (oracle/lf_oracle_p256.c) against the
+compiled reference (oracle/_ref, when present) and against tests/golden/ref_vectors_p256.json (always)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from oracle_lib import P
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fill(seed, n):
+    a = np.zeros((n, 4), dtype=np.uint64)
+    ol.oracle().lfo_p256_fill(seed, n, P(a))
+    return a
+
+
+def un(h, shape=(4,), dtype=np.uint64):
+    return np.frombuffer(bytes.fromhex(h), dtype=dtype).reshape(shape).copy()
+
+
+def sig_tableau(g):
+    c = g["config5_sig_tableau"]
+    T = np.zeros((c["nrow"], c["block_enc"], 4), dtype=np.uint64)
+    for r in range(c["nrow"]):
+        n = c["dblock"] if r in (1, 2) else c["block"]
+        T[r, :n] = fill(c["row_seed0"] + r, n)
+    return c, T
+
+
+@pytest.fixture(scope="module")
+def g():
+    with open(os.path.join(GOLD, "ref_vectors_p256.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_matches_golden_field_ops_and_small_transforms(g):
+    o = ol.oracle()
+    a, b = fill(1, 40), fill(2, 40)
+    pm1 = [0xFFFFFFFFFFFFFFFE, 0x00000000FFFFFFFF, 0, 0xFFFFFFFF00000001]
+    a[0], b[0] = pm1, pm1
+    a[1], b[1] = [0, 0, 0, 0], pm1
+    a[2], b[2] = pm1, [1, 0, 0, 0]
+    for i, want in enumerate(g["field_ops"]["out"]):
+        for name in ("mul", "add", "sub"):
+            got = ol.arr32(getattr(o, "lfo_p256_" + name)(ol.e32(a[i]), ol.e32(b[i])))
+            assert (got == un(want[name])).all(), (name, i)
+        by = np.zeros(32, dtype=np.uint8)
+        o.lfo_p256_to_bytes(P(by), ol.e32(a[i]))
+        assert by.tobytes().hex() == want["bytes"]
+    for n in (8, 64):
+        x = fill(300 + n, n)
+        o.lfo_p256_r2hc(P(x), n)
+        assert x.tobytes().hex() == g["r2hc_%d" % n]["out"]
+        o.lfo_p256_hc2r(P(x), n)  # hc2r(r2hc(x)) = n x
+        y = fill(300 + n, n)
+        nn = o.lfo_p256_of_scalar(n)
+        for i in range(n):
+            assert (x[i] == ol.arr32(o.lfo_p256_mul(ol.e32(y[i]), nn))).all()
+    for v in g["rs"]:
+        y = np.zeros((v["m"], 4), dtype=np.uint64)
+        y[:v["n"]] = fill(v["seed"], v["n"])
+        o.lfo_p256_rs_interpolate(v["n"], v["m"], P(y))
+        assert hashlib.sha256(y.tobytes()).hexdigest() == v["out_sha256"] and y[-1].tobytes().hex() == v["out_tail"]
+
+
+def test_oracle_reproduces_config5_signature_tableau(g):
+    """RS rows (455 -> 4096, 909 -> 4096) + column commit of the mdoc signature tableau shape: encoded bytes and root
+    equal the reference's"""
+    import ligero_fixture as lf
+    o = ol.oracle()
+    c, T = sig_tableau(g)
+    for r in range(c["nrow"]):
+        o.lfo_p256_rs_interpolate(c["dblock"] if r in (1, 2) else c["block"], c["block_enc"], P(T[r]))
+    assert hashlib.sha256(T.tobytes()).hexdigest() == c["encoded_sha256"]
+    nonces = np.frombuffer(lf.LcgRng(c["nonce_lcg_seed"]).bytes(32 * c["block_ext"]), dtype=np.uint8).reshape(-1, 32).copy()
+    root = np.zeros(32, dtype=np.uint8)
+    o.lfo_column_commit32(c["nrow"], c["block_enc"], c["dblock"], c["block_ext"], P(T), P(nonces), P(root), None)
+    assert root.tobytes().hex() == c["root"]
+
+
+@pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref not built (reference absent)")
+def test_oracle_vs_compiled_reference():
+    o, r = ol.oracle(), ol.ref()
+    rng = np.random.default_rng(1)
+    a, b = fill(11, 300), fill(12, 300)
+    pm1 = [0xFFFFFFFFFFFFFFFE, 0x00000000FFFFFFFF, 0, 0xFFFFFFFF00000001]
+    a[0] = [0, 0, 0, 0]
+    a[1], b[1] = pm1, pm1
+    a[2], b[2] = pm1, [1, 0, 0, 0]
+    a[3] = [0xFFFFFFFFFFFFFFFF, 0xFFFFFFFF, 0, 0xFFFFFFFF00000000]
+    b[3] = a[3]
+    for i in range(300):
+        for name in ("mul", "add", "sub"):
+            out = np.zeros(4, dtype=np.uint64)
+            getattr(r, "ref_p256_" + name)(P(a[i]), P(b[i]), P(out))
+            assert (ol.arr32(getattr(o, "lfo_p256_" + name)(ol.e32(a[i]), ol.e32(b[i]))) == out).all(), (name, i)
+    wr, wi, xr, xi = (np.zeros(4, dtype=np.uint64) for _ in range(4))
+    r.ref_p256_omega(P(wr), P(wi))
+    o.lfo_p256_omega(P(xr), P(xi))
+    assert (wr == xr).all() and (wi == xi).all()
+    for n in (2, 4, 8, 16, 32, 64, 128, 1024, 2048):
+        x = fill(20 + n, n)
+        y = x.copy()
+        r.ref_p256_rfft(0, n, P(x))
+        o.lfo_p256_r2hc(P(y), n)
+        assert (x == y).all(), ("r2hc", n)
+        r.ref_p256_rfft(1, n, P(x))
+        o.lfo_p256_hc2r(P(y), n)
+        assert (x == y).all(), ("hc2r", n)
+    for n, m in ((1, 2), (1, 4), (2, 3), (3, 8), (5, 16), (21, 128), (100, 257), (455, 4096), (909, 4096)):
+        x = fill(40 + n, m)
+        y = x.copy()
+        r.ref_p256_rs_interpolate(n, m, P(x))
+        o.lfo_p256_rs_interpolate(n, m, P(y))
+        assert (x == y).all(), ("rs", n, m)
+    T = fill(77, 7 * 40).reshape(7, 40, 4)
+    nz = rng.integers(0, 256, size=(31, 32), dtype=np.uint8)
+    r1, r2 = np.zeros(32, dtype=np.uint8), np.zeros(32, dtype=np.uint8)
+    r.ref_p256_column_commit(7, 40, 9, 31, P(T), P(nz), P(r1))
+    o.lfo_column_commit32(7, 40, 9, 31, P(T), P(nz), P(r2), None)
+    assert (r1 == r2).all()
