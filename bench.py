@@ -97,6 +97,100 @@ def ligero_commit_shape(gpu, torch, np, stream, with_cpu):
     return res
 
 
+def ligero_commit_slig(gpu, torch, np, A, rows, logn):
+    """SURVEY 8(d) row 3, the synthetic Ligero shape large enough for an HBM roofline: LigeroParam(nw, nq = 0,
+    rateinv = 4, nreq = 132, block_enc = 2^20) over GF2_128<5> (lib/ligero/ligero_param.h:185-243) => block = 174 762,
+    dblock = 349 523, block_ext = 699 053 leaves; nrow = 1024 rows resident in HBM (the batch buffer A: its first
+    `block` columns are the message).  Timed: K3 (RS-extend every row 174 762 -> 2^20) and K5 + K6 (column hash of the
+    699 053 x 1024 x 16 B columns + tree).  Checked against the oracle on a sample: two whole rows of the RS extension,
+    64 leaves, and the whole tree rebuilt from the device's leaves."""
+    import ctypes as C
+    import oracle_lib as ol
+    be = 1 << logn
+    block = (be + 1) // 6
+    dblock = 2 * block - 1
+    ext = be - dblock
+    o = ol.oracle()
+    ctx5 = ol.gf_ctx(5)
+    msg = [A[r * be:r * be + block].cpu().numpy().view(np.uint64).copy() for r in (0, rows - 1)]
+    stream = torch.cuda.current_stream()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    nonces = torch.randint(0, 256, (ext, 32), dtype=torch.uint8, device="cuda")
+    layers = torch.zeros(2 * ext * 32, dtype=torch.uint8, device="cuda")
+    # warm (tables, plans), then timed; the encode is idempotent on the message columns
+    gpu.gf2128_rs_encode_rows(A.data_ptr(), rows, block, be, subfield_log_bits=5)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    gpu.gf2128_rs_encode_rows(A.data_ptr(), rows, block, be, subfield_log_bits=5)
+    e1.record(stream)
+    root = gpu.column_commit(4, rows, be, dblock, ext, A.data_ptr(), nonces.data_ptr(), layers.data_ptr())
+    e2.record(stream)
+    torch.cuda.synchronize()
+    rs_ms, hash_ms = e0.elapsed_time(e1), e1.elapsed_time(e2)
+    ok_rs = True
+    for r, m0 in zip((0, rows - 1), msg):
+        want = np.zeros((be, 2), dtype=np.uint64)
+        want[:block] = m0
+        o.lfo_lch14_rs_interpolate(C.byref(ctx5), block, be, ol.P(want))
+        ok_rs = ok_rs and bool((A[r * be:(r + 1) * be].cpu().numpy().view(np.uint64) == want).all())
+    # leaves of 64 sampled columns from a host copy of those columns; the tree from the device's leaves
+    c0 = 12345
+    cols = A.view(rows, be, 2)[:, dblock + c0:dblock + c0 + 64, :].contiguous().cpu().numpy().view(np.uint64)
+    nz = nonces[c0:c0 + 64].cpu().numpy()
+    want_leaves = np.zeros((64, 32), dtype=np.uint8)
+    o.lfo_column_leaves(4, rows, 64, 0, 64, ol.P(np.ascontiguousarray(cols)), ol.P(np.ascontiguousarray(nz)), ol.P(want_leaves))
+    lay = layers.view(2 * ext, 32).cpu().numpy()
+    ok_leaves = bool((lay[ext + c0:ext + c0 + 64] == want_leaves).all())
+    hl = np.zeros((2 * ext, 32), dtype=np.uint8)
+    o.lfo_merkle_build_tree(ext, ol.P(np.ascontiguousarray(lay[ext:])), ol.P(hl))
+    ok_tree = bool(hl[1].tobytes() == root)
+    rs_bytes = rows * (block + be) * 16.0          # read the message, write the codeword (SURVEY 8d)
+    hash_bytes = rows * ext * 16.0 + ext * 32.0    # read the columns, write the leaves
+    return {"shape": "LigeroParam(nw, 0, 4, 132, 2^%d), GF2_128<5>: %d rows, block %d, dblock %d, %d leaves" % (logn, rows, block, dblock, ext),
+            "rs_encode_ms": rs_ms, "rs_algo_GBps": rs_bytes / rs_ms / 1e6, "rs_frac_of_hbm": rs_bytes / rs_ms / 1e6 / HBM_PEAK_GBS,
+            "column_commit_ms": hash_ms, "hash_algo_GBps": hash_bytes / hash_ms / 1e6, "hash_frac_of_hbm": hash_bytes / hash_ms / 1e6 / HBM_PEAK_GBS,
+            "sha256_compressions": ext * ((32 + 16 * rows + 9 + 63) // 64) + ext - 1,
+            "checked_vs_oracle": {"rs_rows_0_and_last": ok_rs, "leaves_64_sampled_columns": ok_leaves, "tree_from_device_leaves": ok_tree}}
+
+
+def ligero_commit_sharded(pkg, gpu, torch, np, dist, rank, world):
+    """SURVEY 8(e): LigeroProver::commit with the tableau rows sharded over the ranks (longfellow-zk_amd/parallel.py:
+    host layout replayed from one RandomEngine stream, row-slab RS encode, all_to_all column re-partition over RCCL,
+    local column hash, all_gather of the leaf digests, tree on every rank).  Statement: GF2_128<4>,
+    LigeroParam(nw, 0, 4, 132, 2^15) with nrow = 1024 (block 5461, block_ext 21 847; 512 MiB tableau).  Reports the wall
+    time of commit and whether every rank derived the same root."""
+    import importlib
+    import time as _t
+    par = importlib.import_module("longfellow_zk_amd.parallel")
+    be = 1 << 15
+    p0 = pkg.ligero_param(pkg.FIELD_GF2_128, 1, 0, 4, 132, be)
+    nw = p0.w * 1021
+    p = pkg.ligero_param(pkg.FIELD_GF2_128, nw, 0, 4, 132, be)
+    W = np.random.default_rng(7).integers(0, 2**63, size=(nw, 2), dtype=np.int64).view(np.uint64)
+    eng = par.GpuEngine(gpu, pkg.FIELD_GF2_128, 4, torch.device("cuda", torch.cuda.current_device()))
+    rng_t = pkg.FsTranscript(b"bench-sharded-commit")
+    times, roots = [], []
+    for rep in range(3):
+        pr = par.ShardedLigeroProver(eng, gpu.L, pkg.FIELD_GF2_128, p, 4, None)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = _t.perf_counter()
+        root = pr.commit(W, 0, [], rng_t.bytes)
+        torch.cuda.synchronize()
+        dist.barrier()
+        times.append((_t.perf_counter() - t0) * 1e3)
+        roots.append(root)
+        pr.close()
+    rng_t.close()
+    mine = torch.tensor(list(roots[-1]), dtype=torch.uint8, device="cuda")
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    same = all(bool((t == allr[0]).all()) for t in allr)
+    return {"shape": "GF2_128<4>, %d rows x 2^15, block %d, %d leaves, rows sharded x%d" % (p.nrow, p.block, p.block_ext, world),
+            "commit_wall_ms": min(times), "all_ranks_same_root": same,
+            "includes": "host layout replay + upload of the slab + RS encode + all_to_all + column hash + all_gather + tree"}
+
+
 def zk_prove_flatsha(pkg, gpu, np, nb, with_cpu, reps=3):
     """BASELINE's first metric, "flatsha256 fp2_128 prove ms" (BM_ShaZK_fp2_128, lib/circuits/sha/
     flatsha256_circuit_test.cc:510-536: ZkProver commit + prove, rate 7, 132 queries): the library's C++ ZK driver
@@ -174,6 +268,7 @@ def main():
     ap.add_argument("--logn", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: rehearses the N > 1 code path on a 1-GPU box")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -190,6 +285,10 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
 
+    # libraries chat on stdout (RCCL prints a version banner at init): keep fd 1 for the ONE JSON line, send the rest to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -199,9 +298,10 @@ def main():
     if world != args.gpus and rank == 0:
         print("bench: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d (the ranks that exist)" % (args.gpus, world, world), file=sys.stderr)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
@@ -312,18 +412,30 @@ def main():
         e1.record(stream)
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / s2
-        out["gf2128_lch14_fft"] = {"field_elems_per_s": nelem / (ms * 1e-3), "ms_per_step": ms,
-                                   "algo_GBps": 2.0 * nelem * 16 / (ms * 1e-3) / 1e9}
+        agb = 2.0 * nelem * 16 / (ms * 1e-3) / 1e9
+        out["gf2128_lch14_fft"] = {"field_elems_per_s": nelem / (ms * 1e-3), "ms_per_step": ms, "algo_GBps": agb,
+                                   "roofline": {"bound": "hbm", "achieved": agb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agb / HBM_PEAK_GBS,
+                                                "note": "whole transform = bs_cin + bs_bfly passes + bs_cout; per-kernel HBM bytes (PMC) in profiles/r02/pmc_bs_kernels.json"}}
+    if rank == 0 and not args.no_secondary and logn == 20 and rows == 1024:
+        out["ligero_commit_slig"] = ligero_commit_slig(gpu, torch, np, A, rows, logn)
     if rank == 0 and not args.no_secondary:
         out["ligero_commit_flatsha32"] = ligero_commit_shape(gpu, torch, np, stream, not args.no_cpu_baseline)
         del A  # the ZK path allocates its own buffers
         out["zk_prove_flatsha256"] = zk_prove_flatsha(pkg, gpu, np, 32, not args.no_cpu_baseline)
+    if dist is not None and not args.no_secondary:
+        try:  # the sharded Ligero commit over RCCL (every rank takes part); a failure here must not cost the headline line
+            sh = ligero_commit_sharded(pkg, gpu, torch, np, dist, rank, world)
+        except Exception as e:  # noqa: BLE001
+            sh = {"error": repr(e)[:300]}
+        if rank == 0:
+            out["ligero_commit_sharded"] = sh
     if dist is not None:
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(logn)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     gpu.close()
     if dist is not None:
         dist.destroy_process_group()

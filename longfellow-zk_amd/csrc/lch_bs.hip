@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256, 2) void bs_bfly_kernel(BflyArgs a) {
 #pragma unroll
   for (u32 b = 0; b < BS_NB_MAX; ++b) {
     twv[b] = 0;
-    if (b < a.nb) twv[b] = a.tw[a.off[b] + ((tc_hi << (a.nb - 1 - b)) | ((tid >> RL) >> b))];
+    // threads beyond the R << (nb - 1) butterflies of a stage hold no pair: clamp their pair index, or a short last group
+    // (nb < 4) reads past the end of the stage table (a fault at l = 17, 18 where the table ends on a page boundary)
+    if (b < a.nb) twv[b] = a.tw[a.off[b] + ((tc_hi << (a.nb - 1 - b)) | (((tid >> RL) & ((1u << (a.nb - 1)) - 1u)) >> b))];
   }
   __syncthreads();
   const u32 ntask = R << (a.nb - 1);

@@ -118,47 +118,44 @@ __global__ __launch_bounds__(RS_THREADS) void gf_rs_rows_kernel(RsPlan p1, RsPla
   }
 }
 
-// ---- rows larger than LDS (2^l > 4096): the same op list, one launch per op over all rows, coefficients in a
-// device work buffer Cc[row][2^l]; the further cosets go through the batched LCH14 FFT (bit-sliced for >= 32 rows).
+// ---- rows larger than LDS (2^l > 4096): coefficients in a device work buffer Cc[row][2^l].  The recursion of
+// bidir_recur is unrolled on the host into (a) whole FFT / IFFT blocks, which run through the batched LCH14 transform
+// (bit-sliced for >= 32 rows: a handful of passes each instead of one global sweep per butterfly stage), and (b) the
+// partial butterfly ranges between them (one elementwise launch each); the further cosets are transformed in place in the
+// rows where they fit.
 __global__ __launch_bounds__(256) void gf_rs_big_load_kernel(u32 n, u32 fftn, const elt_t* __restrict__ T, size_t ld, elt_t* __restrict__ Cc) {
   const u32 i = blockIdx.x * 256 + threadIdx.x;
   if (i >= fftn) return;
   const size_t r = blockIdx.y;
   st16(&Cc[r * fftn + i], i < n ? ld16(&T[r * ld + i]) : elt_zero());
 }
-__global__ __launch_bounds__(256) void gf_rs_big_op_kernel(RsOp op, const elt_t* __restrict__ twp, u32 fftn, elt_t* __restrict__ Cc) {
+// butterflies uv in [lo, hi) of one level: kind OP_FWD / OP_BWD / OP_DIAG (lch14.h:219-237)
+__global__ __launch_bounds__(256) void gf_rs_big_range_kernel(u32 kind, u32 s, u32 base, u32 lo, u32 hi, elt_t tw, u32 fftn, elt_t* __restrict__ Cc) {
   elt_t* B = Cc + (size_t)blockIdx.y * fftn;
-  const u32 t = blockIdx.x * 256 + threadIdx.x;
-  const u32 s = 1u << op.i;
-  u32 i0, i1;
-  elt_t tw;
-  if (op.kind <= OP_DIAG) {
-    const u32 uv = op.lo + t;
-    if (uv >= op.hi) return;
-    i0 = op.base + uv;
-    i1 = i0 + s;
-    tw = ld16(&twp[op.tw]);
-  } else {
-    if (t >= (1u << (op.lo - 1))) return;
-    const u32 v = t & (s - 1), u = t >> op.i;
-    i0 = op.base + (u << (op.i + 1)) + v;
-    i1 = i0 + s;
-    tw = ld16(&twp[op.tw + u]);
-  }
+  const u32 uv = lo + blockIdx.x * 256 + threadIdx.x;
+  if (uv >= hi) return;
+  const u32 i0 = base + uv, i1 = i0 + s;
   elt_t b0 = ld16(&B[i0]), b1 = ld16(&B[i1]);
-  if (op.kind == OP_FWD || op.kind == OP_FFT_STAGE) {  // lch14.h:219-223
+  if (kind == OP_FWD) {
     b0 = gf_add(b0, gf_mul(tw, b1));
     b1 = gf_add(b1, b0);
-  } else if (op.kind == OP_BWD || op.kind == OP_IFFT_STAGE) {  // :225-229
+  } else if (kind == OP_BWD) {
     b1 = gf_add(b1, b0);
     b0 = gf_add(b0, gf_mul(tw, b1));
-  } else {  // diag :232-237
+  } else {
     const elt_t x = b1;
     b1 = gf_add(b1, b0);
     b0 = gf_add(b0, gf_mul(tw, x));
   }
   st16(&B[i0], b0);
   st16(&B[i1], b1);
+}
+// dst[r][0..w) = src[r][0..w) (a strided copy of 16-byte elements; all index arithmetic in 64 bits)
+__global__ __launch_bounds__(256) void gf_rs_big_copy_kernel(u32 w, const elt_t* __restrict__ src, size_t sld, elt_t* __restrict__ dst, size_t dld) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= w) return;
+  const size_t r = blockIdx.y;
+  st16(&dst[r * dld + i], ld16(&src[r * sld + i]));
 }
 // evaluations n..top of the first coset out to the rows; coefficients n..fftn back to zero
 __global__ __launch_bounds__(256) void gf_rs_big_store_kernel(u32 n, u32 top, u32 fftn, elt_t* __restrict__ T, size_t ld, elt_t* __restrict__ Cc) {
@@ -247,50 +244,74 @@ static int gf_rs_plan(lfgpu_ctx* c, const GfHostCtx* g, int k, size_t n, size_t 
 
 extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx*, int, int, size_t, unsigned, uint64_t, void*, size_t);
 
+enum { BIG_FFT = 10, BIG_IFFT = 11 };
+struct BigOp {
+  u32 kind;    // OP_FWD / OP_BWD / OP_DIAG: butterflies uv in [lo, hi) at level i;  BIG_FFT / BIG_IFFT: a whole block of 2^i points
+  u32 i, base, lo, hi;
+  u64 coset;
+  elt_t tw;
+};
+// bidir_recur (lch14.h:185-217) unrolled with its FFT / IFFT calls kept whole
+static void big_bidir(const GfHostCtx* g, std::vector<BigOp>& ops, unsigned i, u64 coset, u32 k, u32 base) {
+  if (i-- > 0) {
+    const u32 s = 1u << i;
+    const elt_t t = h_lch14_twiddle(g, i, coset);
+    if (k < s) {
+      ops.push_back(BigOp{OP_FWD, i, base, k, s, coset, t});
+      big_bidir(g, ops, i, coset, k, base);
+      if (k > 0) ops.push_back(BigOp{OP_DIAG, i, base, 0, k, coset, t});
+      if (i > 0) ops.push_back(BigOp{BIG_FFT, i, base + s, 0, 0, coset + s, t});
+    } else {
+      if (i > 0) ops.push_back(BigOp{BIG_IFFT, i, base, 0, 0, coset, t});
+      if (k - s < s) ops.push_back(BigOp{OP_DIAG, i, base, k - s, s, coset, t});
+      big_bidir(g, ops, i, coset + s, k - s, base + s);
+      if (k - s > 0) ops.push_back(BigOp{OP_BWD, i, base, 0, k - s, coset, t});
+    }
+  }
+}
+
 static int gf_rs_rows_big(lfgpu_ctx* c, const GfHostCtx* g, int k, size_t nrow, size_t n, size_t m, elt_t* T, size_t ld, unsigned l) {
   if ((size_t)1 << g->sub_bits < ((size_t)1 << l)) return lf_fail(c, LFGPU_ERR_ARG, "gf2128_rs_encode_rows: 2^l exceeds the subfield of GF2_128<%d>", k);
   const u32 fftn = 1u << l;
-  // op list + twiddles of the bidirectional transform (host copy: one launch per op)
   char kb[96];
-  snprintf(kb, sizeof(kb), "rsbig:%d:%zu", k, n);
+  snprintf(kb, sizeof(kb), "rsbig2:%d:%zu", k, n);
   const std::string key(kb);
-  void* dtw = nullptr;
   auto it = c->blobs.find(key);
   if (it == c->blobs.end()) {
-    PlanBuilder pb{g, {}, {}};
-    pb.bidir(l, 0, (u32)n, 0);
-    if (pb.tw.empty()) pb.tw.push_back(elt_t{0, 0});
-    LF_TRY(lf_table(c, key + ":tw", pb.tw.data(), pb.tw.size() * 16, &dtw));
-    c->blobs[key] = std::string((const char*)pb.ops.data(), pb.ops.size() * sizeof(RsOp));
+    std::vector<BigOp> ops;
+    big_bidir(g, ops, l, 0, (u32)n, 0);
+    c->blobs[key] = std::string((const char*)ops.data(), ops.size() * sizeof(BigOp));
     it = c->blobs.find(key);
-  } else if (!lf_table_lookup(c, key + ":tw", &dtw)) {
-    return lf_fail(c, LFGPU_ERR_ASSERT, "gf2128_rs_encode_rows: plan cache");
   }
-  const RsOp* ops = (const RsOp*)it->second.data();
-  const size_t nops = it->second.size() / sizeof(RsOp);
-  u32 ncoset = 1;
-  while (((size_t)ncoset << l) < m) ++ncoset;
+  const size_t nops = it->second.size() / sizeof(BigOp);
+  std::vector<BigOp> ops(nops);  // copy out: the FFT calls below may insert into c->blobs
+  memcpy(ops.data(), it->second.data(), nops * sizeof(BigOp));
   void* sc = nullptr;
-  LF_TRY(lf_scratch2(c, (ncoset > 1 ? 2 : 1) * nrow * fftn * 16, &sc));  // scratch2: the batched FFT below takes `scratch`
+  LF_TRY(lf_scratch2(c, nrow * fftn * 16, &sc));  // scratch2: the batched FFT takes `scratch`
   elt_t* Cc = (elt_t*)sc;
-  elt_t* Wk = Cc + nrow * fftn;
-  const dim3 gfull((fftn + 255) / 256, (u32)nrow);
-  hipLaunchKernelGGL(gf_rs_big_load_kernel, gfull, dim3(256), 0, c->stream, (u32)n, fftn, (const elt_t*)T, ld, Cc);
-  for (size_t o = 0; o < nops; ++o) {
-    const RsOp op = ops[o];
-    const u32 work = op.kind <= OP_DIAG ? (op.hi > op.lo ? op.hi - op.lo : 0) : (1u << (op.lo - 1));
-    if (!work) continue;
-    hipLaunchKernelGGL(gf_rs_big_op_kernel, dim3((work + 255) / 256, (u32)nrow), dim3(256), 0, c->stream, op, (const elt_t*)dtw, fftn, Cc);
+  hipLaunchKernelGGL(gf_rs_big_load_kernel, dim3((fftn + 255) / 256, (u32)nrow), dim3(256), 0, c->stream, (u32)n, fftn, (const elt_t*)T, ld, Cc);
+  for (const BigOp& op : ops) {
+    if (op.kind == BIG_FFT || op.kind == BIG_IFFT) {
+      LF_TRY(lfgpu_gf2128_lch14_fft(c, k, op.kind == BIG_IFFT ? 1 : 0, nrow, op.i, op.coset, Cc + op.base, fftn));
+    } else if (op.hi > op.lo) {
+      hipLaunchKernelGGL(gf_rs_big_range_kernel, dim3((op.hi - op.lo + 255) / 256, (u32)nrow), dim3(256), 0, c->stream, op.kind, 1u << op.i, op.base,
+                         op.lo, op.hi, op.tw, fftn, Cc);
+    }
   }
   const u32 top = m < fftn ? (u32)m : fftn;
   if (n < fftn)
     hipLaunchKernelGGL(gf_rs_big_store_kernel, dim3((fftn - (u32)n + 255) / 256, (u32)nrow), dim3(256), 0, c->stream, (u32)n, top, fftn, T, ld, Cc);
   LF_HIP(c, hipGetLastError());
-  for (u32 cs = 1; cs < ncoset; ++cs) {  // further cosets: FFT of the coefficients with coset offset cs * 2^l
-    LF_HIP(c, hipMemcpyAsync(Wk, Cc, nrow * fftn * 16, hipMemcpyDeviceToDevice, c->stream));
-    LF_TRY(lfgpu_gf2128_lch14_fft(c, k, 0, nrow, l, (uint64_t)cs << l, Wk, fftn));
-    const size_t base = (size_t)cs << l, width = (m - base < fftn ? m - base : fftn);
-    LF_HIP(c, hipMemcpy2DAsync(T + base, ld * 16, Wk, (size_t)fftn * 16, width * 16, nrow, hipMemcpyDeviceToDevice, c->stream));
+  for (size_t base = fftn; base < m; base += fftn) {  // further cosets: FFT of the coefficients with coset offset `base`
+    if (base + fftn <= m) {  // fits: copy the coefficients into the row and transform in place (lch14_reed_solomon.h:84-90)
+      hipLaunchKernelGGL(gf_rs_big_copy_kernel, dim3((fftn + 255) / 256, (u32)nrow), dim3(256), 0, c->stream, fftn, (const elt_t*)Cc, (size_t)fftn, T + base, ld);
+      LF_TRY(lfgpu_gf2128_lch14_fft(c, k, 0, nrow, l, (uint64_t)base, T + base, ld));
+    } else {  // partial fit, last coset: transform the work buffer and copy what fits (:91-98)
+      LF_TRY(lfgpu_gf2128_lch14_fft(c, k, 0, nrow, l, (uint64_t)base, Cc, fftn));
+      hipLaunchKernelGGL(gf_rs_big_copy_kernel, dim3((u32)((m - base + 255) / 256), (u32)nrow), dim3(256), 0, c->stream, (u32)(m - base), (const elt_t*)Cc,
+                         (size_t)fftn, T + base, ld);
+      LF_HIP(c, hipGetLastError());
+    }
   }
   return LFGPU_OK;
 }

@@ -44,6 +44,28 @@ def main():
             print(info)
 
 
+def light(blocks):
+    """the other block counts of BM_ShaZK_fp2_128 (docs/content/en/docs/benchmarks.md:55-61; 33 = ragged, non-power-of-two
+    witness): circuit + witness + the reference's commitment root and the length / SHA-256 of its wire bytes only"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/gen_flatsha"])
+    for nb in blocks:
+        with tempfile.TemporaryDirectory() as td:
+            pre = os.path.join(td, "x")
+            info = json.loads(subprocess.check_output([GEN, str(nb), pre]).decode())
+            for ext in (".lfc1", ".w"):
+                data = open(pre + ext, "rb").read()
+                dst = os.path.join(OUT, "flatsha_nb%d%s.xz" % (nb, ext))
+                with open(dst, "wb") as f:
+                    f.write(lzma.compress(data, preset=9 | lzma.PRESET_EXTREME))
+                print(dst, os.path.getsize(dst))
+            wire = open(pre + ".zkwire", "rb").read()
+            info.update(zk_wire_bytes=len(wire), zk_wire_sha256=hashlib.sha256(wire).hexdigest(),
+                        zk_root=open(pre + ".zkproof", "rb").read()[:32].hex())
+            with open(os.path.join(OUT, "flatsha_nb%d.json" % nb), "w") as f:
+                json.dump(info, f)
+            print(info)
+
+
 def variant(nb=1, npub=9, sfb=777):
     """same circuit with the first `npub` inputs declared public and inputs below `sfb` declared subfield (what the
     mdoc hash circuit does): only sizes and hashes are stored -- the LFC1 bytes are the nb fixture with two header
@@ -85,5 +107,7 @@ if __name__ == "__main__":
         fp128()
     elif sys.argv[1:2] == ["variant"]:
         variant()
+    elif sys.argv[1:2] == ["light"]:
+        light([int(a) for a in sys.argv[2:]] or [2, 4, 8, 16, 33])
     else:
         main()

@@ -147,21 +147,24 @@ def test_lch14_fft_bitsliced_batches(G, k, l, coset, rows, inverse):
     assert (G.from_dev(d, np.uint64, a.shape) == want).all()
 
 
-def test_lch14_fft_bitsliced_full_size_rows(G):
-    """l = 20 (GF2_128<5>), 32 rows: row 0 and row 31 against the oracle, then IFFT round trip"""
+@pytest.mark.parametrize("l,coset", [(20, 0), (17, 1 << 17), (18, 0), (19, 5 << 19), (15, 0), (16, 3 << 16)])
+def test_lch14_fft_bitsliced_full_size_rows(G, l, coset):
+    """l = 15 .. 20 (GF2_128<5>), 32 rows: row 0 and row 31 against the oracle, then IFFT round trip.  l = 17, 18, 19 end
+    with a SHORT last butterfly group (1, 2, 3 index bits): the sizes the truncated transform of big Reed-Solomon rows
+    calls (a stage-table read past the table's end faulted there at l = 17, 18)."""
     o = ol.oracle()
     c = ol.gf_ctx(5)
-    rng = np.random.default_rng(2020)
-    rows, l = 32, 20
+    rng = np.random.default_rng(2000 + l)
+    rows = 32
     a = ol.rand_elts(rng, rows << l).reshape(rows, 1 << l, 2)
     d = G.to_dev(a)
-    G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, subfield_log_bits=5)
+    G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, coset=coset, subfield_log_bits=5)
     got = G.from_dev(d, np.uint64, a.shape).copy()
     for r in (0, 31):
         w = a[r].copy()
-        o.lfo_lch14_fft(C.byref(c), l, 0, P(w))
+        o.lfo_lch14_fft(C.byref(c), l, coset, P(w))
         assert (got[r] == w).all()
-    G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, inverse=True, subfield_log_bits=5)
+    G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, coset=coset, inverse=True, subfield_log_bits=5)
     assert (G.from_dev(d, np.uint64, a.shape) == a).all()
 
 
@@ -185,7 +188,11 @@ def test_lch14_fft_roundtrip_full_size(G):
                                         (4, 1819, 8192, 2), (4, 682, 4096, 8), (4, 461, 4151, 3), (5, 1000, 5000, 2),
                                         # rows larger than LDS (2^l > 4096): global-memory op sweeps + batched coset FFTs
                                         (4, 4097, 8192, 2), (4, 5000, 20000, 3), (4, 7279, 32768, 40), (5, 9000, 70000, 2),
-                                        (4, 8192, 8192 + 5, 1), (4, 16384, 65536, 33)])
+                                        (4, 8192, 8192 + 5, 1), (4, 16384, 65536, 33),
+                                        # the S-lig shape (LigeroParam(nw, 0, 4, 132, 2^20) over GF2_128<5>) scaled by 1/4: block 43690, all cosets fit
+                                        (5, 43690, 262144, 36),
+                                        # block transforms of 2^17 points and short last butterfly groups inside the truncated transform
+                                        (5, 174762, 1 << 20, 32)])
 def test_gf2128_rs_encode_rows(G, k, n, m, nrow):
     o = ol.oracle()
     rng = np.random.default_rng(n * 3 + m)

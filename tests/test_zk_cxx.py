@@ -407,3 +407,31 @@ def test_zk_prove_verify_with_explicit_large_block_enc(fp, block_enc):
     assert G.pkg.zk_verify(gpu, circ, bytes(bad), pub, tv, 7, 132, block_enc)[0] is False
     tv.close()
     circ.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb", [2, 4, 8, 16, 33])
+def test_zk_cxx_driver_wire_bytes_other_block_counts(nb):
+    """the remaining sizes of BM_ShaZK_fp2_128 (reference docs/content/en/docs/benchmarks.md:55-61); 33 blocks is the
+    reference's ragged case (witness and layer widths are not powers of two).  Fixtures: circuit + witness + the
+    reference's commitment root and the length / SHA-256 of its ZkProof::write bytes (oracle/gen_flatsha_fixtures.py light)"""
+    import gpu_util as G
+    import ligero_fixture as lf
+    raw, W, info = _load(nb)
+    gpu = G.gpu()
+    circ = G.pkg.Circuit(gpu, raw)
+    assert (circ.info.nl, circ.info.ninputs, circ.info.nterms) == (info["nl"], info["ninputs"], info["nterms"])
+    zk = G.pkg.ZkProver(gpu, circ, 7, 132)
+    assert (zk.param.block_enc, zk.param.nrow, zk.param.nw) == (info["zk_block_enc"], info["zk_nrow"], info["zk_nw"])
+    ts = G.pkg.FsTranscript(b"test")
+    root = zk.commit(W, lf.LcgRng(100).bytes, ts)
+    assert root.hex() == info["zk_root"]
+    assert zk.prove(W, ts)
+    wire = zk.wire()
+    ts.close()
+    assert len(wire) == info["zk_wire_bytes"] and hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"]
+    tv = G.pkg.FsTranscript(b"test")
+    assert G.pkg.zk_verify(gpu, circ, wire, W[:circ.info.npub_in], tv) == (True, "ok")
+    tv.close()
+    zk.close()
+    circ.close()
