@@ -75,14 +75,11 @@ elt_t h_gf_inv(elt_t a) {  // a^(2^128-2)
   return r;
 }
 static elt_t h_fp_rsq() {
-  static bool init = false;
-  static elt_t rsq;
-  if (!init) {
+  static const elt_t rsq = [] {  // thread-safe one-time initialisation (C++11)
     elt_t r{1, 0};
     for (int i = 0; i < 256; ++i) r = fp_add(r, r);
-    rsq = r;
-    init = true;
-  }
+    return r;
+  }();
   return rsq;
 }
 elt_t h_fp_of_scalar(u64 u) { return fp_mul(elt_t{u, 0}, h_fp_rsq()); }

@@ -138,15 +138,12 @@ struct Sampler {
       memcpy(&e.lo, b, 8);
       memcpy(&e.hi, b + 8, 8);
       if (e.hi < FP_P_HI || (e.hi == FP_P_HI && e.lo < FP_P_LO)) {
-        // to_montgomery = mul by R^2 (fp_generic.h:278-282)
-        static elt_t rsq{0, 0};
-        static bool init = false;
-        if (!init) {
+        // to_montgomery = mul by R^2 (fp_generic.h:278-282); C++11 initialises a function-local static once, thread-safely
+        static const elt_t rsq = [] {
           elt_t r{1, 0};
           for (int i = 0; i < 256; ++i) r = fp_add(r, r);
-          rsq = r;
-          init = true;
-        }
+          return r;
+        }();
         return fp_mul(e, rsq);
       }
     }
@@ -384,6 +381,9 @@ extern "C" int lfgpu_ligero_free(lfgpu_ligero_prover* pr) {
   // so work still queued on them finishes before anything a later commit enqueues
   auto stash = [&](void* p, size_t bytes, void** slot, size_t* slot_bytes) {
     if (!p) return;
+    // the tableau holds the witness, the pads and the blinding rows: scrub it before it outlives its prover (enqueued on the
+    // stream, in order behind the prover's last kernels)
+    if (bytes) (void)hipMemsetAsync(p, 0, bytes, c ? c->stream : nullptr);
     if (c && bytes) {
       if (*slot) (void)hipFree(*slot);
       *slot = p;

@@ -29,6 +29,7 @@ struct lfgpu_quad {
   lfgpu_ctx* c;
   int field;
   size_t n, nk, nv;
+  size_t hmax;        // largest hand index (h0 or h1) of any corner: every consumer needs nw > hmax
   corner4* d_morton;  // canonical order
   corner4* d_bygate;  // sorted by g (stable)
   u32* d_goff;        // nv + 1 offsets into d_bygate
@@ -272,8 +273,10 @@ extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32
   LF_HIP(c, hipSetDevice(c->device));
   std::vector<corner4> mort(n), byg(n);
   std::vector<u32> goff(nv + 1, 0);
+  size_t hmax = 0;
   for (size_t i = 0; i < n; ++i) {
     if (g[i] >= nv || vi[i] >= nk) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: corner %zu out of range", i);
+    hmax = std::max<size_t>(hmax, std::max(h0[i], h1[i]));
     mort[i] = corner4{g[i], h0[i], h1[i], vi[i]};
     goff[g[i] + 1]++;
   }
@@ -288,6 +291,7 @@ extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32
   q->n = n;
   q->nk = nk;
   q->nv = nv;
+  q->hmax = hmax;
   q->d_morton = q->d_bygate = nullptr;
   q->d_goff = nullptr;
   q->d_kvec = nullptr;
@@ -336,7 +340,7 @@ int lf_eval_quad_async(lfgpu_quad* q, const void* d_W, void* d_V, int* d_fail) {
 extern "C" int lfgpu_eval_quad(lfgpu_quad* q, size_t nw, const void* d_W, void* d_V, int* ok_out) {
   if (!q || !d_W || !d_V || !ok_out) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = q->c;
-  (void)nw;
+  if (nw <= q->hmax) return lf_fail(c, LFGPU_ERR_ARG, "eval_quad: nw = %zu but a corner reads wire %zu", nw, q->hmax);
   LF_HIP(c, hipSetDevice(c->device));
   int* d_fail = (int*)((uint8_t*)c->mailbox_d + 128);
   LF_HIP(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
@@ -477,8 +481,8 @@ int lf_quad_bind_gh_all_enqueue(lfgpu_quad* q, size_t logv, const void* h_G0, co
                                 const uint64_t beta[2], size_t logw, size_t nw, const void* h_H0, const void* h_H1, u64* d_acc) {
   if (!q || !alpha || !beta || !d_acc || (logv && (!h_G0 || !h_G1)) || (logw && (!h_H0 || !h_H1))) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = q->c;
-  if (logv > 40 || logw > 40 || ((size_t)1 << logv) < q->nv || nw == 0 || ((size_t)1 << logw) < nw)
-    return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_gh_all: table sizes");
+  if (logv > 40 || logw > 40 || ((size_t)1 << logv) < q->nv || nw == 0 || ((size_t)1 << logw) < nw || nw <= q->hmax)
+    return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_gh_all: table sizes (nw must exceed the largest hand index %zu)", q->hmax);
   LF_HIP(c, hipSetDevice(c->device));
   const int field = q->field;
   void* sc = nullptr;
@@ -538,8 +542,8 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
                                     const uint64_t beta[2], size_t logw, size_t nw, void* d_W, const uint64_t wc_in[2][2],
                                     lfgpu_sc_round_fn round, void* user, uint64_t wc_out[2][2], uint64_t* g_out,
                                     uint64_t bound_quad[2]) {
-  if (!q || !alpha || !beta || !d_W || !wc_in || !round || !wc_out || !g_out || nw == 0 || logw > 40 || nw > ((size_t)1 << logw))
-    return q ? lf_fail(q->c, LFGPU_ERR_ARG, "sumcheck_layer: bad argument") : LFGPU_ERR_ARG;
+  if (!q || !alpha || !beta || !d_W || !wc_in || !round || !wc_out || !g_out || nw == 0 || logw > 40 || nw > ((size_t)1 << logw) || nw <= q->hmax)
+    return q ? lf_fail(q->c, LFGPU_ERR_ARG, "sumcheck_layer: bad argument (nw must exceed the largest hand index)") : LFGPU_ERR_ARG;
   lfgpu_ctx* c = q->c;
   const int field = q->field;
   LF_HIP(c, hipSetDevice(c->device));

@@ -246,7 +246,9 @@ extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t le
     return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "LFC1: field id %zu (the ZK driver handles GF2_128 = 4 and Fp128 = 6)", fid);
   const int field = (int)fid;
   if (nc != 1) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "LFC1: nc = %zu copies (logc must be 0)", nc);
-  if (npub > nin || nv == 0 || nl == 0) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: inconsistent header");
+  // CircuitReader::read_header's sanity checks (lib/proto/circuit_reader.h:104-110): an oversized subfield_boundary would
+  // mark every witness row subfield-only, including the rows that hold the full-field sumcheck pads
+  if (npub > nin || sfb > nin || nv == 0 || nl == 0 || nl > 10000 /* CircuitIO::kMaxLayers */) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: inconsistent header");
   if (!need(16 * nk)) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated constant table");
   std::vector<elt_t> kvec(nk ? nk : 1);
   for (size_t i = 0; i < nk; ++i)  // of_bytes_field: 16 little-endian bytes (Fp128: canonical value -> Montgomery)
@@ -259,7 +261,8 @@ extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t le
   for (size_t ly = 0; ly < nl; ++ly) {
     size_t logw, nw, nq;
     if (!num(&logw) || !num(&nw) || !num(&nq)) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated layer header");
-    if (logw > kMaxBindings || nw == 0 || nw > ((size_t)1 << logw) || !need(12 * nq))
+    // read_layers (circuit_reader.h:161-168): lw in (0, kMaxBindings], 0 < nw, lw <= nw <= 2^lw, nq > 0
+    if (logw > kMaxBindings || logw == 0 || nw == 0 || nw < logw || nw > ((size_t)1 << logw) || nq == 0 || !need(12 * nq))
       return lf_fail(c, LFGPU_ERR_ARG, "LFC1: bad layer %zu", ly);
     g.resize(nq); h0.resize(nq); h1.resize(nq); vi.resize(nq);
     int64_t acc[3] = {0, 0, 0};

@@ -586,6 +586,10 @@ def test_eval_quad_and_bind_g(G, field, logv, logw, nterms, n_assert):
     dV = torch.ones(L["nv"] * 16, dtype=torch.uint8, device="cuda")
     assert q.eval(L["nw"], dW.data_ptr(), dV.data_ptr()) is True
     assert (G.from_dev(dV, np.uint64, (L["nv"], 2)) == want).all()
+    if L["nw"] > 1:  # a caller that passes fewer wires than the corners index gets an argument error, not an out-of-bounds read
+        hmax = int(max(L["h0"].max(), L["h1"].max()))
+        with pytest.raises(G.pkg.LfGpuError):
+            q.eval(hmax, dW.data_ptr(), dV.data_ptr())
     if n_assert:  # a violated assert-zero term is reported, as eval_quad returns false
         W2 = ol.rand_elts(rng, L["nw"], field)
         W2[W2[:, 0] == 0, 0] = 1

@@ -143,7 +143,16 @@ def test_zk_cxx_driver_rejects_bad_witness_and_bad_circuits():
     import ligero_fixture as lf
     raw, W, _ = _load(1)
     gpu = G.gpu()
-    for bad in (raw[:-1], raw[:100], b"\x02" + raw[1:], raw + b"\x00"):
+    # the reference reader's sanity checks (lib/proto/circuit_reader.h:104-110,161-168): subfield_boundary <= ninputs,
+    # 0 < logw, logw <= nw, nq > 0
+    nin = int.from_bytes(raw[16:19], "little")
+    nk = int.from_bytes(raw[22:25], "little")
+    lay0 = 25 + 16 * nk  # first layer header: logw, nw, nq
+    sfb_big = raw[:13] + (nin + 1).to_bytes(3, "little") + raw[16:]
+    logw_zero = raw[:lay0] + (0).to_bytes(3, "little") + raw[lay0 + 3:]
+    nw_small = raw[:lay0] + (9).to_bytes(3, "little") + (8).to_bytes(3, "little") + raw[lay0 + 6:]
+    nq_zero = raw[:lay0 + 6] + (0).to_bytes(3, "little") + raw[lay0 + 9:]
+    for bad in (raw[:-1], raw[:100], b"\x02" + raw[1:], raw + b"\x00", sfb_big, logw_zero, nw_small, nq_zero):
         with pytest.raises(G.pkg.LfGpuError):
             G.pkg.Circuit(gpu, bad)
     circ = G.pkg.Circuit(gpu, raw)
