@@ -62,6 +62,12 @@ struct lfgpu_ctx {
   volatile u64* poll_h = nullptr;
   u64 poll_seq = 0, poll_next = 0;
   int resident_state = 0;  // 0 untested, 1 the resident sumcheck kernel may be used, -1 it may not
+  // per-context (= per-device) launch configuration: nothing below the C ABI is process-global, so one process may hold
+  // contexts on several devices (hipFuncSetAttribute is applied once per context)
+  unsigned attr_done = 0;  // bit 0 FFT tile kernels, 1 RS row kernel, 2 bit-sliced butterflies, 3 sumcheck grid tail
+  int tile_log = 12;       // FFT tile = 2^tile_log elements (LFGPU_TILE_LOG = 12 | 13)
+  unsigned bs_rlog = 5;    // bit-sliced butterfly tile: 2^bs_rlog combos (LFGPU_BS_RLOG = 5..7)
+  int sc_tail_ok = -1;     // the shrinking-grid kernel may use its LDS tail (-1 undecided)
   int num_cu = 256;
   u64 wall_khz = 100000;  // rate of wall_clock64() (hipDeviceAttributeWallClockRate)
 };

@@ -18,7 +18,7 @@ int lf_lch14_fft_bitsliced(lfgpu_ctx* c, int k, int inverse, size_t rows, unsign
 #define TILE_ELTS 8192u  // largest tile (128 KiB)
 // Tile geometry: 2^13 elements / 1024 threads (one workgroup per CU) or 2^12 elements / 512 threads
 // (two workgroups per CU, so one workgroup's HBM phase overlaps the other's butterfly phase).
-static int g_tile_log = 12;  // measured: 46.9 ms vs 54.8 ms per 2^20 x 1024 Fp128 batch (profiles/r01)
+// c->tile_log = 12 by default: measured 46.9 ms vs 54.8 ms per 2^20 x 1024 Fp128 batch (profiles/r01)
 
 struct TilePlan {
   const elt_t* src;
@@ -210,17 +210,16 @@ __global__ __launch_bounds__(FFT_THREADS) void lch_fft_tile(TilePlan p, int inve
 
 // ------------------------------------------------------------------ host side
 static int set_lds_limit(lfgpu_ctx* c) {
-  static bool done = false;
-  if (!done) {
+  if (!(c->attr_done & 1u)) {
     if (const char* e = getenv("LFGPU_TILE_LOG")) {  // tuning knob: 12 or 13
       int v = atoi(e);
-      if (v == 12 || v == 13) g_tile_log = v;
+      if (v == 12 || v == 13) c->tile_log = v;
     }
     LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     LF_HIP(c, hipFuncSetAttribute((const void*)lch_fft_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
     LF_HIP(c, hipFuncSetAttribute((const void*)lch_fft_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
-    done = true;
+    c->attr_done |= 1u;
   }
   return LFGPU_OK;
 }
@@ -233,14 +232,14 @@ static size_t fp_lds_bytes(TilePlan& p) {
 }
 template <class... Args>
 static void launch_fp(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
-  if (g_tile_log == 13)
+  if (c->tile_log == 13)
     hipLaunchKernelGGL(fp_fft_tile<1024>, grid, dim3(1024), lds, c->stream, args...);
   else
     hipLaunchKernelGGL(fp_fft_tile<512>, grid, dim3(512), lds, c->stream, args...);
 }
 template <class... Args>
 static void launch_lch(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
-  if (g_tile_log == 13)
+  if (c->tile_log == 13)
     hipLaunchKernelGGL(lch_fft_tile<1024>, grid, dim3(1024), lds, c->stream, args...);
   else
     hipLaunchKernelGGL(lch_fft_tile<512>, grid, dim3(512), lds, c->stream, args...);
@@ -270,9 +269,9 @@ static std::string keyf(const char* fmt, ...) {
 }
 
 // single-pass plan: T = n points, batch = rows
-static TilePlan plan_single(void* A, size_t rows, u32 logn, size_t ld) {
+static TilePlan plan_single(const lfgpu_ctx* c, void* A, size_t rows, u32 logn, size_t ld) {
   TilePlan p{};
-  u32 logC = (u32)g_tile_log - logn;
+  u32 logC = (u32)c->tile_log - logn;
   u32 need = lf_log2(rows);
   if (logC > need) logC = need;
   p.src = (const elt_t*)A;
@@ -288,69 +287,61 @@ static TilePlan plan_single(void* A, size_t rows, u32 logn, size_t ld) {
   return p;
 }
 
-extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, const uint64_t omega[2],
-                               uint64_t omega_order, void* d_A, size_t ld) {
-  if (!c || !omega || (!d_A && rows && n)) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: null argument");
-  if (rows == 0 || n <= 1) return LFGPU_OK;
-  if (n & (n - 1)) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: n=%zu is not a power of two", n);
-  if (omega_order < n || (omega_order & (omega_order - 1)))
-    return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: omega_order must be a power of two >= n");
-  if (ld < n) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: ld < n");
-  if (rows > 0x7fffffffu) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: too many rows");
-  const u32 logn = lf_log2(n);
-  if (logn > 20) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "fp128_fft: n > 2^20 not covered yet");
-  LF_HIP(c, hipSetDevice(c->device));
-  LF_TRY(set_lds_limit(c));
-
-  elt_t w{omega[0], omega[1]};
-  if (dir == 1) w = h_fp_inv(w);  // fftf = fftb with omega^-1 (fft.h:198-201)
-  elt_t wn = fp_reroot(w, omega_order, n);
-  const u32 logn2 = logn <= (u32)g_tile_log ? logn : 10, logn1 = logn - logn2;
-  const u32 logTw = logn1 > logn2 ? logn1 : logn2;  // root table covers the larger tile
-
-  // root table W[i] = w_Tw^i, i < Tw/2
-  void *dW = nullptr, *dlo = nullptr, *dhi = nullptr;
+// root table W[i] = w_Tw^i, i < Tw/2, for a transform of 2^logn points with the root wn of that order
+static int fp_root_table(lfgpu_ctx* c, const elt_t wn, u32 logn, u32 logTw, std::string* key_out, void** dW) {
+  const size_t n = (size_t)1 << logn;
   std::string key = keyf("fpW:%llx:%llx:%u:%u", (u64)wn.lo, (u64)wn.hi, logn, logTw);
-  if (!lf_table_lookup(c, key, &dW)) {
+  if (!lf_table_lookup(c, key, dW)) {
     std::vector<elt_t> W((size_t)1 << (logTw ? logTw - 1 : 0));
     elt_t wt = fp_reroot(wn, n, (u64)1 << logTw), x = h_fp_of_scalar(1);
     for (size_t i = 0; i < W.size(); ++i) {
       W[i] = x;
       x = fp_mul(x, wt);
     }
-    LF_TRY(lf_table(c, key, W.data(), W.size() * 16, &dW));
+    LF_TRY(lf_table(c, key, W.data(), W.size() * 16, dW));
   }
-  if (logn1 == 0) {
-    TilePlan p = plan_single(d_A, rows, logn, ld);
-    u32 ntiles = (u32)((rows + (1u << p.logC) - 1) >> p.logC);
-    size_t lds = fp_lds_bytes(p);
-    launch_fp(c, dim3(ntiles, 1), lds, p, (const elt_t*)dW, logTw - logn, (const elt_t*)nullptr, (const elt_t*)nullptr, 0u);
-    LF_HIP(c, hipGetLastError());
-    return LFGPU_OK;
+  *key_out = key;
+  return LFGPU_OK;
+}
+// the two-level inter-pass table lo[e & 1023] = wn^(e & 1023), hi[e >> 10] = wn^(1024 (e >> 10)), e < n
+static int fp_two_level_tables(lfgpu_ctx* c, const elt_t wn, u32 logn, const std::string& key, void** dlo, void** dhi) {
+  std::string klo = key + ":lo", khi = key + ":hi";
+  if (!lf_table_lookup(c, klo, dlo) || !lf_table_lookup(c, khi, dhi)) {
+    std::vector<elt_t> lo(1024), hi((size_t)1 << (logn > 10 ? logn - 10 : 0));
+    elt_t x = h_fp_of_scalar(1);
+    for (size_t i = 0; i < 1024; ++i) {
+      lo[i] = x;
+      x = fp_mul(x, wn);
+    }
+    elt_t w1024 = x;  // wn^1024
+    x = h_fp_of_scalar(1);
+    for (size_t i = 0; i < hi.size(); ++i) {
+      hi[i] = x;
+      x = fp_mul(x, w1024);
+    }
+    LF_TRY(lf_table(c, klo, lo.data(), lo.size() * 16, dlo));
+    LF_TRY(lf_table(c, khi, hi.data(), hi.size() * 16, dhi));
   }
-  // two passes.  Inter-pass twiddles w_n^(j1*k2): either the full [j1][k2] table (n elements, default: one product
+  return LFGPU_OK;
+}
+
+// Two tile passes for 2^12 < n <= 2^20: `rows` transforms with the root wn of order n, row r read at src + r*sld and
+// written to X[j] = dst[r*drow + j*dstep] (dstep = 1, drow = ld: a plain row).  Goes through `scratch`.
+static int fp_fft_two_pass(lfgpu_ctx* c, const elt_t wn, u32 logn, size_t rows, const elt_t* src, size_t sld, elt_t* dst, long long drow,
+                           long long dstep) {
+  const size_t n = (size_t)1 << logn;
+  const u32 logn2 = 10, logn1 = logn - logn2;
+  const u32 logTw = logn1 > logn2 ? logn1 : logn2;  // root table covers the larger tile
+  void *dW = nullptr, *dlo = nullptr, *dhi = nullptr;
+  std::string key;
+  LF_TRY(fp_root_table(c, wn, logn, logTw, &key, &dW));
+  // Inter-pass twiddles w_n^(j1*k2): either the full [j1][k2] table (n elements, default: one product
   // per element, table slices stay in L2 because batch rows vary fastest in the grid) or, with LFGPU_FP_TW=2, the
   // two-level form lo[e & 1023] * hi[e >> 10] (2 KiB + n/64 bytes of tables, two products per element).
   static const bool two_level = getenv("LFGPU_FP_TW") && atoi(getenv("LFGPU_FP_TW")) == 2;
   const size_t n1 = (size_t)1 << logn1, n2 = (size_t)1 << logn2;
   if (two_level) {
-    std::string klo = key + ":lo", khi = key + ":hi";
-    if (!lf_table_lookup(c, klo, &dlo) || !lf_table_lookup(c, khi, &dhi)) {
-      std::vector<elt_t> lo(1024), hi((size_t)1 << (logn - 10));
-      elt_t x = h_fp_of_scalar(1);
-      for (size_t i = 0; i < 1024; ++i) {
-        lo[i] = x;
-        x = fp_mul(x, wn);
-      }
-      elt_t w1024 = x;  // wn^1024
-      x = h_fp_of_scalar(1);
-      for (size_t i = 0; i < hi.size(); ++i) {
-        hi[i] = x;
-        x = fp_mul(x, w1024);
-      }
-      LF_TRY(lf_table(c, klo, lo.data(), lo.size() * 16, &dlo));
-      LF_TRY(lf_table(c, khi, hi.data(), hi.size() * 16, &dhi));
-    }
+    LF_TRY(fp_two_level_tables(c, wn, logn, key, &dlo, &dhi));
   } else {
     std::string kfull = key + ":full";
     if (!lf_table_lookup(c, kfull, &dlo)) {
@@ -374,11 +365,11 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
   {  // pass A: n1-point transforms over k1 (stride n2), C consecutive k2 per tile
     TilePlan p{};
     p.logT = logn1;
-    p.logC = (u32)g_tile_log - logn1;
+    p.logC = (u32)c->tile_log - logn1;
     if (p.logC > logn2) p.logC = logn2;
-    p.src = (const elt_t*)d_A;
+    p.src = src;
     p.dst = (elt_t*)scratch;
-    p.src_row = (long long)ld;
+    p.src_row = (long long)sld;
     p.dst_row = (long long)n;
     p.src_tile = p.dst_tile = 1ll << p.logC;
     p.sk = p.dk = (long long)n2;
@@ -396,18 +387,18 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
   {  // pass B: n2-point transforms on contiguous rows j1; output X[j1 + n1*j2]
     TilePlan p{};
     p.logT = logn2;
-    p.logC = (u32)g_tile_log - logn2;
+    p.logC = (u32)c->tile_log - logn2;
     if (p.logC > logn1) p.logC = logn1;
     p.src = (const elt_t*)scratch;
-    p.dst = (elt_t*)d_A;
+    p.dst = dst;
     p.src_row = (long long)n;
-    p.dst_row = (long long)ld;
+    p.dst_row = drow;
     p.src_tile = (long long)n2 << p.logC;
-    p.dst_tile = 1ll << p.logC;
+    p.dst_tile = (1ll << p.logC) * dstep;
     p.sk = 1;
     p.sc = (long long)n2;
-    p.dk = (long long)n1;
-    p.dc = 1;
+    p.dk = (long long)n1 * dstep;
+    p.dc = dstep;
     p.nbatch = (u32)n1;
     p.kfast_src = 1;
     p.kfast_dst = 0;
@@ -415,6 +406,68 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     launch_fp(c, dim3((u32)(n1 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn2, (const elt_t*)nullptr,
               (const elt_t*)nullptr, 0u);
     LF_HIP(c, hipGetLastError());
+  }
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, const uint64_t omega[2],
+                               uint64_t omega_order, void* d_A, size_t ld) {
+  if (!c || !omega || (!d_A && rows && n)) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: null argument");
+  if (rows == 0 || n <= 1) return LFGPU_OK;
+  if (n & (n - 1)) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: n=%zu is not a power of two", n);
+  if (omega_order < n || (omega_order & (omega_order - 1)))
+    return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: omega_order must be a power of two >= n");
+  if (ld < n) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: ld < n");
+  if (rows > 0x7fffffffu) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: too many rows");
+  const u32 logn = lf_log2(n);
+  if (logn > 30) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "fp128_fft: n > 2^30");
+  LF_HIP(c, hipSetDevice(c->device));
+  LF_TRY(set_lds_limit(c));
+
+  elt_t w{omega[0], omega[1]};
+  if (dir == 1) w = h_fp_inv(w);  // fftf = fftb with omega^-1 (fft.h:198-201)
+  elt_t wn = fp_reroot(w, omega_order, n);
+  if (logn <= (u32)c->tile_log) {  // one pass
+    void* dW = nullptr;
+    std::string key;
+    LF_TRY(fp_root_table(c, wn, logn, logn, &key, &dW));
+    TilePlan p = plan_single(c, d_A, rows, logn, ld);
+    u32 ntiles = (u32)((rows + (1u << p.logC) - 1) >> p.logC);
+    size_t lds = fp_lds_bytes(p);
+    launch_fp(c, dim3(ntiles, 1), lds, p, (const elt_t*)dW, 0u, (const elt_t*)nullptr, (const elt_t*)nullptr, 0u);
+    LF_HIP(c, hipGetLastError());
+    return LFGPU_OK;
+  }
+  if (logn <= 20) return fp_fft_two_pass(c, wn, logn, rows, (const elt_t*)d_A, ld, (elt_t*)d_A, (long long)ld, 1);
+  // n > 2^20: n = n1 * 2^20.  Per row: one tile pass of n1-point transforms down the stride-2^20 dimension, multiplied by
+  // the twiddles w_n^(j1 * column) (two-level table), written as n1 contiguous sequences of 2^20 points; those are
+  // transformed by the two-pass plan with the root w_n^n1 and written to X[j1 + n1 * J].
+  const u32 logn1 = logn - 20;
+  const size_t n1 = (size_t)1 << logn1, n2 = (size_t)1 << 20;
+  void *dW = nullptr, *dlo = nullptr, *dhi = nullptr, *mid = nullptr;
+  std::string key;
+  LF_TRY(fp_root_table(c, wn, logn, logn1, &key, &dW));
+  LF_TRY(fp_two_level_tables(c, wn, logn, key, &dlo, &dhi));
+  LF_TRY(lf_scratch2(c, n * 16, &mid));
+  elt_t wi = wn;  // w_n^n1: the root of order 2^20 of the inner transforms
+  for (u32 i = 0; i < logn1; ++i) wi = fp_mul(wi, wi);
+  for (size_t r = 0; r < rows; ++r) {
+    elt_t* row = (elt_t*)d_A + r * ld;
+    TilePlan p{};
+    p.logT = logn1;
+    p.logC = (u32)c->tile_log - logn1;
+    p.src = row;
+    p.dst = (elt_t*)mid;
+    p.src_row = p.dst_row = 0;
+    p.src_tile = p.dst_tile = 1ll << p.logC;
+    p.sk = p.dk = (long long)n2;
+    p.sc = p.dc = 1;
+    p.nbatch = (u32)n2;
+    p.kfast_src = p.kfast_dst = 0;
+    size_t lds = fp_lds_bytes(p);
+    launch_fp(c, dim3((u32)(n2 >> p.logC), 1), lds, p, (const elt_t*)dW, 0u, (const elt_t*)dlo, (const elt_t*)dhi, 0u);
+    LF_HIP(c, hipGetLastError());
+    LF_TRY(fp_fft_two_pass(c, wi, 20, n1, (const elt_t*)mid, n2, row, 1, (long long)n1));
   }
   return LFGPU_OK;
 }
@@ -467,7 +520,10 @@ extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx* c, int k, int dir, size_t rows,
   if (!g) return lf_fail(c, LFGPU_ERR_ARG, "lch14_fft: subfield_log_bits must be 4 or 5");
   if (l > g->sub_bits) return lf_fail(c, LFGPU_ERR_ARG, "lch14_fft: l <= kSubFieldBits violated (lch14.h:107)");
   if (rows == 0 || l == 0) return LFGPU_OK;
-  if (l > 20) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "lch14_fft: l > 20 not covered yet");
+  // the two-pass tile plan splits l = (l - 10) + 10 with a first tile of at most 2^tile_log points: l <= 22; batches of
+  // >= 32 rows take the bit-sliced path, whose passes are generic in l (bounded here by its u32 column indices and the
+  // 2^l x 128-byte internal buffer per 32 rows)
+  if (l > (rows >= 32 ? 24u : 10u + (unsigned)c->tile_log)) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "lch14_fft: l = %u too large for %zu rows", l, rows);
   if (ld < ((size_t)1 << l)) return lf_fail(c, LFGPU_ERR_ARG, "lch14_fft: ld < 2^l");
   if (rows > 0x7fffffffu) return lf_fail(c, LFGPU_ERR_ARG, "lch14_fft: too many rows");
   LF_HIP(c, hipSetDevice(c->device));
@@ -481,8 +537,8 @@ extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx* c, int k, int dir, size_t rows,
     }
     if (bs && rows >= 32 && l >= 7) return lf_lch14_fft_bitsliced(c, k, inverse, rows, l, coset, d_B, ld);
   }
-  if (l <= (unsigned)g_tile_log) {
-    TilePlan p = plan_single(d_B, rows, l, ld);
+  if (l <= (unsigned)c->tile_log) {
+    TilePlan p = plan_single(c, d_B, rows, l, ld);
     LchTables t{};
     LF_TRY(lch_tables(c, g, 0, l, coset, true, 1, &t));
     u32 ntiles = (u32)((rows + (1u << p.logC) - 1) >> p.logC);
@@ -497,7 +553,7 @@ extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx* c, int k, int dir, size_t rows,
   LchTables ta{}, tb{};
   // pass A: stages i >= lo over k1 (stride n2); twiddle index u = k1 >> (ii+1): no block term
   pa.logT = logn1;
-  pa.logC = (u32)g_tile_log - logn1;
+  pa.logC = (u32)c->tile_log - logn1;
   if (pa.logC > lo) pa.logC = lo;
   pa.src = (const elt_t*)d_B;
   pa.dst = (elt_t*)d_B;
@@ -510,7 +566,7 @@ extern "C" int lfgpu_gf2128_lch14_fft(lfgpu_ctx* c, int k, int dir, size_t rows,
   LF_TRY(lch_tables(c, g, lo, logn1, coset, true, 1, &ta));
   // pass B: stages i < lo on contiguous blocks k1; C consecutive blocks per tile
   pb.logT = lo;
-  pb.logC = (u32)g_tile_log - lo;
+  pb.logC = (u32)c->tile_log - lo;
   if (pb.logC > logn1) pb.logC = logn1;
   pb.src = (const elt_t*)d_B;
   pb.dst = (elt_t*)d_B;

@@ -25,7 +25,6 @@
 // (one stage per pass whose twiddle differs between the two halves of a wave: run as two exec-masked scalar-branched
 // products, bs_mac_groups) or r_log 6 / nb 3 (every stage wave-uniform, more passes):
 // LFGPU_BS_RLOG selects; see DESIGN.md.
-static u32 g_bs_rlog = 5;
 #define BS_PS(units) ((units) + 1)  // LDS plane stride (words): +1 keeps the 8x4-byte scatter of a 128-byte chunk on distinct banks
 
 // ------------------------------------------------------------------ conversions
@@ -325,17 +324,18 @@ static int bs_tables(lfgpu_ctx* c, const GfHostCtx* g, unsigned l, u64 coset, co
 template <int K>
 static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows, unsigned l, u64 coset, void* d_B, size_t ld) {
   constexpr int M = Tower<K>::M, D = Tower<K>::D;
-  static bool env = false;
-  if (!env) {
+  if (!(c->attr_done & 4u)) {
     if (const char* e = getenv("LFGPU_BS_RLOG")) {
       int v = atoi(e);
-      if (v >= 5 && v <= 7) g_bs_rlog = (u32)v;
+      if (v >= 5 && v <= 7) c->bs_rlog = (u32)v;
     }
-    env = true;
   }
+  const u32 g_bs_rlog = c->bs_rlog;
   const u32 R = 1u << g_bs_rlog, nbmax = 9 - g_bs_rlog;
-  static u32 cu_env = 3;
-  if (const char* e = getenv("LFGPU_BS_CU")) cu_env = (u32)atoi(e) <= 5 ? (u32)atoi(e) : 3;
+  static const u32 cu_env = [] {
+    const char* e = getenv("LFGPU_BS_CU");
+    return e && (u32)atoi(e) <= 5 ? (u32)atoi(e) : 3u;
+  }();
   const u32 n = 1u << l;
   const u32 nrg = (u32)((rows + 31) / 32);
   const u32 combos = ((nrg * D + R - 1) / R) * R;  // padded to whole butterfly tiles
@@ -344,13 +344,12 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
   const u32* d_tw = nullptr;
   std::vector<u32> offs;
   LF_TRY(bs_tables<K>(c, g, l, coset, &d_tw, &offs));
-  static bool attr = false;
-  if (!attr) {
+  if (!(c->attr_done & 4u)) {
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr = true;
+    c->attr_done |= 4u;
   }
   if (combos > nrg * D)  // padded combos: define the bits (values are never read back)
     LF_HIP(c, hipMemsetAsync((u32*)internal + (size_t)nrg * D * n * M, 0, (size_t)(combos - nrg * D) * n * M * 4, c->stream));

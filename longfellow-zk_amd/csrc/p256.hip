@@ -144,14 +144,11 @@ __global__ void p256_rs_post_kernel(u32 n, u32 m, u32 P, u32 nrow, const elt32_t
 
 // host-side field helpers
 static elt32_t h256_rsq() {  // R^2 mod p
-  static bool init = false;
-  static elt32_t v;
-  if (!init) {
+  static const elt32_t v = [] {
     elt32_t x{{1, 0, 0, 0}};
     for (int i = 0; i < 512; ++i) x = fp256_add(x, x);
-    v = x;
-    init = true;
-  }
+    return x;
+  }();
   return v;
 }
 static elt32_t h256_to_mont(const elt32_t& raw) { return fp256_mul(raw, h256_rsq()); }

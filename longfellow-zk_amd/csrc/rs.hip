@@ -334,10 +334,9 @@ extern "C" int lfgpu_gf2128_rs_encode_rows(lfgpu_ctx* c, int k, size_t nrow, siz
   RsPlan plan;
   LF_TRY(gf_rs_plan(c, g, k, n, m, &plan));
   size_t lds = (size_t)32 << l;
-  static bool attr = false;
-  if (!attr) {
+  if (!(c->attr_done & 2u)) {
     LF_HIP(c, hipFuncSetAttribute((const void*)gf_rs_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 << 12));
-    attr = true;
+    c->attr_done |= 2u;
   }
   hipLaunchKernelGGL(gf_rs_rows_kernel, dim3((u32)nrow), dim3(RS_THREADS), lds, c->stream, plan, plan, 0u, 0u, (elt_t*)d_T, ld);
   LF_HIP(c, hipGetLastError());
@@ -355,10 +354,9 @@ int lf_gf_rs_rows_mixed(lfgpu_ctx* c, int k, size_t nrow, size_t n1, size_t n2, 
   RsPlan p1, p2;
   LF_TRY(gf_rs_plan(c, g, k, n1, m, &p1));
   LF_TRY(gf_rs_plan(c, g, k, n2, m, &p2));
-  static bool attr = false;
-  if (!attr) {
+  if (!(c->attr_done & 2u)) {
     LF_HIP(c, hipFuncSetAttribute((const void*)gf_rs_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 << 12));
-    attr = true;
+    c->attr_done |= 2u;
   }
   const size_t lds = (size_t)32 << (p1.l > p2.l ? p1.l : p2.l);
   hipLaunchKernelGGL(gf_rs_rows_kernel, dim3((u32)nrow), dim3(RS_THREADS), lds, c->stream, p1, p2, (u32)lo2, (u32)hi2, d_T, ld);

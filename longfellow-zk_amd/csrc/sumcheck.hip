@@ -1260,7 +1260,7 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   LF_HIP(c, hipMemsetAsync(d_state, 0, 64 + 1024, c->stream));  // counters (both levels), abort flag, challenge slot
   void* args[] = {&a};
   const void* fn = field == LFGPU_FIELD_GF2_128 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
-  static int tail_ok = -1;  // dynamic LDS for the tail (112 KiB) needs the attribute once per kernel
+  int& tail_ok = c->sc_tail_ok;  // dynamic LDS for the tail (112 KiB) needs the attribute once per kernel and context
   if (tail_ok < 0) {
     const bool off = getenv("LFGPU_SC_TAIL") && atoi(getenv("LFGPU_SC_TAIL")) == 0;
     tail_ok = !off && hipFuncSetAttribute((const void*)sc_grid_layer_kernel<FIELD_GF2_128>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_TAIL_LDS_BYTES) == hipSuccess &&
@@ -1277,9 +1277,8 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   static const int split_env = getenv("LFGPU_SC_SPLIT") ? atoi(getenv("LFGPU_SC_SPLIT")) : -1;
   a.split_waves = split_env >= 0 ? (u32)split_env : 1u;
   {  // all G workgroups must be resident together (they synchronise through device memory)
-    static int per_cu[2] = {-1, -1};
-    int& pc = per_cu[field == LFGPU_FIELD_GF2_128 ? 0 : 1];
-    if (pc < 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, SM_THREADS, tail_ok ? SC_TAIL_LDS_BYTES : 0) != hipSuccess) pc = 0;
+    int pc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, SM_THREADS, tail_ok ? SC_TAIL_LDS_BYTES : 0) != hipSuccess) pc = 0;
     if (pc < 1 || (long)G > (long)pc * c->num_cu) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "sc_grid_begin: %u workgroups cannot be co-resident", G);
   }
   LF_HIP(c, hipLaunchKernel(fn, dim3(G), dim3(SM_THREADS), args, tail_ok ? SC_TAIL_LDS_BYTES : 0, c->stream));

@@ -112,6 +112,47 @@ def test_fp128_fft_full_row_2pow20_vs_oracle(G):
     assert (G.from_dev(d, np.uint64, (2, n, 2)) == want).all()
 
 
+@pytest.mark.parametrize("logn,rows", [(21, 2), (22, 1), (23, 1)])
+def test_fp128_fft_beyond_2pow20(G, logn, rows):
+    """n > 2^20 (the reference benchmarks BM_FFT_Fp128/4194304; fft.h:185-201 takes any power of two under the root's
+    order): one more tile pass in front of the two-pass plan.  Whole rows against the oracle, then fftf(fftb(x)) = n x."""
+    o = ol.oracle()
+    n = 1 << logn
+    a = np.zeros((rows, n, 2), dtype=np.uint64)
+    for r in range(rows):
+        o.lfo_fp_bogorng_fill(777 + r + logn, n, P(a[r]))
+    want = a.copy()
+    for r in range(rows):
+        o.lfo_fp_fftb(P(want[r]), n, o.lfo_fp_omega32(), 1 << 32)
+    d = G.to_dev(a)
+    G.gpu().fp128_fft(d.data_ptr(), rows, n)
+    assert (G.from_dev(d, np.uint64, a.shape) == want).all()
+    G.gpu().fp128_fft(d.data_ptr(), rows, n, forward=True)
+    got = G.from_dev(d, np.uint64, a.shape)
+    nn = o.lfo_fp_of_scalar(n)
+    for i in list(range(0, n, 262139))[:40] + [n - 1]:
+        assert (got[0, i] == arr(o.lfo_fp_mul(elt(a[0, i]), nn))).all()
+
+
+@pytest.mark.parametrize("l,rows", [(21, 1), (22, 2), (21, 32), (22, 32)])
+def test_lch14_fft_beyond_2pow20(G, l, rows):
+    """l > 20 (GF2_128<5>): the tile plan for small batches, the bit-sliced passes for >= 32 rows; rows 0 and last
+    against the oracle and the IFFT round trip"""
+    o = ol.oracle()
+    c = ol.gf_ctx(5)
+    rng = np.random.default_rng(l * 31 + rows)
+    a = ol.rand_elts(rng, rows << l).reshape(rows, 1 << l, 2)
+    d = G.to_dev(a)
+    G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, subfield_log_bits=5)
+    got = G.from_dev(d, np.uint64, a.shape).copy()
+    for r in sorted({0, rows - 1}):
+        w = a[r].copy()
+        o.lfo_lch14_fft(C.byref(c), l, 0, P(w))
+        assert (got[r] == w).all()
+    G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, inverse=True, subfield_log_bits=5)
+    assert (G.from_dev(d, np.uint64, a.shape) == a).all()
+
+
 # ---------------------------------------------------------------- K2 LCH14 FFT
 @pytest.mark.parametrize("k,l,coset,rows", [(4, 1, 0, 3), (4, 4, 16, 2), (4, 10, 0, 3), (4, 10, 5 << 10, 9), (4, 13, 0, 2),
                                             (4, 14, 0, 2), (4, 16, 0, 1), (5, 17, 3 << 17, 1), (5, 11, 1 << 11, 4)])
@@ -649,3 +690,34 @@ def test_ligero_inner_product_rows(G, field, w, r, ld, nrows, ndense, nsparse):
             G.gpu().ligero_inner_product_rows(field, w, r, ld, nrows, d_dense.data_ptr(), ndense, scale, bad, val, d_rows.data_ptr())
     with pytest.raises(pkg.LfGpuError):  # r + w must fit the row
         G.gpu().ligero_inner_product_rows(field, w, ld, ld, nrows, d_dense.data_ptr(), ndense, scale, idx, val, d_rows.data_ptr())
+
+
+def test_two_contexts_in_one_process(G):
+    """launch configuration (dynamic-LDS attributes, tile geometry, plan caches) is per context, not per process: a second
+    context created after the first has run everything produces the same results (round 1 kept this state in process-global
+    statics, which is wrong for one process driving two devices)"""
+    import torch
+    o = ol.oracle()
+    rng = np.random.default_rng(99)
+    g2 = G.pkg.LfGpu(0)
+    g2.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        n = 1 << 14
+        a = np.zeros((3, n, 2), dtype=np.uint64)
+        o.lfo_fp_bogorng_fill(5, 3 * n, P(a))
+        b = ol.rand_elts(rng, 40 << 9).reshape(40, 1 << 9, 2)
+        t = ol.rand_elts(rng, 3 * 4096).reshape(3, 4096, 2)
+        res = []
+        for gpu in (G.gpu(), g2):
+            da, db, dt = G.to_dev(a), G.to_dev(b), G.to_dev(t)
+            gpu.fp128_fft(da.data_ptr(), 3, n)
+            gpu.gf2128_lch14_fft(db.data_ptr(), 40, 9)
+            gpu.gf2128_rs_encode_rows(dt.data_ptr(), 3, 455, 4096)
+            res.append([G.from_dev(x, np.uint64, y.shape).copy() for x, y in ((da, a), (db, b), (dt, t))])
+        for x, y in zip(*res):
+            assert (x == y).all()
+        want = a[0].copy()
+        o.lfo_fp_fftb(P(want), n, o.lfo_fp_omega32(), 1 << 32)
+        assert (res[1][0][0] == want).all()
+    finally:
+        g2.close()
