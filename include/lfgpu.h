@@ -292,6 +292,8 @@ int lfgpu_gf2128_lch14_fft_host(lfgpu_ctx* ctx, int subfield_log_bits, int dir, 
                                 void* h_B);
 int lfgpu_gf2128_rs_encode_rows_host(lfgpu_ctx* ctx, int subfield_log_bits, size_t nrow, size_t n, size_t m,
                                      void* h_T, size_t ld);
+int lfgpu_fp128_rs_encode_rows_host(lfgpu_ctx* ctx, size_t nrow, size_t n, size_t m, const uint64_t omega[2],
+                                    uint64_t omega_order, void* h_T, size_t ld);
 int lfgpu_column_commit_host(lfgpu_ctx* ctx, int field, size_t nrow, size_t ld, size_t col0, size_t ncols,
                              const void* h_T, const uint8_t* h_nonces, uint8_t* h_layers,
                              uint8_t root_out[32]);

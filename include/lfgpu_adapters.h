@@ -92,13 +92,8 @@ class GpuReedSolomon {
       check(c_.get(), lfgpu_gf2128_rs_encode_rows_host(c_.get(), subfield_log_bits<Field>(), nrow, n_, m_, T, ld),
             "lfgpu_gf2128_rs_encode_rows_host");
     } else {
-      void* d = nullptr;
-      check(c_.get(), lfgpu_malloc(c_.get(), nrow * ld * 16, &d), "lfgpu_malloc");
-      check(c_.get(), lfgpu_memcpy_h2d(c_.get(), d, T, nrow * ld * 16), "h2d");
-      check(c_.get(), lfgpu_fp128_rs_encode_rows(c_.get(), nrow, n_, m_, omega_, omega_order_, d, ld),
-            "lfgpu_fp128_rs_encode_rows");
-      check(c_.get(), lfgpu_memcpy_d2h(c_.get(), T, d, nrow * ld * 16), "d2h");
-      lfgpu_free(c_.get(), d);
+      check(c_.get(), lfgpu_fp128_rs_encode_rows_host(c_.get(), nrow, n_, m_, omega_, omega_order_, T, ld),
+            "lfgpu_fp128_rs_encode_rows_host");
     }
   }
 

@@ -190,6 +190,7 @@ struct BflyArgs {
   u32 r_log;          // log2(lanes per column pair) = log2(combos per tile) + cu
   u32 cu;             // low column bits kept inside the tile (2^cu consecutive columns: 2^cu * 4m-byte segments)
   int inverse;
+  u32 probe;  // timing experiments only (LFGPU_BS_PROBE): 1 = no butterflies (memory only), 2 = every tile aliases tile 0 (compute only)
 };
 
 template <int K, bool INV>
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void bs_bfly_kernel(BflyArgs a) {
   const u32 tid = threadIdx.x;
   const u32 ncol = 1u << a.nb, units = R << a.nb, PS = BS_PS(units);
   const u32 CU = a.cu, cumask = (1u << CU) - 1;
-  const u32 tc = blockIdx.x, cb0 = blockIdx.y << (RL - CU);
+  const u32 tc = a.probe == 2 ? 0u : blockIdx.x, cb0 = (a.probe == 2 ? 0u : blockIdx.y) << (RL - CU);
   const u32 tc_lo = tc & ((1u << (a.lo_bit - CU)) - 1), tc_hi = tc >> (a.lo_bit - CU);
   const u32 cbase = (tc_hi << (a.lo_bit + a.nb)) | (tc_lo << CU);
   constexpr u32 PIECES = M / 4;  // 16-byte pieces per unit
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void bs_bfly_kernel(BflyArgs a) {
   }
   __syncthreads();
   const u32 ntask = R << (a.nb - 1);
-  for (u32 step = 0; step < a.nb; ++step) {
+  for (u32 step = 0; step < (a.probe == 1 ? 0u : a.nb); ++step) {
     const u32 b = INV ? step : (a.nb - 1 - step);
     if (tid < ntask) {
       const u32 cl = tid & (R - 1), pv = tid >> RL;
@@ -375,6 +376,8 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
     a.r_log = g_bs_rlog;
     a.cu = std::min(std::min(cu_env, gr.first), g_bs_rlog);  // inner bits must lie below the stage bits
     a.inverse = inverse;
+    static const u32 probe_env = getenv("LFGPU_BS_PROBE") ? (u32)atoi(getenv("LFGPU_BS_PROBE")) : 0u;
+    a.probe = probe_env;
     const u32 units = R << gr.second;
     if (inverse)
       hipLaunchKernelGGL((bs_bfly_kernel<K, true>), dim3(n >> (gr.second + a.cu), combos >> (g_bs_rlog - a.cu)), dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);

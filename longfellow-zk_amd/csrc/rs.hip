@@ -482,3 +482,16 @@ extern "C" int lfgpu_fp128_rs_encode_rows(lfgpu_ctx* c, size_t nrow, size_t n, s
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
 }
+
+extern "C" int lfgpu_fp128_rs_encode_rows_host(lfgpu_ctx* c, size_t nrow, size_t n, size_t m, const uint64_t omega[2], uint64_t omega_order,
+                                               void* h_T, size_t ld) {
+  if (!c || !h_T) return LFGPU_ERR_ARG;
+  void* d = nullptr;
+  const size_t bytes = nrow * ld * 16;
+  LF_TRY(lf_scratch4(c, bytes, &d));  // scratch4: the encode below works through scratch (FFT) and scratch2 (convolution)
+  LF_HIP(c, hipMemcpyAsync(d, h_T, bytes, hipMemcpyHostToDevice, c->stream));
+  LF_TRY(lfgpu_fp128_rs_encode_rows(c, nrow, n, m, omega, omega_order, d, ld));
+  LF_HIP(c, hipMemcpyAsync(h_T, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  return LFGPU_OK;
+}
