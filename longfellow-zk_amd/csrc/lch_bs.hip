@@ -20,7 +20,7 @@
 #include "ctx.h"
 
 #define BS_COLS 64      // columns per conversion tile (one wave = one plane row)
-#define BS_NB_MAX 4     // index bits per butterfly pass (array bound)
+#define BS_NB_MAX 5     // index bits per butterfly pass (array bound)
 // Butterfly tile = 2^r_log (row-group, coordinate) combos x 2^nb columns = 512 units.  r_log 5 / nb 4
 // (one stage per pass whose twiddle differs between the two halves of a wave: run as two exec-masked scalar-branched
 // products, bs_mac_groups) or r_log 6 / nb 3 (every stage wave-uniform, more passes):
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256, WPC) void bs_cin_kernel(const elt_t* __restric
   }
 }
 
-template <int K>
-__global__ __launch_bounds__(256, 2) void bs_cout_kernel(const u32* __restrict__ src, size_t ld, u32 rows, u32 n,
+template <int K, int WPC>
+__global__ __launch_bounds__(256, WPC) void bs_cout_kernel(const u32* __restrict__ src, size_t ld, u32 rows, u32 n,
                                                          elt_t* __restrict__ dst) {
   constexpr int M = Tower<K>::M, D = Tower<K>::D;
   extern __shared__ u32 lds[];
@@ -290,6 +290,158 @@ __global__ __launch_bounds__(256, 2) void bs_bfly_kernel(BflyArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ butterflies, register-resident (v2)
+// Measured on the LDS-tile kernel above (profiles/r02: probes + PMC): a pass is COMPUTE-bound -- 8.35 ms with every tile
+// aliased to tile 0 (no HBM traffic) against 6.45 ms with the butterflies skipped -- because its 233 VGPRs and its
+// 64 KiB tile allow 2 waves per SIMD, and one or two waves in their XOR phase issue at 4-5 cycles per instruction where
+// four issue at ~2 (tools/ubench: v_xor_b32 28 / 53 / 66 T lane-ops/s at 1 / 2 / 4 waves per SIMD).
+// Here a lane keeps its butterfly pair (2 units = 2 x M words) in registers through all nb stages of a pass:
+//   * lanes of a wave = 64 (combo, inner column) slots that share every twiddle of the pass -> all stages are wave-uniform:
+//     scalar branches on the twiddle's bits, no masked passes;
+//   * wave w of the workgroup owns pair w of the tile's 2^nb columns; between two stages exactly one of its two units
+//     changes owner (the constant-geometry exchange w <-> w ^ 2^s), so a stage moves ONE unit per lane through LDS
+//     (M words out, M words in) instead of reading and writing both, and the tile never lives in LDS;
+//   * the product is evaluated in Horner form, acc = acc * h ^ (t_k ? b : 0): no `cur` copy of the operand -> ~110 VGPRs,
+//     4 waves per SIMD (two 512-thread workgroups per CU with 64 KiB of exchange buffer each);
+//   * units go straight between HBM and registers (128 contiguous bytes per lane).
+template <int M, u32 MU_LOW>
+__device__ __forceinline__ void bs_mul_horner(u32 t, const u32 (&b)[M], u32 (&acc)[M]) {  // acc = t * b, t wave-uniform
+#pragma unroll
+  for (int j = 0; j < M; ++j) acc[j] = 0;
+#pragma unroll
+  for (int k = M - 1; k >= 0; --k) {
+    if (k != M - 1) bs_mulh<M, MU_LOW>(acc);
+    if ((t >> k) & 1u) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) acc[j] ^= b[j];
+    }
+  }
+}
+
+// NW = waves per workgroup = column pairs per tile: 8 (<= 4 index bits per pass, two workgroups per CU) or 16 (5 bits,
+// one 1024-thread workgroup per CU); either way 16 waves per CU
+template <int K, bool INV, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void bs_bfly2_kernel(BflyArgs a) {
+  constexpr int M = Tower<K>::M;
+  constexpr u32 MU = Tower<K>::MU_LOW;
+  extern __shared__ u32 xch[];  // [NW waves][M planes][64 + 2 lanes]
+  const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+  const u32 CU = a.cu, cumask = (1u << CU) - 1;
+  const u32 tc = blockIdx.x, cb0 = blockIdx.y << (6 - CU);
+  const u32 tc_lo = tc & ((1u << (a.lo_bit - CU)) - 1), tc_hi = tc >> (a.lo_bit - CU);
+  const u32 cbase = (tc_hi << (a.lo_bit + a.nb)) | (tc_lo << CU);
+  const u32 npair = 1u << (a.nb - 1);
+  const bool active = w < npair;
+  u32 b0[M], b1[M];
+  u32 j0 = 0, j1 = 0;
+  {
+    const u32 b = INV ? 0u : a.nb - 1, u = w >> b, v = w & ((1u << b) - 1);
+    j0 = (u << (b + 1)) | v;
+    j1 = j0 + (1u << b);
+  }
+  // A unit is 128 (K = 5) / 64 (K = 4) contiguous bytes, so HBM wants 8 / 4 lanes per unit: a wave instruction moves whole
+  // 128-byte lines (8 or 16 units).  The wave's own exchange region doubles as the transposition buffer between that
+  // layout and "lane = slot, registers = planes": plane stride 64 + 2 words puts the 64 lanes of a transposing write on
+  // 64 different banks (bank = 8 * piece + 2 * k + slot mod 64), the per-lane plane reads are conflict-free anyway.
+  constexpr u32 PIECES = M / 4, UPI = 64 / PIECES, NIT = 64 / UPI, XS = 66;
+  u32* const stage = xch + (size_t)w * M * XS;
+  const u32 piece = lane % PIECES, sub = lane / PIECES;
+  auto slot_base = [&](u32 slot) { return a.data + ((size_t)(cb0 + (slot >> CU)) * a.n + cbase + (slot & cumask)) * M; };
+  auto unit_in = [&](u32 j, u32 (&dst)[M]) {
+    uint4 v[NIT];
+    if (active) {
+#pragma unroll
+      for (u32 it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const uint4*>(slot_base(it * UPI + sub) + ((size_t)j << a.lo_bit) * M + 4 * piece);
+#pragma unroll
+      for (u32 it = 0; it < NIT; ++it) {
+        u32* q = stage + (4 * piece) * XS + it * UPI + sub;
+        q[0] = v[it].x; q[XS] = v[it].y; q[2 * XS] = v[it].z; q[3 * XS] = v[it].w;
+      }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int p = 0; p < M; ++p) dst[p] = stage[p * XS + lane];
+    }
+    __syncthreads();
+  };
+  auto unit_out = [&](u32 j, const u32 (&src)[M]) {
+    if (active) {
+#pragma unroll
+      for (int p = 0; p < M; ++p) stage[p * XS + lane] = src[p];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (u32 it = 0; it < NIT; ++it) {
+        const u32* q = stage + (4 * piece) * XS + it * UPI + sub;
+        *reinterpret_cast<uint4*>(slot_base(it * UPI + sub) + ((size_t)j << a.lo_bit) * M + 4 * piece) = make_uint4(q[0], q[XS], q[2 * XS], q[3 * XS]);
+      }
+    }
+    __syncthreads();
+  };
+  unit_in(j0, b0);
+  unit_in(j1, b1);
+  for (u32 step = 0; step < a.nb; ++step) {
+    const u32 b = INV ? step : (a.nb - 1 - step);
+    if (active) {
+      // twiddle of (stage lo_bit + b, column block): the same for the whole wave
+      const u32 t = __builtin_amdgcn_readfirstlane(a.tw[a.off[b] + ((tc_hi << (a.nb - 1 - b)) | (w >> b))]);
+      u32 acc[M];
+      if (INV) {  // b1 ^= b0; b0 ^= t*b1   (lch14.h:225-229)
+#pragma unroll
+        for (int p = 0; p < M; ++p) b1[p] ^= b0[p];
+        bs_mul_horner<M, MU>(t, b1, acc);
+#pragma unroll
+        for (int p = 0; p < M; ++p) b0[p] ^= acc[p];
+      } else {  // b0 ^= t*b1; b1 ^= b0   (lch14.h:219-223)
+        bs_mul_horner<M, MU>(t, b1, acc);
+#pragma unroll
+        for (int p = 0; p < M; ++p) {
+          b0[p] ^= acc[p];
+          b1[p] ^= b0[p];
+        }
+      }
+    }
+    if (step + 1 < a.nb) {
+      // next stage pairs columns that differ in bit sb' ; my two columns agree in that bit (= s): the unit that keeps
+      // its slot stays, the other one is swapped with wave w ^ 2^sb
+      const u32 sb = INV ? b : b - 1;
+      const u32 s = (w >> sb) & 1u, partner = w ^ (1u << sb);
+      __syncthreads();  // everybody has read the previous exchange
+      if (active) {
+        u32* out = xch + ((size_t)partner * M) * XS + lane;
+        if (s == 0) {
+#pragma unroll
+          for (int p = 0; p < M; ++p) out[p * XS] = b1[p];
+        } else {
+#pragma unroll
+          for (int p = 0; p < M; ++p) out[p * XS] = b0[p];
+        }
+      }
+      __syncthreads();
+      if (active) {
+        const u32* in = xch + ((size_t)w * M) * XS + lane;
+        if (s == 0) {
+#pragma unroll
+          for (int p = 0; p < M; ++p) b1[p] = in[p * XS];
+        } else {
+#pragma unroll
+          for (int p = 0; p < M; ++p) b0[p] = in[p * XS];
+        }
+      }
+      // the columns this wave now holds
+      const u32 nbit = INV ? b + 1 : b - 1;
+      const u32 u = w >> nbit, v = w & ((1u << nbit) - 1);
+      j0 = (u << (nbit + 1)) | v;
+      j1 = j0 + (1u << nbit);
+    }
+  }
+  __syncthreads();  // the last exchange has been read everywhere: the regions are free for the way out
+  unit_out(j0, b0);
+  unit_out(j1, b1);
+}
+
 // ------------------------------------------------------------------ host
 template <int K>
 static int bs_tables(lfgpu_ctx* c, const GfHostCtx* g, unsigned l, u64 coset, const u32** d_tw, std::vector<u32>* offs) {
@@ -332,7 +484,12 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
     }
   }
   const u32 g_bs_rlog = c->bs_rlog;
-  const u32 R = 1u << g_bs_rlog, nbmax = 9 - g_bs_rlog;
+  static const int v2_env = getenv("LFGPU_BS_V2") ? atoi(getenv("LFGPU_BS_V2")) : 1;
+  const bool v2 = v2_env && (u32)((rows + 31) / 32) * D >= 64;  // register-resident butterflies: lanes = 64 (combo, inner column) slots
+  // 4 index bits per pass (two 512-thread workgroups per CU overlap their HBM and XOR phases): 61.0 ms per 2^20 x 1024 batch;
+  // 5 bits (LFGPU_BS_V2_NB=5: one 1024-thread workgroup per CU, 4 passes instead of 5) measured 64.1 ms
+  static const u32 v2_nb = getenv("LFGPU_BS_V2_NB") && atoi(getenv("LFGPU_BS_V2_NB")) == 5 ? 5u : 4u;
+  const u32 R = v2 ? 64u : 1u << g_bs_rlog, nbmax = v2 ? v2_nb : 9 - g_bs_rlog;
   static const u32 cu_env = [] {
     const char* e = getenv("LFGPU_BS_CU");
     return e && (u32)atoi(e) <= 5 ? (u32)atoi(e) : 3u;
@@ -350,6 +507,14 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
     c->attr_done |= 4u;
   }
   if (combos > nrg * D)  // padded combos: define the bits (values are never read back)
@@ -357,6 +522,9 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
   static const int cin_wpc = getenv("LFGPU_BS_CIN_WPC") ? atoi(getenv("LFGPU_BS_CIN_WPC")) : 2;
   if (cin_wpc == 3)
     hipLaunchKernelGGL((bs_cin_kernel<K, 3>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
+                       (u32*)internal);
+  else if (cin_wpc == 4)
+    hipLaunchKernelGGL((bs_cin_kernel<K, 4>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
                        (u32*)internal);
   else
     hipLaunchKernelGGL((bs_cin_kernel<K, 2>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
@@ -373,19 +541,35 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
     a.n = n;
     a.lo_bit = gr.first;
     a.nb = gr.second;
-    a.r_log = g_bs_rlog;
-    a.cu = std::min(std::min(cu_env, gr.first), g_bs_rlog);  // inner bits must lie below the stage bits
+    a.r_log = v2 ? 6u : g_bs_rlog;
+    a.cu = std::min(std::min(cu_env, gr.first), a.r_log);  // inner bits must lie below the stage bits
     a.inverse = inverse;
     static const u32 probe_env = getenv("LFGPU_BS_PROBE") ? (u32)atoi(getenv("LFGPU_BS_PROBE")) : 0u;
     a.probe = probe_env;
     const u32 units = R << gr.second;
-    if (inverse)
-      hipLaunchKernelGGL((bs_bfly_kernel<K, true>), dim3(n >> (gr.second + a.cu), combos >> (g_bs_rlog - a.cu)), dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
+    const dim3 grid(n >> (gr.second + a.cu), combos >> (a.r_log - a.cu));
+    if (v2 && gr.second == 5) {  // 16 waves x M planes x (64 + 2) words of exchange / staging buffer
+      if (inverse)
+        hipLaunchKernelGGL((bs_bfly2_kernel<K, true, 16>), grid, dim3(1024), (size_t)16 * M * 66 * 4, c->stream, a);
+      else
+        hipLaunchKernelGGL((bs_bfly2_kernel<K, false, 16>), grid, dim3(1024), (size_t)16 * M * 66 * 4, c->stream, a);
+    } else if (v2) {
+      if (inverse)
+        hipLaunchKernelGGL((bs_bfly2_kernel<K, true, 8>), grid, dim3(512), (size_t)8 * M * 66 * 4, c->stream, a);
+      else
+        hipLaunchKernelGGL((bs_bfly2_kernel<K, false, 8>), grid, dim3(512), (size_t)8 * M * 66 * 4, c->stream, a);
+    } else if (inverse)
+      hipLaunchKernelGGL((bs_bfly_kernel<K, true>), grid, dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
     else
-      hipLaunchKernelGGL((bs_bfly_kernel<K, false>), dim3(n >> (gr.second + a.cu), combos >> (g_bs_rlog - a.cu)), dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
+      hipLaunchKernelGGL((bs_bfly_kernel<K, false>), grid, dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
   }
-  hipLaunchKernelGGL(bs_cout_kernel<K>, dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const u32*)internal, ld, (u32)rows, n,
-                     (elt_t*)d_B);
+  static const int cout_wpc = getenv("LFGPU_BS_COUT_WPC") ? atoi(getenv("LFGPU_BS_COUT_WPC")) : 2;
+  if (cout_wpc == 4)
+    hipLaunchKernelGGL((bs_cout_kernel<K, 4>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const u32*)internal, ld, (u32)rows, n, (elt_t*)d_B);
+  else if (cout_wpc == 3)
+    hipLaunchKernelGGL((bs_cout_kernel<K, 3>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const u32*)internal, ld, (u32)rows, n, (elt_t*)d_B);
+  else
+    hipLaunchKernelGGL((bs_cout_kernel<K, 2>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const u32*)internal, ld, (u32)rows, n, (elt_t*)d_B);
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
 }

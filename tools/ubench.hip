@@ -55,6 +55,15 @@ __global__ __launch_bounds__(256) void k(u32* out, u32 seed) {
     if (OP == 13)
       asm volatile("v_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %4\n\tv_add_f64 %2, %2, %4\n\tv_add_f64 %3, %3, %4"
                    : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(fc));
+    if (OP == 15)  // a ^= (x & m): three-input boolean op (truth table 0x78 = A ^ (B & C)), mask in a VGPR
+      asm volatile("v_bitop3_b32 %0, %0, %4, %5 bitop3:0x78\n\tv_bitop3_b32 %1, %1, %4, %5 bitop3:0x78\n\tv_bitop3_b32 %2, %2, %4, %5 bitop3:0x78\n\tv_bitop3_b32 %3, %3, %4, %5 bitop3:0x78"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(seed ^ 0x55u));
+    if (OP == 16)  // ... mask in an SGPR (wave-uniform)
+      asm volatile("v_bitop3_b32 %0, %0, %4, %5 bitop3:0x78\n\tv_bitop3_b32 %1, %1, %4, %5 bitop3:0x78\n\tv_bitop3_b32 %2, %2, %4, %5 bitop3:0x78\n\tv_bitop3_b32 %3, %3, %4, %5 bitop3:0x78"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "s"(seed ^ 0x55u));
+    if (OP == 17)  // the two-instruction form: v_and + v_xor
+      asm volatile("v_and_b32 %4, %0, %5\n\tv_xor_b32 %1, %1, %4\n\tv_and_b32 %4, %2, %5\n\tv_xor_b32 %3, %3, %4"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b) : "v"(seed ^ 0x55u));
     if (OP == 14)  // v_mad_u64_u32 with the accumulate chain only through the 64-bit addend (the schoolbook-row shape)
       asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %6, %1\n\tv_mad_u64_u32 %2, vcc, %4, %7, %2\n\tv_mad_u64_u32 %3, vcc, %4, %8, %3"
                    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(b), "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");
@@ -73,6 +82,31 @@ __global__ __launch_bounds__(256) void kf(elt_t* out, u64 seed) {
     z = Fld<F>::mul(z, y);
   }
   out[blockIdx.x * 256 + threadIdx.x] = Fld<F>::add(x, z);
+}
+
+// the same loop under a given occupancy: `lds` bytes of dynamic LDS per 256-thread workgroup bound the workgroups per CU
+// (160 KiB per CU), i.e. waves per SIMD = workgroups per CU
+template <int OP>
+double run_occ(const char* name, int ops_per_iter, size_t lds) {
+  u32* d;
+  int blocks = 256 * 16;
+  CHK(hipMalloc(&d, blocks * 256 * 4));
+  CHK(hipFuncSetAttribute((const void*)k<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0));
+  CHK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), lds, 0, d, 12345u);
+  CHK(hipDeviceSynchronize());
+  CHK(hipEventRecord(e0));
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), lds, 0, d, 12345u + r);
+  CHK(hipEventRecord(e1));
+  CHK(hipEventSynchronize(e1));
+  float ms;
+  CHK(hipEventElapsedTime(&ms, e0, e1));
+  double g = 5.0 * blocks * 256.0 * ITERS * ops_per_iter / (ms * 1e-3) / 1e9;
+  printf("%-22s %6zu KiB LDS/WG (%zu waves/SIMD) %10.1f G lane-ops/s\n", name, lds >> 10, lds ? (160 * 1024) / lds : 8, g);
+  CHK(hipFree(d));
+  return g;
 }
 
 template <int OP>
@@ -134,6 +168,14 @@ int main() {
   run<11>("v_fma_f32", 4);
   run<10>("v_fma_f64", 4);
   run<13>("v_add_f64", 4);
+  for (size_t lds : {(size_t)160 * 1024, (size_t)80 * 1024, (size_t)53 * 1024, (size_t)40 * 1024, (size_t)20 * 1024}) {
+    run_occ<4>("v_xor_b32", 4, lds);
+    run_occ<8>("v_add_co+v_addc_co", 4, lds);
+    run_occ<14>("v_mad_u64_u32", 4, lds);
+    run_occ<15>("v_bitop3_b32 (vgpr mask)", 4, lds);
+    run_occ<16>("v_bitop3_b32 (sgpr mask)", 4, lds);
+    run_occ<17>("v_and_b32 + v_xor_b32", 4, lds);
+  }
   runf<FIELD_FP128>("fp128 montgomery mul");
   runf<FIELD_GF2_128>("gf2_128 mul (kronecker)");
   return 0;
