@@ -444,3 +444,42 @@ def test_zk_cxx_driver_wire_bytes_other_block_counts(nb):
     tv.close()
     zk.close()
     circ.close()
+
+
+@pytest.mark.gpu
+def test_zk_mdoc_hash_circuit_matches_reference():
+    """BASELINE config 5, the GF2_128 half: the REAL mdoc hash circuit (kZkSpecs[0]; 17 layers, 7.76 M terms, 952 public
+    inputs, subfield boundary 85112, Ligero block_enc 4151 -- not a power of two) with the witness of the reference's own
+    example (mdoc_tests[0], age_over_18), proved by the library's ZK driver: wire bytes identical to the reference's
+    ZkProver<GF2_128<>, LCH14ReedSolomonFactory> under the same transcript and RandomEngine (oracle/ref_mdoc.cc ->
+    oracle/gen_mdoc_fixture.py), and accepted by the library's verifier.  (The signature half, ZkProver<Fp256Base, ...>:
+    Reed-Solomon rows and column commitment in tests/test_p256_gpu.py; its sumcheck is not on the device yet.)"""
+    import gpu_util as G
+    import ligero_fixture as lf
+    info = json.load(open(os.path.join(GOLD, "mdoc.json")))["hash"]
+    raw = lzma.decompress(open(os.path.join(GOLD, "mdoc_hash.lfc1.xz"), "rb").read())
+    W = np.frombuffer(lzma.decompress(open(os.path.join(GOLD, "mdoc_hash.w.xz"), "rb").read()), dtype=np.uint64).reshape(-1, 2).copy()
+    gpu = G.gpu()
+    circ = G.pkg.Circuit(gpu, raw)
+    ci = circ.info
+    assert (ci.nl, ci.ninputs, ci.npub_in, ci.subfield_boundary, ci.nterms) == (info["nl"], info["ninputs"], info["npub_in"],
+                                                                               info["subfield_boundary"], info["nterms"])
+    zk = G.pkg.ZkProver(gpu, circ, info["rate"], info["nreq"], info["block_enc"])
+    assert (zk.param.block_enc, zk.param.nrow, zk.param.block, zk.param.nw) == (info["block_enc"], info["nrow"], info["block"], info["nw"])
+    ts = G.pkg.FsTranscript(b"test")
+    root = zk.commit(W, lf.LcgRng(100).bytes, ts)
+    assert root.hex() == info["zk_root"]
+    assert zk.prove(W, ts)
+    wire = zk.wire()
+    ts.close()
+    assert len(wire) == info["zk_wire_bytes"] and hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"]
+    tv = G.pkg.FsTranscript(b"test")
+    assert G.pkg.zk_verify(gpu, circ, wire, W[:ci.npub_in], tv, info["rate"], info["nreq"], info["block_enc"]) == (True, "ok")
+    tv.close()
+    pub_bad = W[:ci.npub_in].copy()
+    pub_bad[5, 0] ^= np.uint64(1)
+    tv = G.pkg.FsTranscript(b"test")
+    assert G.pkg.zk_verify(gpu, circ, wire, pub_bad, tv, info["rate"], info["nreq"], info["block_enc"])[0] is False
+    tv.close()
+    zk.close()
+    circ.close()

@@ -17,16 +17,22 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 nb = int(args[0]) if args else 32
 reps = int(args[1]) if len(args) > 1 else 5
 FP = "--fp128" in sys.argv  # the circuit compiled over Fp128 (fixture for 1 block only)
-stem = "flatsha_fp_nb%d" % nb if FP else "flatsha_nb%d" % nb
+MDOC = "--mdoc" in sys.argv  # BASELINE config 5, GF2_128 half: the real mdoc hash circuit (tests/golden/mdoc_hash.*)
+stem = "mdoc_hash" if MDOC else "flatsha_fp_nb%d" % nb if FP else "flatsha_nb%d" % nb
 gold = os.path.join(ROOT, "tests", "golden")
 raw = lzma.decompress(open(os.path.join(gold, stem + ".lfc1.xz"), "rb").read())
 W = np.frombuffer(lzma.decompress(open(os.path.join(gold, stem + ".w.xz"), "rb").read()), dtype=np.uint64).reshape(-1, 2).copy()
-info = json.load(open(os.path.join(gold, stem + ".json")))
+if MDOC:
+    mi = json.load(open(os.path.join(gold, "mdoc.json")))["hash"]
+    info = dict(mi, zk_nw=mi["nw"], zk_block_enc=mi["block_enc"], zk_nrow=mi["nrow"], round_hands=None)
+else:
+    info = json.load(open(os.path.join(gold, stem + ".json")))
+BE = info["zk_block_enc"] if MDOC else 0
 pkg, gpu = G.pkg, G.gpu()
 t0 = time.perf_counter()
 circ = pkg.Circuit(gpu, raw)
 t_load = (time.perf_counter() - t0) * 1e3
-zk = pkg.ZkProver(gpu, circ, 7, 132)
+zk = pkg.ZkProver(gpu, circ, 7, 132, BE)
 res = {"nb": nb, "field": "Fp128" if FP else "GF2_128", "shape": {k: info[k] for k in ("zk_nw", "zk_block_enc", "zk_nrow", "nterms", "round_hands")},
        "circuit_parse_upload_ms": t_load}
 
@@ -77,7 +83,7 @@ vruns = []
 for rep in range(reps):
     ts = pkg.FsTranscript(b"test")
     t0 = time.perf_counter()
-    okv, why = pkg.zk_verify(gpu, circ, wire, pub, ts)
+    okv, why = pkg.zk_verify(gpu, circ, wire, pub, ts, 7, 132, BE)
     vruns.append((time.perf_counter() - t0) * 1e3)
     ts.close()
     assert okv, why
@@ -96,7 +102,10 @@ if "--harness" in sys.argv:
     res["gpu_python_harness_total_ms"] = (t1 - t0) * 1e3
 
 gen = os.path.join(ROOT, "oracle", "_ref", "gen_flatsha_fp" if FP else "gen_flatsha")
-if os.path.exists(gen) and "--no-cpu" not in sys.argv:
+if MDOC:
+    res["cpu_reference_ms"] = {"commit": mi["ref_commit_ms"], "prove": mi["ref_prove_ms"], "total": mi["ref_commit_ms"] + mi["ref_prove_ms"], "cores": 1,
+                               "note": "measured in the build container when the fixture was made (oracle/ref_mdoc.cc)"}
+elif os.path.exists(gen) and "--no-cpu" not in sys.argv:
     with tempfile.TemporaryDirectory() as td_:
         r = json.loads(subprocess.check_output([gen, str(nb), os.path.join(td_, "x")]).decode())
     res["cpu_reference_ms"] = {"commit": r["ref_zk_commit_ms"], "prove": r["ref_zk_prove_ms"], "total": r["ref_zk_commit_ms"] + r["ref_zk_prove_ms"],
