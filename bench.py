@@ -385,7 +385,7 @@ def main():
     # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE with the gfx950 correction + WRITE_SIZE), collected
     # with the same command and committed under profiles/ -- counters cannot be read in-process
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_fp_fft_tile_v7.json")
+    pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic_fp_fft_tile.json")
     if os.path.exists(pmc) and rows == 1024 and logn == 20:
         with open(pmc) as f:
             traffic = json.load(f)["hbm_bytes_per_launch"]
