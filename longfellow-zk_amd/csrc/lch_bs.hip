@@ -69,7 +69,29 @@ __global__ __launch_bounds__(256, WPC) void bs_cin_kernel(const elt_t* __restric
     const u32 lc = t & (BS_COLS - 1), q0 = t / BS_COLS;
 #define BS_IN(i) lds[BS_PL(i, lc)]
 #define BS_OUT(o) out[o]
-    if (K == 5) {
+    if (K == 5 && WPC >= 4) {
+      // 8 outputs per program (a quarter of a coordinate): +14 % XORs over the 32-output programs, but the live set fits
+      // 128 VGPRs without spills -> 4 waves per SIMD (the 16-output halves need 191)
+      const u32 q = q0;
+#define BS_CIN_Q(O)                                                                                             \
+  {                                                                                                             \
+    u32 out[8];                                                                                                 \
+    switch (q) {                                                                                                \
+      case 0: TOWER_K5_P2T_Q0O##O(BS_IN, BS_OUT); break;                                                        \
+      case 1: TOWER_K5_P2T_Q1O##O(BS_IN, BS_OUT); break;                                                        \
+      case 2: TOWER_K5_P2T_Q2O##O(BS_IN, BS_OUT); break;                                                        \
+      default: TOWER_K5_P2T_Q3O##O(BS_IN, BS_OUT); break;                                                       \
+    }                                                                                                           \
+    uint4* u = reinterpret_cast<uint4*>(dst + ((size_t)(rg * D + q) * n + c0 + lc) * M + 8 * O);                \
+    u[0] = make_uint4(out[0], out[1], out[2], out[3]);                                                          \
+    u[1] = make_uint4(out[4], out[5], out[6], out[7]);                                                          \
+  }
+      BS_CIN_Q(0)
+      BS_CIN_Q(1)
+      BS_CIN_Q(2)
+      BS_CIN_Q(3)
+#undef BS_CIN_Q
+    } else if (K == 5) {
       // 16 outputs per program (half a coordinate): +4 % XORs over the 32-output programs, about half the live
       // registers; a wave does both halves of its coordinate one after the other
       const u32 q = q0;  // D == 4 == waves per workgroup
@@ -147,7 +169,30 @@ __global__ __launch_bounds__(256, WPC) void bs_cout_kernel(const u32* __restrict
     u32 x[32];
 #define BS_IN(i) lds[BS_PL(i, lc)]
 #define BS_OUT(o) x[o]
-    if (K == 5) {
+    if (K == 5 && WPC >= 4) {
+#undef BS_OUT
+#define BS_COUT_Q(O)                                     \
+  switch (w) {                                           \
+    case 0: TOWER_K5_T2P_W0O##O(BS_IN, BS_OUT); break;   \
+    case 1: TOWER_K5_T2P_W1O##O(BS_IN, BS_OUT); break;   \
+    case 2: TOWER_K5_T2P_W2O##O(BS_IN, BS_OUT); break;   \
+    default: TOWER_K5_T2P_W3O##O(BS_IN, BS_OUT); break;  \
+  }
+#define BS_OUT(o) x[(o)]
+      BS_COUT_Q(0)
+#undef BS_OUT
+#define BS_OUT(o) x[8 + (o)]
+      BS_COUT_Q(1)
+#undef BS_OUT
+#define BS_OUT(o) x[16 + (o)]
+      BS_COUT_Q(2)
+#undef BS_OUT
+#define BS_OUT(o) x[24 + (o)]
+      BS_COUT_Q(3)
+#undef BS_OUT
+#define BS_OUT(o) x[o]
+#undef BS_COUT_Q
+    } else if (K == 5) {
       switch (w) {
         case 0: TOWER_K5_T2P_W0(BS_IN, BS_OUT); break;
         case 1: TOWER_K5_T2P_W1(BS_IN, BS_OUT); break;
@@ -519,7 +564,8 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
   }
   if (combos > nrg * D)  // padded combos: define the bits (values are never read back)
     LF_HIP(c, hipMemsetAsync((u32*)internal + (size_t)nrg * D * n * M, 0, (size_t)(combos - nrg * D) * n * M * 4, c->stream));
-  static const int cin_wpc = getenv("LFGPU_BS_CIN_WPC") ? atoi(getenv("LFGPU_BS_CIN_WPC")) : 2;
+  // GF2_128<5>: 8-output basis-change programs at 4 waves per SIMD (12.6 -> 10.4 ms per 2^30 elements); <4>: 16-plane programs, 2
+  static const int cin_wpc = getenv("LFGPU_BS_CIN_WPC") ? atoi(getenv("LFGPU_BS_CIN_WPC")) : (K == 5 ? 4 : 2);
   if (cin_wpc == 3)
     hipLaunchKernelGGL((bs_cin_kernel<K, 3>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
                        (u32*)internal);
@@ -563,7 +609,7 @@ static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows
     else
       hipLaunchKernelGGL((bs_bfly_kernel<K, false>), grid, dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
   }
-  static const int cout_wpc = getenv("LFGPU_BS_COUT_WPC") ? atoi(getenv("LFGPU_BS_COUT_WPC")) : 2;
+  static const int cout_wpc = getenv("LFGPU_BS_COUT_WPC") ? atoi(getenv("LFGPU_BS_COUT_WPC")) : (K == 5 ? 4 : 2);
   if (cout_wpc == 4)
     hipLaunchKernelGGL((bs_cout_kernel<K, 4>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const u32*)internal, ld, (u32)rows, n, (elt_t*)d_B);
   else if (cout_wpc == 3)

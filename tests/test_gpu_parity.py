@@ -28,7 +28,10 @@ def test_field_binops(G, field):
     x, y = ol.rand_elts(rng, n, field), ol.rand_elts(rng, n, field)
     pm1 = [0, 0xFFFFF00000000000]
     edge = [[0, 0], [1, 0], pm1, [0xFFFFFFFFFFFFFFFF, 0xFFFFEFFFFFFFFFFF], [0xFFFFFFFFFFFFFFFF, 0], [0, 1],
-            [0, 0xFFFFF00000000000 - 1], [0xFFFFFFFF, 0], [0x100000000, 0], [0, 0xFFFFEFFF00000000]]
+            [0, 0xFFFFF00000000000 - 1], [0xFFFFFFFF, 0], [0x100000000, 0], [0, 0xFFFFEFFF00000000],
+            # the one-step REDC folds t0 << 12 into limb 3 and takes a carry out of T_lo + m: low 20 bits zero / all ones,
+            # limb-3 overflow, T_lo = 0
+            [1 << 20, 0], [(1 << 20) - 1, 0], [0xFFFFF, 0xFFFFFFFF00000000], [0, 1 << 44], [0xFFF00000, 0xFFF0000000000000]]
     if field == GF:
         edge += [[0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF], [0, 0x8000000000000000]]
     k = 0

@@ -385,6 +385,17 @@ def main():
                                             "IN(%d)", "OUT(%d)", "poly planes -> tower coordinate %d, planes %d..%d" % (q, 16 * hh, 16 * hh + 15))
                     out.append(prog)
                     halves_total = nx
+        if m == 32:  # quarter programs (8 outputs): <= 128 VGPRs for the conversion kernels -> 4 waves per SIMD
+            for q in range(d):
+                for o in range(4):
+                    prog, nx = emit_program("TOWER_K%d_P2T_Q%dO%d" % (k, q, o), to_tower[q * m + 8 * o:q * m + 8 * o + 8], 128,
+                                            "IN(%d)", "OUT(%d)", "poly planes -> tower coordinate %d, planes %d..%d" % (q, 8 * o, 8 * o + 7))
+                    out.append(prog)
+            for w in range(4):
+                for o in range(4):
+                    prog, nx = emit_program("TOWER_K%d_T2P_W%dO%d" % (k, w, o), to_poly[w * 32 + 8 * o:w * 32 + 8 * o + 8], 128,
+                                            "IN(%d)", "OUT(%d)", "tower planes -> poly dword %d, bits %d..%d" % (w, 8 * o, 8 * o + 7))
+                    out.append(prog)
         # tower -> poly, output chunks of 32 poly planes (one dword of the element), inputs = 128 tower planes
         for w in range(4):
             prog, nx = emit_program("TOWER_K%d_T2P_W%d" % (k, w), to_poly[w * 32:(w + 1) * 32], 128, "IN(%d)", "OUT(%d)",
