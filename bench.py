@@ -415,11 +415,12 @@ def main():
     }
     if logn == 20:
         # the roofline that actually binds this kernel: VALU instruction issue.  Static instruction counts of the
-        # hand-written arithmetic (csrc/fields.h): 84 per Montgomery product, 27 per add+sub pair; per element and
+        # hand-written arithmetic (csrc/fields.h): 71 per Montgomery product (one-step REDC), 27 per add+sub pair; per element and
         # transform: 9 products (4 + 4 butterfly products of the two 1024-point passes, skipping w^0, + 1 inter-pass
-        # twiddle) and 10 butterfly add/sub pairs.  Peak: 36 T lane-instr/s measured with tools/ubench.hip
-        # (profiles/r01/ubench_int_rates.txt).
-        instr = nelem * (9 * 84 + 10 * 27)
+        # twiddle) and 10 butterfly add/sub pairs.  Peak: 36 T lane-instr/s, the measured rate of the slow instruction class
+        # (carry adds, v_mad_u64_u32) that this kernel consists of (tools/ubench.hip, profiles/r02/ubench_int_rates.txt).  The
+        # counter-based figure (SQ_INSTS_VALU x 4 cycles / SIMD cycles = 96 %) is in profiles/r02/pmc_fp_fft_tile_redc1.json.
+        instr = nelem * (9 * 71 + 10 * 27)
         rate = instr / (dev_ms / args.steps * 1e-3) / 1e12
         out["alu_roofline"] = {"bound": "valu", "achieved": rate, "peak": 36.0, "unit": "T lane-instr/s", "frac": rate / 36.0,
                                "basis": "static instruction counts x live kernel time"}
