@@ -101,6 +101,8 @@ int lfgpu_fp128_rs_encode_rows(lfgpu_ctx* ctx, size_t nrow, size_t n, size_t m, 
  * No omega argument: the interpolation does not depend on which 2^k-th root of unity carries the convolution (the
  * device uses the reference's root of order 2^31, mdoc_zk.cc:82-88). */
 int lfgpu_fp256_rs_encode_rows(lfgpu_ctx* ctx, size_t nrow, size_t n, size_t m, void* d_T, size_t ld);
+/* Host-buffer form: what GpuReedSolomon<Fp256Base>::interpolate (include/lfgpu_adapters.h) forwards to. */
+int lfgpu_fp256_rs_encode_rows_host(lfgpu_ctx* ctx, size_t nrow, size_t n, size_t m, void* h_T, size_t ld);
 
 /* ---- K5 + K6: Merkle column commitment ------------------------------------
  * Replaces MerkleCommitment::commit (lib/merkle/merkle_commitment.h:50-64) with

@@ -59,8 +59,8 @@ class Context {
 };
 
 template <class Field>
-constexpr int field_id() {
-  return Field::kCharacteristicTwo ? LFGPU_FIELD_GF2_128 : LFGPU_FIELD_FP128;
+constexpr int field_id() {  // GF2_128<k>, Fp128, Fp256Base (the only 32-byte field on the path: mdoc_zk.cc:70-76)
+  return Field::kCharacteristicTwo ? LFGPU_FIELD_GF2_128 : Field::kBytes == 32 ? LFGPU_FIELD_P256 : LFGPU_FIELD_FP128;
 }
 template <class Field>
 constexpr int subfield_log_bits() {
@@ -78,7 +78,7 @@ constexpr int subfield_log_bits() {
 template <class Field>
 class GpuReedSolomon {
   using Elt = typename Field::Elt;
-  static_assert(sizeof(Elt) == 16, "16-byte field elements");
+  static_assert(sizeof(Elt) == (field_id<Field>() == LFGPU_FIELD_P256 ? 32 : 16), "in-memory Elt image = kBytes");
 
  public:
   GpuReedSolomon(size_t n, size_t m, const Context& c, const uint64_t omega[2], uint64_t omega_order)
@@ -91,6 +91,8 @@ class GpuReedSolomon {
     if constexpr (Field::kCharacteristicTwo) {
       check(c_.get(), lfgpu_gf2128_rs_encode_rows_host(c_.get(), subfield_log_bits<Field>(), nrow, n_, m_, T, ld),
             "lfgpu_gf2128_rs_encode_rows_host");
+    } else if constexpr (field_id<Field>() == LFGPU_FIELD_P256) {
+      check(c_.get(), lfgpu_fp256_rs_encode_rows_host(c_.get(), nrow, n_, m_, T, ld), "lfgpu_fp256_rs_encode_rows_host");
     } else {
       check(c_.get(), lfgpu_fp128_rs_encode_rows_host(c_.get(), nrow, n_, m_, omega_, omega_order_, T, ld),
             "lfgpu_fp128_rs_encode_rows_host");
@@ -107,13 +109,15 @@ class GpuReedSolomon {
 template <class Field>
 class GpuReedSolomonFactory {
  public:
-  // GF2_128: GpuReedSolomonFactory(ctx).  Fp128: pass the root of unity (Montgomery image)
-  // and its order, as FFTConvolutionFactory does (lib/algebra/convolution.h:114-115).
+  // GF2_128 and Fp256Base: GpuReedSolomonFactory(ctx).  Fp128: pass the root of unity (Montgomery image)
+  // and its order, as FFTConvolutionFactory does (lib/algebra/convolution.h:114-115).  Fp256Base replaces
+  // ReedSolomonFactory<Fp256Base, FFTExtConvolutionFactory<Fp256Base, Fp2<Fp256Base>>> (mdoc_zk.cc:75-76,485-487); the
+  // interpolation does not depend on the extension-field root, so none is passed.
   explicit GpuReedSolomonFactory(const Context& c, const typename Field::Elt* omega = nullptr,
                                  uint64_t omega_order = 0)
       : c_(c), omega_order_(omega_order) {
     omega_[0] = omega_[1] = 0;
-    if (omega) std::memcpy(omega_, omega, 16);
+    if (omega && field_id<Field>() == LFGPU_FIELD_FP128) std::memcpy(omega_, omega, 16);
   }
   std::unique_ptr<GpuReedSolomon<Field>> make(size_t n, size_t m) const {
     return std::make_unique<GpuReedSolomon<Field>>(n, m, c_, omega_, omega_order_);

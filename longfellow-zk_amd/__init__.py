@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "lfgpu_gf2128_rs_encode_rows", "lfgpu_gf2128_rs_encode_tableau", "lfgpu_fp128_rs_encode_rows", "lfgpu_fp256_rs_encode_rows", "lfgpu_column_commit", "lfgpu_column_leaves", "lfgpu_merkle_build_tree",
     "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
     "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_field_binop", "lfgpu_fp128_fft_host", "lfgpu_gf2128_lch14_fft_host",
-    "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_fp128_rs_encode_rows_host", "lfgpu_column_commit_host",
+    "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_fp128_rs_encode_rows_host", "lfgpu_fp256_rs_encode_rows_host", "lfgpu_column_commit_host",
     "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_layout_rows", "lfgpu_ligero_encode_rows", "lfgpu_ligero_prover_from_slab", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
     "lfgpu_ligero_inner_product_rows", "lfgpu_ligero_dot_proof_sparse",
     "lfgpu_ligero_quadratic_proof", "lfgpu_ligero_open", "lfgpu_ligero_tableau", "lfgpu_ligero_free",
@@ -116,6 +116,7 @@ def load_library():
         "lfgpu_gf2128_lch14_fft_host": [vp, ci, ci, C.c_uint, u64, vp],
         "lfgpu_gf2128_rs_encode_rows_host": [vp, ci, sz, sz, sz, vp, sz],
         "lfgpu_fp128_rs_encode_rows_host": [vp, sz, sz, sz, pu64, u64, vp, sz],
+        "lfgpu_fp256_rs_encode_rows_host": [vp, sz, sz, sz, vp, sz],
         "lfgpu_column_commit_host": [vp, ci, sz, sz, sz, sz, vp, vp, vp, vp],
         "lfgpu_ligero_param_init": [C.POINTER(LigeroParam), ci, ci, sz, sz, sz, sz, sz],
         "lfgpu_ligero_commit": [vp, ci, ci, C.POINTER(LigeroParam), vp, sz, vp, RNG_FN, vp, vp, C.POINTER(vp)],

@@ -215,7 +215,7 @@ extern "C" int lfgpu_column_commit_host(lfgpu_ctx* c, int field, size_t nrow, si
                                         const void* h_T, const uint8_t* h_nonces, uint8_t* h_layers,
                                         uint8_t root_out[32]) {
   if (!c || !h_T || !h_nonces) return LFGPU_ERR_ARG;
-  size_t tb = nrow * ld * 16, nb = ncols * 32, lb = 2 * ncols * 32;
+  size_t tb = nrow * ld * (field == LFGPU_FIELD_P256 ? 32 : 16), nb = ncols * 32, lb = 2 * ncols * 32;
   void* d = nullptr;
   LF_TRY(lf_scratch(c, tb + nb + lb + 64, &d));
   u8* dT = (u8*)d;

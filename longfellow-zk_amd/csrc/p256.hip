@@ -266,6 +266,23 @@ extern "C" int lfgpu_fp256_rs_encode_rows(lfgpu_ctx* c, size_t nrow, size_t n, s
   return LFGPU_OK;
 }
 
+// Host-buffer form (what GpuReedSolomon<Fp256Base>::interpolate calls from inside the reference's LigeroProver): stage in
+// scratch4 -- the encode itself works through scratch2.
+extern "C" int lfgpu_fp256_rs_encode_rows_host(lfgpu_ctx* c, size_t nrow, size_t n, size_t m, void* h_T, size_t ld) {
+  if (!c || (!h_T && nrow)) return lf_fail(c, LFGPU_ERR_ARG, "fp256_rs_encode_rows_host: null argument");
+  if (n == 0 || m < n || ld < m) return lf_fail(c, LFGPU_ERR_ARG, "fp256_rs_encode_rows_host: need 0 < n <= m <= ld");
+  if (nrow == 0 || m == n) return LFGPU_OK;
+  LF_HIP(c, hipSetDevice(c->device));
+  void* d = nullptr;
+  const size_t bytes = ((nrow - 1) * ld + m) * sizeof(elt32_t);
+  LF_TRY(lf_scratch4(c, bytes, &d));
+  LF_HIP(c, hipMemcpyAsync(d, h_T, bytes, hipMemcpyHostToDevice, c->stream));
+  LF_TRY(lfgpu_fp256_rs_encode_rows(c, nrow, n, m, d, ld));
+  LF_HIP(c, hipMemcpyAsync(h_T, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  return LFGPU_OK;
+}
+
 // ------------------------------------------------------------------ column hash, 32-byte elements
 // leaf_j = SHA256(nonce_j[32] || canon(T[0][col0+j]) || ... ), canon = 32 little-endian bytes of the value out of
 // Montgomery form.  One lane per column; a row read is two coalesced 16 B/lane loads per lane.

@@ -6,6 +6,8 @@
                                    subfield boundary 85112, block_enc 4151) in the reference's LFC1 wire format
   tests/golden/mdoc_hash.w.xz      its witness as the reference's prover holds it at prove time (mdoc_tests[0], age_over_18,
                                    MACs and MAC key filled in: lib/circuits/mdoc/mdoc_zk.cc:466-515)
+  tests/golden/mdoc_sig.lfc1.xz    the mdoc SIGNATURE circuit (Fp256Base, 32-byte elements, block_enc 4096) in LFC1
+  tests/golden/mdoc_sig.w.xz       its witness at prove time (in-memory Elt images, 32 bytes each)
   tests/golden/mdoc.json           sizes of both circuits (hash: GF2_128, signature: Fp256Base), the Ligero parameters, and
                                    length + SHA-256 of ZkProof::write for the hash circuit proved stand-alone (transcript
                                    "test", LCG RandomEngine seed 100, rate 7, 132 queries), with the reference's timings
@@ -37,6 +39,14 @@ def main():
             print(dst, os.path.getsize(dst))
         wire = open(pre + ".hash.zkwire", "rb").read()
         info["hash"].update(zk_wire_bytes=len(wire), zk_wire_sha256=hashlib.sha256(wire).hexdigest(), zk_root=wire[:32].hex())
+        for ext in (".sig.lfc1", ".sig.w"):
+            data = open(pre + ext, "rb").read()
+            dst = os.path.join(OUT, "mdoc_sig" + ext[4:] + ".xz")
+            with open(dst, "wb") as f:
+                f.write(lzma.compress(data, preset=9 | lzma.PRESET_EXTREME))
+            print(dst, os.path.getsize(dst))
+        wire = open(pre + ".sig.zkwire", "rb").read()
+        info["sig"].update(zk_wire_bytes=len(wire), zk_wire_sha256=hashlib.sha256(wire).hexdigest(), zk_root=wire[:32].hex())
     with open(os.path.join(OUT, "mdoc.json"), "w") as f:
         json.dump(info, f)
     print(info)

@@ -4,7 +4,8 @@
 // lib/circuits/mdoc/mdoc_zk_test.cc:652-685), so that the witnesses are the ones a real proof uses, and then proves the
 // HASH circuit (GF2_128; public inputs, subfield boundary, block_enc 4151) stand-alone with ZkProver under the fixtures'
 // transcript ("test") and LCG engine.  Dumps: the hash circuit in LFC1, its final witness, length + SHA-256 of the
-// stand-alone proof's wire bytes; for the signature circuit (Fp256Base) its size figures and LigeroParam.
+// stand-alone proof's wire bytes; the same for the signature circuit (Fp256Base, 32-byte elements), proved stand-alone with the
+// reference's ReedSolomonFactory<Fp256Base, FFTExtConvolutionFactory> (mdoc_zk.cc:75-76).
 // The reference's mdoc_zk.cc is compiled where it lies by including it (its helpers have no header).
 #include <chrono>
 #include <cstdio>
@@ -121,13 +122,35 @@ int mdoc_fixture(const std::string& prefix) {
   auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   size_t nterms = 0;
   for (auto& ly : c_hash->l) nterms += ly.nterms();
+
+  // ---- the signature circuit (Fp256Base) alone, same convention
+  std::vector<uint8_t> sb;
+  CircuitWriter<Fp256Base> sw(p256_base, P256_ID);
+  sw.to_bytes(*c_sig, sb);
+  dump(prefix + ".sig.lfc1", sb.data(), sb.size());
+  dump(prefix + ".sig.w", W_sig.v_.data(), 32 * c_sig->ninputs);
+  Transcript ts2((const uint8_t*)"test", 4);
+  LcgRng rng3(100);
+  ZkProof<Fp256Base> sz(*c_sig, r, req, zk_spec->block_enc_sig);
+  ZkProver<Fp256Base, RSFactory_b> sp(*c_sig, p256_base, rsf_b);
+  auto t3 = std::chrono::steady_clock::now();
+  sp.commit(sz, W_sig, ts2, rng3);
+  auto t4 = std::chrono::steady_clock::now();
+  if (!sp.prove(sz, W_sig, ts2)) return 11;
+  auto t5 = std::chrono::steady_clock::now();
+  std::vector<uint8_t> swire;
+  sz.write(swire, p256_base);
+  dump(prefix + ".sig.zkwire", swire.data(), swire.size());
+  size_t snterms = 0;
+  for (auto& ly : c_sig->l) snterms += ly.nterms();
   printf(
       "{\"spec\": 0, \"hash\": {\"nl\": %zu, \"ninputs\": %zu, \"npub_in\": %zu, \"subfield_boundary\": %zu, \"nterms\": %zu, \"lfc1_bytes\": %zu, "
       "\"block_enc\": %zu, \"nrow\": %zu, \"block\": %zu, \"nw\": %zu, \"rate\": %zu, \"nreq\": %zu, \"ref_commit_ms\": %.2f, \"ref_prove_ms\": %.2f}, "
-      "\"sig\": {\"nl\": %zu, \"ninputs\": %zu, \"npub_in\": %zu, \"block_enc\": %zu, \"nrow\": %zu, \"block\": %zu, \"dblock\": %zu, \"nw\": %zu}}\n",
+      "\"sig\": {\"nl\": %zu, \"ninputs\": %zu, \"npub_in\": %zu, \"block_enc\": %zu, \"nrow\": %zu, \"block\": %zu, \"dblock\": %zu, \"nw\": %zu, "
+      "\"subfield_boundary\": %zu, \"nterms\": %zu, \"lfc1_bytes\": %zu, \"ref_commit_ms\": %.2f, \"ref_prove_ms\": %.2f}}\n",
       c_hash->nl, c_hash->ninputs, c_hash->npub_in, c_hash->subfield_boundary, nterms, cb.size(), hz.param.block_enc, hz.param.nrow, hz.param.block,
       hz.param.nw, r, req, ms(t0, t1), ms(t1, t2), c_sig->nl, c_sig->ninputs, c_sig->npub_in, sig_zk.param.block_enc, sig_zk.param.nrow,
-      sig_zk.param.block, sig_zk.param.dblock, sig_zk.param.nw);
+      sig_zk.param.block, sig_zk.param.dblock, sig_zk.param.nw, c_sig->subfield_boundary, snterms, sb.size(), ms(t3, t4), ms(t4, t5));
   return 0;
 }
 }  // namespace proofs

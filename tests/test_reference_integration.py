@@ -1,7 +1,7 @@
 """The integration of INTEGRATION.md section 2a, executed: the reference's OWN ZkProver / LigeroProver / sumcheck prover /
 transcript / ZkProof::write, compiled from /root/reference in the build container with one template argument swapped --
 InterpolatorFactory = lfgpu::GpuReedSolomonFactory<Field> (include/lfgpu_adapters.h) -- and linked against liblfgpu.so
-(oracle/ref_zk_adapters.cc -> oracle/_ref/zk_adapters[_fp], built by `make -C oracle ref`).  On the GPU box the binary
+(oracle/ref_zk_adapters.cc -> oracle/_ref/zk_adapters[_fp|_p256], built by `make -C oracle ref`).  On the GPU box the binary
 proves the fixture circuits with every Reed-Solomon row extension running in the HIP kernels; its wire bytes must hash to
 what the unmodified reference produced (tests/golden/flatsha_*.json)."""
 import json
@@ -37,3 +37,32 @@ def test_reference_zkprover_with_gpu_interpolator_emits_reference_wire_bytes(ste
     assert res["wire_bytes"] == info["zk_wire_bytes"]
     assert res["wire_sha256"] == info["zk_wire_sha256"]
     assert (res["block_enc"], res["nrow"]) == (info["zk_block_enc"], info["zk_nrow"])
+
+
+@pytest.mark.gpu
+def test_reference_zkprover_p256_signature_circuit_with_gpu_interpolator():
+    """BASELINE config 5, the signature half: the reference's ZkProver<Fp256Base, .> on the REAL mdoc signature circuit
+    (kZkSpecs[0]: 21 layers, 481 833 terms, 32-byte elements, block_enc 4096, 19 rows) and the witness of a real proof
+    (oracle/ref_mdoc.cc), with lfgpu::GpuReedSolomonFactory<Fp256Base> in place of
+    ReedSolomonFactory<Fp256Base, FFTExtConvolutionFactory> (mdoc_zk.cc:75-76): every row extension of commit, dot_proof and
+    quadratic_proof runs in csrc/p256.hip.  The wire bytes must hash to what the unmodified reference produced; the timings
+    the binary prints go beside the reference's own (tests/golden/mdoc.json: 206 ms commit + 507 ms prove on one CPU
+    thread, most of it in the RFFT twiddle rebuilds of SURVEY section 8 f2)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "zk_adapters_p256")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/zk_adapters_p256 not built (needs the reference sources: make -C oracle ref in the build container)")
+    info = json.load(open(os.path.join(GOLD, "mdoc.json")))["sig"]
+    with tempfile.TemporaryDirectory() as td:
+        paths = []
+        for ext in (".lfc1", ".w"):
+            p = os.path.join(td, "x" + ext)
+            with open(p, "wb") as f:
+                f.write(lzma.decompress(open(os.path.join(GOLD, "mdoc_sig" + ext + ".xz"), "rb").read()))
+            paths.append(p)
+        out = subprocess.run([exe] + paths + [str(info["block_enc"])], capture_output=True, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    res = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    print("mdoc signature circuit, reference prover + GPU Reed-Solomon:", res, "reference alone:", info["ref_commit_ms"], info["ref_prove_ms"])
+    assert res["wire_bytes"] == info["zk_wire_bytes"]
+    assert res["wire_sha256"] == info["zk_wire_sha256"]
+    assert (res["block_enc"], res["nrow"]) == (info["block_enc"], info["nrow"])
