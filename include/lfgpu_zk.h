@@ -42,6 +42,11 @@ typedef struct lfgpu_transcript_ops {
    * copy, zk_prover.h:117-124); release with free_clone */
   void* (*clone)(void* user);
   void (*free_clone)(void* user);
+  /* the element writes for a field whose to_bytes_field image is not 16 bytes (Fp256Base, field id 1: nbytes = 32):
+   * tag 1 || image[nbytes];  tag 2 || u64 count || count images.  The 16-byte fields never call them; a transcript that
+   * only serves those may leave them NULL (the P-256 prover then fails with LFGPU_ERR_ARG). */
+  void (*write_elt_sized)(void* user, const uint8_t* elt, size_t nbytes);
+  void (*write_elt_array_sized)(void* user, const uint8_t* elts, size_t n, size_t nbytes);
 } lfgpu_transcript_ops;
 
 /* built-in transcript, byte-identical to the reference's (pinned by the ZK fixtures and FIPS-197/180-4 vectors) */

@@ -57,7 +57,8 @@ SC_ROUND_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.
 class TranscriptOps(C.Structure):
     """lfgpu_transcript_ops (include/lfgpu_zk.h): the caller's Fiat-Shamir transcript behind function pointers"""
     _fields_ = [("user", C.c_void_p), ("write_bytes", C.c_void_p), ("write_elt", C.c_void_p),
-                ("write_elt_array", C.c_void_p), ("gen_bytes", C.c_void_p), ("clone", C.c_void_p), ("free_clone", C.c_void_p)]
+                ("write_elt_array", C.c_void_p), ("gen_bytes", C.c_void_p), ("clone", C.c_void_p), ("free_clone", C.c_void_p),
+                ("write_elt_sized", C.c_void_p), ("write_elt_array_sized", C.c_void_p)]  # 32-byte elements (Fp256Base)
 
 
 class CircuitInfo(C.Structure):

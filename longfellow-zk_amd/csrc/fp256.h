@@ -5,6 +5,8 @@
 // 32 bytes.  p = 2^256 - 2^224 + 2^192 + 2^96 - 1, so p = -1 (mod 2^96): -p^-1 mod 2^32 = 1 and a reduction step needs no
 // multiplication -- with m = the low limb, m * p = m * 2^256 - m * 2^224 + m * 2^192 + m * 2^96 - m (fp_p256.h:43-62).
 #pragma once
+#include <string.h>
+
 #include "fields.h"
 
 struct alignas(16) elt32_t {
@@ -16,8 +18,8 @@ struct alignas(16) fp2_t {  // Fp2<Fp256Base>::Elt {re, im}
 
 #define FIELD_P256 1  // FieldID P256_ID (lib/proto/circuit_io.h:24-36)
 
-LF_HD inline elt32_t e32_zero() { return elt32_t{{0, 0, 0, 0}}; }
-LF_HD inline bool e32_eq(const elt32_t& a, const elt32_t& b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
+LF_HD elt32_t e32_zero() { return elt32_t{{0, 0, 0, 0}}; }
+LF_HD bool e32_eq(const elt32_t& a, const elt32_t& b) { return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3]; }
 
 // p as 8 x u32 limbs
 #define P256_W0 0xFFFFFFFFu
@@ -30,24 +32,24 @@ LF_HD inline bool e32_eq(const elt32_t& a, const elt32_t& b) { return a.l[0] == 
 #define P256_W7 0xFFFFFFFFu
 
 namespace fp256_detail {
-LF_HD inline void to_w(const elt32_t& a, u32 (&w)[8]) {
+LF_HD void to_w(const elt32_t& a, u32 (&w)[8]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     w[2 * i] = (u32)a.l[i];
     w[2 * i + 1] = (u32)(a.l[i] >> 32);
   }
 }
-LF_HD inline elt32_t from_w(const u32 (&w)[8]) {
+LF_HD elt32_t from_w(const u32 (&w)[8]) {
   elt32_t r;
 #pragma unroll
   for (int i = 0; i < 4; ++i) r.l[i] = (u64)w[2 * i] | ((u64)w[2 * i + 1] << 32);
   return r;
 }
-LF_HD inline u32 pw(int i) {
+LF_HD u32 pw(int i) {
   return i == 0 ? P256_W0 : i == 1 ? P256_W1 : i == 2 ? P256_W2 : i == 3 ? P256_W3 : i == 4 ? P256_W4 : i == 5 ? P256_W5 : i == 6 ? P256_W6 : P256_W7;
 }
 // r = a - p if a >= p (a < 2p given with its carry-out bit `hi`)
-LF_HD inline void cond_sub_p(u32 (&t)[8], u32 hi) {
+LF_HD void cond_sub_p(u32 (&t)[8], u32 hi) {
   u32 d[8];
   u64 br = 0;
 #pragma unroll
@@ -62,7 +64,7 @@ LF_HD inline void cond_sub_p(u32 (&t)[8], u32 hi) {
 }
 }  // namespace fp256_detail
 
-LF_HD inline elt32_t fp256_add(const elt32_t& a, const elt32_t& b) {
+LF_HD elt32_t fp256_add(const elt32_t& a, const elt32_t& b) {
   u32 x[8], y[8], t[8];
   fp256_detail::to_w(a, x);
   fp256_detail::to_w(b, y);
@@ -76,7 +78,7 @@ LF_HD inline elt32_t fp256_add(const elt32_t& a, const elt32_t& b) {
   fp256_detail::cond_sub_p(t, (u32)c);
   return fp256_detail::from_w(t);
 }
-LF_HD inline elt32_t fp256_sub(const elt32_t& a, const elt32_t& b) {
+LF_HD elt32_t fp256_sub(const elt32_t& a, const elt32_t& b) {
   u32 x[8], y[8], t[8];
   fp256_detail::to_w(a, x);
   fp256_detail::to_w(b, y);
@@ -97,11 +99,11 @@ LF_HD inline elt32_t fp256_sub(const elt32_t& a, const elt32_t& b) {
   }
   return fp256_detail::from_w(t);
 }
-LF_HD inline elt32_t fp256_neg(const elt32_t& a) { return fp256_sub(e32_zero(), a); }
+LF_HD elt32_t fp256_neg(const elt32_t& a) { return fp256_sub(e32_zero(), a); }
 
 // Montgomery product a * b / 2^256 mod p: operand scanning over 32-bit limbs, one multiplication-free reduction step per
 // limb (m = t[0]: t += m * p, then drop the zero limb).
-LF_HD inline elt32_t fp256_mul(const elt32_t& a, const elt32_t& b) {
+LF_HD elt32_t fp256_mul(const elt32_t& a, const elt32_t& b) {
   u32 x[8], y[8];
   fp256_detail::to_w(a, x);
   fp256_detail::to_w(b, y);
@@ -146,16 +148,107 @@ LF_HD inline elt32_t fp256_mul(const elt32_t& a, const elt32_t& b) {
 }
 
 // canonical value (to_bytes_field = from_montgomery, little-endian bytes): x * 1 / R
-LF_HD inline elt32_t fp256_canon(const elt32_t& a) { return fp256_mul(a, elt32_t{{1, 0, 0, 0}}); }
+LF_HD elt32_t fp256_canon(const elt32_t& a) { return fp256_mul(a, elt32_t{{1, 0, 0, 0}}); }
 
 // ---- Fp2<Fp256Base>, i^2 = -1 (lib/algebra/fp2.h:77-95: Karatsuba, 3 products)
-LF_HD inline fp2_t fp2_add(const fp2_t& a, const fp2_t& b) { return fp2_t{fp256_add(a.re, b.re), fp256_add(a.im, b.im)}; }
-LF_HD inline fp2_t fp2_sub(const fp2_t& a, const fp2_t& b) { return fp2_t{fp256_sub(a.re, b.re), fp256_sub(a.im, b.im)}; }
-LF_HD inline fp2_t fp2_mul(const fp2_t& a, const fp2_t& y) {
+LF_HD fp2_t fp2_add(const fp2_t& a, const fp2_t& b) { return fp2_t{fp256_add(a.re, b.re), fp256_add(a.im, b.im)}; }
+LF_HD fp2_t fp2_sub(const fp2_t& a, const fp2_t& b) { return fp2_t{fp256_sub(a.re, b.re), fp256_sub(a.im, b.im)}; }
+LF_HD fp2_t fp2_mul(const fp2_t& a, const fp2_t& y) {
   const elt32_t p0 = fp256_mul(a.re, y.re), p1 = fp256_mul(a.im, y.im);
   const elt32_t a01 = fp256_add(a.re, a.im), y01 = fp256_add(y.re, y.im);
   fp2_t r;
   r.re = fp256_sub(p0, p1);
   r.im = fp256_sub(fp256_sub(fp256_mul(a01, y01), p0), p1);
   return r;
+}
+
+// ---- device loads / stores (two 16-byte accesses per element)
+#if defined(__HIPCC__)
+__device__ inline elt32_t ld32(const elt32_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  elt32_t r;
+  r.l[0] = (u64)a.x | ((u64)a.y << 32);
+  r.l[1] = (u64)a.z | ((u64)a.w << 32);
+  r.l[2] = (u64)b.x | ((u64)b.y << 32);
+  r.l[3] = (u64)b.z | ((u64)b.w << 32);
+  return r;
+}
+__device__ inline void st32(elt32_t* p, const elt32_t& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4((u32)v.l[0], (u32)(v.l[0] >> 32), (u32)v.l[1], (u32)(v.l[1] >> 32));
+  q[1] = make_uint4((u32)v.l[2], (u32)(v.l[2] >> 32), (u32)v.l[3], (u32)(v.l[3] >> 32));
+}
+#endif
+
+LF_HD bool e32_is_zero(const elt32_t& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+
+// sum_k acc[k] 2^(32k) mod p for eight 64-bit limb accumulators (sums of 32-bit limbs of canonical residues; images add, so
+// the result of summing Montgomery images is the image of the sum).  S = lo + 2^256 hi with hi < 2^40:
+// S = (lo mod p) + hi * R, and hi * R mod p is the Montgomery image of hi = fp256_mul(hi, R^2).
+LF_HD elt32_t fp256_reduce_limbs(const u64 acc[8], const elt32_t& rsq) {
+  u32 w[8];
+  u64 c = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    c += (u64)(u32)acc[k];
+    if (k) c += acc[k - 1] >> 32;
+    w[k] = (u32)c;
+    c >>= 32;
+  }
+  c += acc[7] >> 32;  // the part above 2^256
+  fp256_detail::cond_sub_p(w, 0);  // lo < 2^256 < 2p
+  const elt32_t lo = fp256_detail::from_w(w);
+  return fp256_add(lo, fp256_mul(elt32_t{{c, 0, 0, 0}}, rsq));
+}
+
+// ---- host-side helpers (FpGeneric: to_montgomery, of_scalar, invertf, of_bytes_field, sample)
+inline elt32_t h256_rsq() {  // R^2 mod p
+  static const elt32_t v = [] {
+    elt32_t x{{1, 0, 0, 0}};
+    for (int i = 0; i < 512; ++i) x = fp256_add(x, x);
+    return x;
+  }();
+  return v;
+}
+inline elt32_t h256_to_mont(const elt32_t& raw) { return fp256_mul(raw, h256_rsq()); }
+inline elt32_t h256_of_scalar(u64 u) { return h256_to_mont(elt32_t{{u, 0, 0, 0}}); }
+inline elt32_t h256_inv(const elt32_t& x) {  // x^(p-2)
+  const u64 e[4] = {0xFFFFFFFFFFFFFFFDull, 0x00000000FFFFFFFFull, 0, 0xFFFFFFFF00000001ull};
+  elt32_t r = h256_of_scalar(1), b = x;
+  for (int i = 0; i < 256; ++i) {
+    if ((e[i / 64] >> (i % 64)) & 1) r = fp256_mul(r, b);
+    b = fp256_mul(b, b);
+  }
+  return r;
+}
+inline bool h256_fits(const elt32_t& raw) {  // raw < p
+  const u64 P[4] = {0xFFFFFFFFFFFFFFFFull, 0x00000000FFFFFFFFull, 0, 0xFFFFFFFF00000001ull};
+  for (int i = 3; i >= 0; --i) {
+    if (raw.l[i] < P[i]) return true;
+    if (raw.l[i] > P[i]) return false;
+  }
+  return false;
+}
+// of_bytes_field (fp_generic.h:344-351): 32 little-endian bytes of the canonical value -> Montgomery; false if >= p
+inline bool h256_of_bytes(const uint8_t in[32], elt32_t& e) {
+  elt32_t raw;
+  memcpy(&raw, in, 32);
+  if (!h256_fits(raw)) return false;
+  e = h256_to_mont(raw);
+  return true;
+}
+inline void h256_to_bytes(const elt32_t& e, uint8_t out[32]) {  // to_bytes_field (:378-380)
+  const elt32_t r = fp256_canon(e);
+  memcpy(out, &r, 32);
+}
+// FpGeneric::sample (:360-371): exact_bits = 256, so 32 bytes per attempt, rejected when >= p
+template <class Fill>
+inline elt32_t h256_sample(Fill fill) {
+  for (;;) {
+    uint8_t b[32];
+    fill(b, 32);
+    elt32_t e;
+    if (h256_of_bytes(b, e)) return e;
+  }
 }

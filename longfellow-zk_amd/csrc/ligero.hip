@@ -41,7 +41,8 @@ static size_t merkle_tree_len(size_t n) {  // merkle_tree.h:62-70
 // estimate, or SIZE_MAX where the reference rejects the layout.
 static size_t ligero_layout(lfgpu_ligero_param* p, int field, int k, size_t e) {
   const size_t max_lg_size = 28, max_size = (size_t)1 << max_lg_size;
-  const size_t field_bytes = 16, subfield_bytes = field == LFGPU_FIELD_GF2_128 ? (((size_t)1 << k) / 8) : 16;
+  const size_t field_bytes = field == LFGPU_FIELD_P256 ? 32 : 16;  // Field::kBytes / kSubFieldBytes
+  const size_t subfield_bytes = field == LFGPU_FIELD_GF2_128 ? (((size_t)1 << k) / 8) : field_bytes;
   const size_t nw = p->nw, nq = p->nq, rateinv = p->rateinv, nreq = p->nreq;
   p->r = nreq;
   p->block_enc = e;

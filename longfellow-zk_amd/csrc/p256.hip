@@ -20,22 +20,7 @@
 
 #define P256_LOCAL_LOG 9  // points per LDS tile of the local FFT kernel: 512 x 64 B = 32 KiB
 
-LF_HD inline fp2_t fp2_conj(const fp2_t& a) { return fp2_t{a.re, fp256_neg(a.im)}; }
-__device__ inline elt32_t ld32(const elt32_t* p) {
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-  const uint4 a = q[0], b = q[1];
-  elt32_t r;
-  r.l[0] = (u64)a.x | ((u64)a.y << 32);
-  r.l[1] = (u64)a.z | ((u64)a.w << 32);
-  r.l[2] = (u64)b.x | ((u64)b.y << 32);
-  r.l[3] = (u64)b.z | ((u64)b.w << 32);
-  return r;
-}
-__device__ inline void st32(elt32_t* p, const elt32_t& v) {
-  uint4* q = reinterpret_cast<uint4*>(p);
-  q[0] = make_uint4((u32)v.l[0], (u32)(v.l[0] >> 32), (u32)v.l[1], (u32)(v.l[1] >> 32));
-  q[1] = make_uint4((u32)v.l[2], (u32)(v.l[2] >> 32), (u32)v.l[3], (u32)(v.l[3] >> 32));
-}
+LF_HD fp2_t fp2_conj(const fp2_t& a) { return fp2_t{a.re, fp256_neg(a.im)}; }
 __device__ inline fp2_t ldc(const fp2_t* p) { return fp2_t{ld32(&p->re), ld32(&p->im)}; }
 __device__ inline void stc(fp2_t* p, const fp2_t& v) {
   st32(&p->re, v.re);
@@ -142,26 +127,7 @@ __global__ void p256_rs_post_kernel(u32 n, u32 m, u32 P, u32 nrow, const elt32_t
   if (r1 < nrow) st32(&T[(size_t)r1 * ld + i], fp256_mul(l, z.im));
 }
 
-// host-side field helpers
-static elt32_t h256_rsq() {  // R^2 mod p
-  static const elt32_t v = [] {
-    elt32_t x{{1, 0, 0, 0}};
-    for (int i = 0; i < 512; ++i) x = fp256_add(x, x);
-    return x;
-  }();
-  return v;
-}
-static elt32_t h256_to_mont(const elt32_t& raw) { return fp256_mul(raw, h256_rsq()); }
-static elt32_t h256_of_scalar(u64 u) { return h256_to_mont(elt32_t{{u, 0, 0, 0}}); }
-static elt32_t h256_inv(const elt32_t& x) {  // x^(p-2)
-  const u64 e[4] = {0xFFFFFFFFFFFFFFFDull, 0x00000000FFFFFFFFull, 0, 0xFFFFFFFF00000001ull};
-  elt32_t r = h256_of_scalar(1), b = x;
-  for (int i = 0; i < 256; ++i) {
-    if ((e[i / 64] >> (i % 64)) & 1) r = fp256_mul(r, b);
-    b = fp256_mul(b, b);
-  }
-  return r;
-}
+// host-side field helpers: fp256.h
 static elt32_t h256_dec(const char* s) {
   elt32_t r = e32_zero();
   const elt32_t ten = h256_of_scalar(10);

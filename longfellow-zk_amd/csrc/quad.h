@@ -1,0 +1,34 @@
+// quad.h -- an uploaded circuit layer (lfgpu_quad) as quad.hip, sumcheck.hip and zk256.hip see it.
+#pragma once
+#include <vector>
+
+#include "ctx.h"
+
+#define BG_THREADS 1024  // Quad::bind_g kernels: long runs fold inside the block (runfold.h); d_runoff is per block of this size
+
+struct __attribute__((aligned(16))) corner4 {
+  u32 g, h0, h1, vi;
+};
+
+struct lfgpu_quad {
+  lfgpu_ctx* c;
+  int field;
+  size_t n, nk, nv;
+  size_t hmax;        // largest hand index (h0 or h1) of any corner: every consumer needs nw > hmax
+  corner4* d_morton;  // canonical order
+  corner4* d_bygate;  // sorted by g (stable)
+  u32* d_goff;        // nv + 1 offsets into d_bygate
+  elt_t* d_kvec;      // nk constants (field 1, Fp256Base: nk 32-byte elements behind the same pointer)
+  // the run structure of the canonical order (which terms share a hand pair) depends on the circuit only: block offsets of
+  // the run heads and the HQUAD size of Quad::bind_g are computed once at upload
+  u32* d_runoff;      // per block of BG_THREADS terms: number of run heads before it
+  u32* d_nh;          // device copy of nh0
+  size_t nh0;
+  // the same holds for every HQuad::bind_h of the layer's sumcheck: filled by the first proof for the round-hands that
+  // run on the multi-kernel path (per-block output offsets + the size after the bind), reused by every later proof
+  struct BindShape {
+    u32* d_off;
+    size_t n_in, n_out;
+  };
+  std::vector<BindShape> bind_shape;  // indexed by round-hand
+};

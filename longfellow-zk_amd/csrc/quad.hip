@@ -15,38 +15,12 @@
 #include <numeric>
 
 #include "ctx.h"
+#include "quad.h"
 #include "runfold.h"
+#include "zkint.h"
 #include <chrono>
 
 #define QD_THREADS 256
-#define BG_THREADS 1024  // Quad::bind_g kernels: long runs fold inside the block (runfold.h)
-
-struct __attribute__((aligned(16))) corner4 {
-  u32 g, h0, h1, vi;
-};
-
-struct lfgpu_quad {
-  lfgpu_ctx* c;
-  int field;
-  size_t n, nk, nv;
-  size_t hmax;        // largest hand index (h0 or h1) of any corner: every consumer needs nw > hmax
-  corner4* d_morton;  // canonical order
-  corner4* d_bygate;  // sorted by g (stable)
-  u32* d_goff;        // nv + 1 offsets into d_bygate
-  elt_t* d_kvec;      // nk constants
-  // the run structure of the canonical order (which terms share a hand pair) depends on the circuit only: block offsets of
-  // the run heads and the HQUAD size of Quad::bind_g are computed once at upload
-  u32* d_runoff;      // per block of BG_THREADS terms: number of run heads before it
-  u32* d_nh;          // device copy of nh0
-  size_t nh0;
-  // the same holds for every HQuad::bind_h of the layer's sumcheck: filled by the first proof for the round-hands that
-  // run on the multi-kernel path (per-block output offsets + the size after the bind), reused by every later proof
-  struct BindShape {
-    u32* d_off;
-    size_t n_in, n_out;
-  };
-  std::vector<BindShape> bind_shape;  // indexed by round-hand
-};
 
 // ---- K11: V[g] = sum_{terms of g} kvec[vi] * W[h1] * W[h0]; assert-zero terms must vanish
 template <int F>
@@ -268,7 +242,8 @@ extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32
                                  lfgpu_quad** out) {
   if (!c || !out || n == 0 || !g || !h0 || !h1 || !vi || !h_kvec || nk == 0 || nv == 0)
     return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: bad argument (Quad n > 0, quad.h:86)");
-  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: field");
+  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128 && field != LFGPU_FIELD_P256) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: field");
+  const size_t esz = field == LFGPU_FIELD_P256 ? 32 : 16;  // h_kvec: nk elements of the field's in-memory size
   if (n > 0xfffffff0u || nv > 0xfffffff0u) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: too large");
   LF_HIP(c, hipSetDevice(c->device));
   std::vector<corner4> mort(n), byg(n);
@@ -298,11 +273,11 @@ extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32
   q->d_runoff = q->d_nh = nullptr;
   q->nh0 = 0;
   bool ok = hipMalloc((void**)&q->d_morton, n * 16) == hipSuccess && hipMalloc((void**)&q->d_bygate, n * 16) == hipSuccess &&
-            hipMalloc((void**)&q->d_goff, (nv + 1) * 4) == hipSuccess && hipMalloc((void**)&q->d_kvec, nk * 16) == hipSuccess;
+            hipMalloc((void**)&q->d_goff, (nv + 1) * 4) == hipSuccess && hipMalloc((void**)&q->d_kvec, nk * esz) == hipSuccess;
   ok = ok && hipMemcpy(q->d_morton, mort.data(), n * 16, hipMemcpyHostToDevice) == hipSuccess &&
        hipMemcpy(q->d_bygate, byg.data(), n * 16, hipMemcpyHostToDevice) == hipSuccess &&
        hipMemcpy(q->d_goff, goff.data(), (nv + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
-       hipMemcpy(q->d_kvec, h_kvec, nk * 16, hipMemcpyHostToDevice) == hipSuccess;
+       hipMemcpy(q->d_kvec, h_kvec, nk * esz, hipMemcpyHostToDevice) == hipSuccess;
   if (!ok) {
     lfgpu_quad_free(q);
     return lf_fail(c, LFGPU_ERR_NOMEM, "quad_upload: device allocation / copy failed");
@@ -330,6 +305,7 @@ extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32
 // one layer, asynchronously: assert-zero failures are OR-ed into *d_fail (device); the caller clears and reads it
 int lf_eval_quad_async(lfgpu_quad* q, const void* d_W, void* d_V, int* d_fail) {
   lfgpu_ctx* c = q->c;
+  if (q->field == LFGPU_FIELD_P256) return lf256_eval_quad_async(q, d_W, d_V, d_fail);
   u32 nb = (u32)((q->nv + QD_THREADS - 1) / QD_THREADS);
   QD_DISPATCH(q->field, eval_quad_kernel, dim3(nb), dim3(QD_THREADS), (u32)q->nv, (const u32*)q->d_goff,
               (const corner4*)q->d_bygate, (const elt_t*)q->d_kvec, (const elt_t*)d_W, (elt_t*)d_V, d_fail);
@@ -396,6 +372,7 @@ int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G
                    const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out) {
   if (!q || !alpha || !beta || !d_hc_out || !d_vc_out || (logv && (!h_G0 || !h_G1))) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = q->c;
+  if (q->field == LFGPU_FIELD_P256) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "quad_bind_g: Fp256Base layers are bound inside the ZK driver (zk256.hip)");
   if (logv > 40 || ((size_t)1 << logv) < q->nv) return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_g: 2^logv < nv");
   LF_HIP(c, hipSetDevice(c->device));
   const int field = q->field;
@@ -481,6 +458,7 @@ int lf_quad_bind_gh_all_enqueue(lfgpu_quad* q, size_t logv, const void* h_G0, co
                                 const uint64_t beta[2], size_t logw, size_t nw, const void* h_H0, const void* h_H1, u64* d_acc) {
   if (!q || !alpha || !beta || !d_acc || (logv && (!h_G0 || !h_G1)) || (logw && (!h_H0 || !h_H1))) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = q->c;
+  if (q->field == LFGPU_FIELD_P256) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "quad_bind_gh_all: not built for Fp256Base");
   if (logv > 40 || logw > 40 || ((size_t)1 << logv) < q->nv || nw == 0 || ((size_t)1 << logw) < nw || nw <= q->hmax)
     return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_gh_all: table sizes (nw must exceed the largest hand index %zu)", q->hmax);
   LF_HIP(c, hipSetDevice(c->device));
@@ -546,6 +524,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     return q ? lf_fail(q->c, LFGPU_ERR_ARG, "sumcheck_layer: bad argument (nw must exceed the largest hand index)") : LFGPU_ERR_ARG;
   lfgpu_ctx* c = q->c;
   const int field = q->field;
+  if (field == LFGPU_FIELD_P256) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "sumcheck_layer: Fp256Base layers run inside the ZK driver (zk256.hip)");
   LF_HIP(c, hipSetDevice(c->device));
   const HostField F(c, field);
   // device state: HQUAD ping-pong, QW, out-of-place buffer for the first bind of hand 0 (context scratch: no

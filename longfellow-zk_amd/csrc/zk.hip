@@ -16,8 +16,10 @@
 #include <memory>
 
 #include "../../include/lfgpu_zk.h"
+#include "fp256.h"
 #include "fs_crypto.h"
 #include "hostfield.h"
+#include "zkint.h"
 
 extern "C" int lfgpu_raw_eq2(lfgpu_ctx*, int, size_t, size_t, const void*, const void*, const uint64_t*, void*);
 
@@ -47,14 +49,14 @@ struct lfgpu_transcript {  // Transcript + FSPRF (lib/random/transcript.h:33-190
     tag_len(0, n);
     if (n) upd(d, n);
   }
-  void write_elt(const uint8_t* e) {  // tag 1 || image (:136-140)
+  void write_elt(const uint8_t* e, size_t nbytes = 16) {  // tag 1 || image (:136-140)
     const uint8_t t = 1;
     upd(&t, 1);
-    upd(e, 16);
+    upd(e, nbytes);
   }
-  void write_elt_array(const uint8_t* e, size_t n) {  // tag 2 || u64 count || images (:144-152)
+  void write_elt_array(const uint8_t* e, size_t n, size_t nbytes = 16) {  // tag 2 || u64 count || images (:144-152)
     tag_len(2, n);
-    if (n) upd(e, 16 * n);
+    if (n) upd(e, nbytes * n);
   }
   void bytes(uint8_t* out, size_t n) {
     if (!prf) {  // key = SHA-256 of a copy of the running state (:160-172)
@@ -121,6 +123,8 @@ static void op_write_bytes(void* u, const uint8_t* d, size_t n) { ((lfgpu_transc
 static void op_write_elt(void* u, const uint8_t* e) { ((lfgpu_transcript*)u)->write_elt(e); }
 static void op_write_arr(void* u, const uint8_t* e, size_t n) { ((lfgpu_transcript*)u)->write_elt_array(e, n); }
 static void op_bytes(void* u, uint8_t* o, size_t n) { ((lfgpu_transcript*)u)->bytes(o, n); }
+static void op_write_elt_sized(void* u, const uint8_t* e, size_t nb) { ((lfgpu_transcript*)u)->write_elt(e, nb); }
+static void op_write_arr_sized(void* u, const uint8_t* e, size_t n, size_t nb) { ((lfgpu_transcript*)u)->write_elt_array(e, n, nb); }
 static void* op_clone(void* u) {  // Transcript::clone copies the hash state only; the PRF restarts (:95-99)
   lfgpu_transcript* t = new (std::nothrow) lfgpu_transcript();
   if (t) t->sha = ((lfgpu_transcript*)u)->sha;
@@ -135,6 +139,8 @@ void lfgpu_transcript_get_ops(lfgpu_transcript* t, lfgpu_transcript_ops* ops) {
   ops->gen_bytes = op_bytes;
   ops->clone = op_clone;
   ops->free_clone = op_free;
+  ops->write_elt_sized = op_write_elt_sized;
+  ops->write_elt_array_sized = op_write_arr_sized;
 }
 }  // extern "C"
 
@@ -213,20 +219,6 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 }  // namespace
 
 // ------------------------------------------------------------------ circuit
-struct lfgpu_circuit {
-  lfgpu_ctx* c = nullptr;
-  lfgpu_circuit_info info{};
-  struct Layer {
-    size_t logw, nw, nterms;
-    lfgpu_quad* q;
-  };
-  std::vector<Layer> layers;
-  ~lfgpu_circuit() {
-    for (auto& l : layers)
-      if (l.q) lfgpu_quad_free(l.q);
-  }
-};
-
 extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t len, lfgpu_circuit** out) {
   if (!c || !b || !out) return LFGPU_ERR_ARG;
   size_t pos = 0;
@@ -242,18 +234,22 @@ extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t le
   size_t fid, nv, nc, npub, sfb, nin, nl, nk;
   if (!num(&fid) || !num(&nv) || !num(&nc) || !num(&npub) || !num(&sfb) || !num(&nin) || !num(&nl) || !num(&nk))
     return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated header");
-  if (fid != LFGPU_FIELD_GF2_128 && fid != LFGPU_FIELD_FP128)
-    return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "LFC1: field id %zu (the ZK driver handles GF2_128 = 4 and Fp128 = 6)", fid);
+  if (fid != LFGPU_FIELD_GF2_128 && fid != LFGPU_FIELD_FP128 && fid != LFGPU_FIELD_P256)
+    return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "LFC1: field id %zu (the ZK driver handles GF2_128 = 4, Fp128 = 6 and Fp256Base = 1)", fid);
   const int field = (int)fid;
+  const size_t esz = field == LFGPU_FIELD_P256 ? 32 : 16;  // Field::kBytes
   if (nc != 1) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "LFC1: nc = %zu copies (logc must be 0)", nc);
   // CircuitReader::read_header's sanity checks (lib/proto/circuit_reader.h:104-110): an oversized subfield_boundary would
   // mark every witness row subfield-only, including the rows that hold the full-field sumcheck pads
   if (npub > nin || sfb > nin || nv == 0 || nl == 0 || nl > 10000 /* CircuitIO::kMaxLayers */) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: inconsistent header");
-  if (!need(16 * nk)) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated constant table");
-  std::vector<elt_t> kvec(nk ? nk : 1);
-  for (size_t i = 0; i < nk; ++i)  // of_bytes_field: 16 little-endian bytes (Fp128: canonical value -> Montgomery)
-    if (!elt_of_bytes(field, b + pos + 16 * i, kvec[i])) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: constant %zu is not a field element", i);
-  pos += 16 * nk;
+  if (nk > (len - pos) / esz) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated constant table");
+  std::vector<elt_t> kvec((nk ? nk : 1) * (esz / 16));  // Fp256Base: nk 32-byte elements in the same storage
+  for (size_t i = 0; i < nk; ++i) {  // of_bytes_field: kBytes little-endian bytes (prime fields: canonical value -> Montgomery)
+    const bool fits = field == LFGPU_FIELD_P256 ? h256_of_bytes(b + pos + 32 * i, reinterpret_cast<elt32_t*>(kvec.data())[i])
+                                                : elt_of_bytes(field, b + pos + 16 * i, kvec[i]);
+    if (!fits) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: constant %zu is not a field element", i);
+  }
+  pos += esz * nk;
   std::unique_ptr<lfgpu_circuit> C(new lfgpu_circuit());
   C->c = c;
   size_t nterms = 0, nout = nv;
@@ -315,6 +311,7 @@ extern "C" int lfgpu_circuit_free(lfgpu_circuit* C) {
 struct lfgpu_zk_prover {
   lfgpu_ctx* c = nullptr;
   const lfgpu_circuit* C = nullptr;
+  Zk256* z256 = nullptr;  // Fp256Base circuits: the whole prover lives in zk256.hip
   lfgpu_ligero_param param{};
   size_t npub = 0, n_witness = 0, pad_size = 0;
   struct LayerPad {  // Proof-shaped pad (zk_prover.h:152-188): hp[hand][round] = {t0, t2}, wc[2]
@@ -343,6 +340,7 @@ struct lfgpu_zk_prover {
   void* h_V = nullptr;  // pinned: outputs (nv elements) then the assert-zero flag, read back without blocking the host
   double ms[6] = {0, 0, 0, 0, 0, 0};
   ~lfgpu_zk_prover() {
+    if (z256) zk256_free(z256);
     if (lp) lfgpu_ligero_free(lp);
     for (void* p : d_in)
       if (p) (void)hipFree(p);
@@ -593,6 +591,11 @@ extern "C" int lfgpu_zk_prover_new(lfgpu_ctx* c, const lfgpu_circuit* C, size_t 
   std::unique_ptr<lfgpu_zk_prover> zk(new lfgpu_zk_prover());
   zk->c = c;
   zk->C = C;
+  if (C->info.field == LFGPU_FIELD_P256) {
+    LF_TRY(zk256_new(c, C, rateinv, nreq, block_enc, &zk->z256));
+    *out = zk.release();
+    return LFGPU_OK;
+  }
   zk->npub = C->info.npub_in;
   zk->n_witness = C->info.ninputs - C->info.npub_in;
   for (const auto& l : C->layers) zk->pad_size += layer_size(l.logw);
@@ -615,6 +618,7 @@ extern "C" int lfgpu_zk_prover_new(lfgpu_ctx* c, const lfgpu_circuit* C, size_t 
 
 extern "C" int lfgpu_zk_prover_param(const lfgpu_zk_prover* zk, lfgpu_ligero_param* p) {
   if (!zk || !p) return LFGPU_ERR_ARG;
+  if (zk->z256) return zk256_param(zk->z256, p);
   *p = zk->param;
   return LFGPU_OK;
 }
@@ -622,6 +626,7 @@ extern "C" int lfgpu_zk_prover_param(const lfgpu_zk_prover* zk, lfgpu_ligero_par
 extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_fn rng, void* rng_user,
                                const lfgpu_transcript_ops* ts, uint8_t root_out[32]) {
   if (!zk || !h_W || !rng || !ts) return LFGPU_ERR_ARG;
+  if (zk->z256) return zk256_commit(zk->z256, h_W, rng, rng_user, ts, root_out);
   const double t0 = now_ms();
   lfgpu_ctx* c = zk->c;
   const lfgpu_circuit* C = zk->C;
@@ -678,6 +683,7 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
 
 extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_transcript_ops* tso, int* ok) {
   if (!zk || !h_W || !tso || !ok) return LFGPU_ERR_ARG;
+  if (zk->z256) return zk256_prove(zk->z256, h_W, tso, ok);
   lfgpu_ctx* c = zk->c;
   if (!zk->lp) return lf_fail(c, LFGPU_ERR_ARG, "zk_prove: must run commit before prove");
   const double t_start = now_ms();
@@ -840,6 +846,7 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
 
 extern "C" int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, size_t cap, size_t* nbytes) {
   if (!zk || !nbytes) return LFGPU_ERR_ARG;
+  if (zk->z256) return zk256_proof_write(zk->z256, buf, cap, nbytes);
   if (!zk->have_proof) return lf_fail(zk->c, LFGPU_ERR_ARG, "zk_proof_write: no proof");
   std::vector<uint8_t> o;
   const int field = zk->C->info.field;
@@ -909,6 +916,7 @@ extern "C" int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, siz
 
 extern "C" int lfgpu_zk_timings(const lfgpu_zk_prover* zk, double ms[6]) {
   if (!zk || !ms) return LFGPU_ERR_ARG;
+  if (zk->z256) return zk256_timings(zk->z256, ms);
   memcpy(ms, zk->ms, sizeof(zk->ms));
   return LFGPU_OK;
 }
@@ -1079,6 +1087,7 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
                                "wrong dot product", "quadratic_check failed"};
   if (!c || !C || C->c != c || !proof || !tso || !ok || (C->info.npub_in && !h_pub)) return LFGPU_ERR_ARG;
   *ok = 0;
+  if (C->info.field == LFGPU_FIELD_P256) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "zk_verify: no verifier for Fp256Base circuits yet (the prover is zk256.hip)");
   auto fail = [&](int w) {
     if (why_out) *why_out = kWhy[w];
     return LFGPU_OK;

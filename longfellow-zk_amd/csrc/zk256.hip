@@ -1,0 +1,1157 @@
+// zk256.hip -- ZkProver<Fp256Base, .> on the device: the P-256 base-field half of BASELINE config 5 (the mdoc signature
+// circuit: 21 layers, 4.8e5 terms, 32-byte elements, lib/circuits/mdoc/mdoc_zk.cc:70-76,485-522).
+//
+// Same algorithms as the 16-byte fields, restated over elt32_t (fp256.h) with the straightforward kernel structure -- the
+// circuit is small (layers of 2^9 .. 2^16 wires), so every round-hand is a handful of short launches and ONE read-back:
+//   eval_circuit            ProverLayers::eval_quad            lib/sumcheck/prover_layers.h:278-305
+//   bind_g                  Quad::bind_g + Eqs::raw_eq2        lib/sumcheck/quad.h:152-185, lib/arrays/eqs.h:46-80
+//   round body              ProverLayers::layer / evaluations  lib/sumcheck/prover_layers.h:230-263,357-402
+//   binds                   Dense::bind, HQuad::bind_h         lib/arrays/dense.h:70-87, lib/sumcheck/hquad.h:90-123
+//   Ligero                  LigeroProver::commit / prove       lib/ligero/ligero_prover.h:58-146,171-351
+//   driver                  ZkProver::commit / prove, ZkCommon::verifier_constraints, ZkProof::write
+//                           lib/zk/zk_prover.h:72-188, lib/zk/zk_common.h:49-136,406-439, lib/zk/zk_proof.h:90-185
+// Sums over many terms (run sums of bind_g, the QW scatter) add the 32-bit limbs of canonical residues into 64-bit integer
+// accumulators with atomics and reduce once (fp256_reduce_limbs): exact and independent of arrival order, as for Fp128.
+// Row extension and column hashing are csrc/p256.hip.  No verifier for this field yet (the parity test compares the wire
+// bytes with the reference prover's).
+#include <algorithm>
+#include <chrono>
+#include <memory>
+#include <string>
+
+#include "fp256.h"
+#include "zkint.h"
+
+typedef elt32_t E;
+#define Z_THREADS 256
+
+namespace {
+// ------------------------------------------------------------------ kernels
+__device__ __forceinline__ void limbs_atomic_add(u64* a, const E& v) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    atomicAdd(&a[2 * k], (u64)(u32)v.l[k]);
+    atomicAdd(&a[2 * k + 1], v.l[k] >> 32);
+  }
+}
+__global__ __launch_bounds__(Z_THREADS) void limb_normalize256_kernel(size_t n, const u64* __restrict__ acc, E rsq, E* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  if (i >= n) return;
+  u64 a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = acc[8 * i + k];
+  st32(&out[i], fp256_reduce_limbs(a, rsq));
+}
+
+// K11: V[g] = sum_{terms of g} kvec[vi] * W[h1] * W[h0]; assert-zero terms must vanish
+__global__ __launch_bounds__(Z_THREADS) void eval_quad256_kernel(u32 nv, const u32* __restrict__ goff, const corner4* __restrict__ terms,
+                                                                 const E* __restrict__ kvec, const E* __restrict__ W, E* __restrict__ V,
+                                                                 int* __restrict__ fail) {
+  const u32 g = blockIdx.x * Z_THREADS + threadIdx.x;
+  if (g >= nv) return;
+  E acc = e32_zero();
+  bool bad = false;
+  for (u32 t = goff[g]; t < goff[g + 1]; ++t) {
+    const corner4 cr = terms[t];
+    const E v = ld32(&kvec[cr.vi]);
+    const E p = fp256_mul(ld32(&W[cr.h1]), ld32(&W[cr.h0]));
+    if (e32_is_zero(v)) bad |= !e32_is_zero(p);
+    else acc = fp256_add(acc, fp256_mul(v, p));
+  }
+  st32(&V[g], acc);
+  if (bad) atomicOr(fail, 1);
+}
+
+// eq[i] = EQ(G0, i) + alpha EQ(G1, i), EQ(G, i) = prod_l (bit_l(i) ? G[l] : 1 - G[l]); G = G0 | G1 | 1-G0 | 1-G1
+__global__ __launch_bounds__(Z_THREADS) void raw_eq2_256_kernel(u32 logn, u32 n, const E* __restrict__ G, E alpha, E one, E* __restrict__ eq) {
+  const u32 i = blockIdx.x * Z_THREADS + threadIdx.x;
+  if (i >= n) return;
+  E e0 = one, e1 = alpha;
+  for (u32 l = 0; l < logn; ++l) {
+    const u32 bit = (i >> l) & 1;
+    e0 = fp256_mul(e0, ld32(&G[(bit ? 0 : 2 * logn) + l]));
+    e1 = fp256_mul(e1, ld32(&G[(bit ? logn : 3 * logn) + l]));
+  }
+  st32(&eq[i], fp256_add(e0, e1));
+}
+
+// Quad::bind_g: every term computes prep_v(v, beta) * eq[g]; the terms of a run (equal hand pair, contiguous in canonical
+// order) add into the run's limb accumulators
+__device__ __forceinline__ bool is_head256(const corner4* t, size_t i) { return i == 0 || t[i].h0 != t[i - 1].h0 || t[i].h1 != t[i - 1].h1; }
+__global__ __launch_bounds__(BG_THREADS) void bindg_emit256_kernel(size_t n, const corner4* __restrict__ t, const E* __restrict__ kvec,
+                                                                   const E* __restrict__ eq, E beta, const u32* __restrict__ block_off,
+                                                                   uint2* __restrict__ hc_out, u64* __restrict__ acc) {
+  __shared__ u32 wave_off[BG_THREADS / 64];
+  const size_t i = (size_t)blockIdx.x * BG_THREADS + threadIdx.x;
+  const bool valid = i < n;
+  const bool head = valid && is_head256(t, i);
+  const u64 mask = __ballot(head);
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_off[wave] = (u32)__popcll(mask);
+  __syncthreads();
+  if (!valid) return;
+  u32 ri = block_off[blockIdx.x];
+  for (u32 w = 0; w < wave; ++w) ri += wave_off[w];
+  ri += (u32)__popcll(mask & ((2ull << lane) - 1)) - 1;
+  const corner4 c0 = t[i];
+  E v = ld32(&kvec[c0.vi]);
+  if (e32_is_zero(v)) v = beta;
+  const E pv = fp256_mul(v, ld32(&eq[c0.g]));
+  if (head) hc_out[ri] = make_uint2(c0.h0, c0.h1);
+  limbs_atomic_add(acc + 8 * (size_t)ri, pv);
+}
+
+// QW[h[hand]] += v * Wother[h[1-hand]]
+__global__ __launch_bounds__(Z_THREADS) void qw_scatter256_kernel(size_t n, const uint2* __restrict__ hc, const E* __restrict__ vc, int hand,
+                                                                  const E* __restrict__ Wo, u64* __restrict__ acc) {
+  const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const uint2 h = hc[i];
+  const u32 p0 = hand ? h.y : h.x, p1 = hand ? h.x : h.y;
+  limbs_atomic_add(acc + 8 * (size_t)p0, fp256_mul(ld32(&vc[i]), ld32(&Wo[p1])));
+}
+
+__device__ __forceinline__ E block_sum256(E v, E* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (u32 s = Z_THREADS / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] = fp256_add(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  const E r = sh[0];
+  __syncthreads();
+  return r;
+}
+// partial[2b] = a0 part, partial[2b+1] = a2 part of block b (ProverLayers::evaluations :357-402)
+__global__ __launch_bounds__(Z_THREADS) void partials256_kernel(size_t n, const E* __restrict__ QW, const E* __restrict__ W, E* __restrict__ partial) {
+  __shared__ E sh[Z_THREADS];
+  const size_t nodd = n / 2;
+  E a0 = e32_zero(), a2 = e32_zero();
+  for (size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x; i < nodd; i += (size_t)gridDim.x * Z_THREADS) {
+    const E q0 = ld32(&QW[2 * i]), q1 = ld32(&QW[2 * i + 1]), w0 = ld32(&W[2 * i]), w1 = ld32(&W[2 * i + 1]);
+    a0 = fp256_add(a0, fp256_mul(q0, w0));
+    a2 = fp256_add(a2, fp256_mul(fp256_sub(q1, q0), fp256_sub(w1, w0)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && 2 * nodd < n) {  // odd tail (:381-388)
+    const E t = fp256_mul(ld32(&QW[2 * nodd]), ld32(&W[2 * nodd]));
+    a0 = fp256_add(a0, t);
+    a2 = fp256_add(a2, t);
+  }
+  a0 = block_sum256(a0, sh);
+  a2 = block_sum256(a2, sh);
+  if (threadIdx.x == 0) {
+    st32(&partial[2 * blockIdx.x], a0);
+    st32(&partial[2 * blockIdx.x + 1], a2);
+  }
+}
+__global__ __launch_bounds__(Z_THREADS) void partials_final256_kernel(u32 nblocks, const E* __restrict__ partial, E* __restrict__ out) {
+  __shared__ E sh[Z_THREADS];
+  E a0 = e32_zero(), a2 = e32_zero();
+  for (u32 b = threadIdx.x; b < nblocks; b += Z_THREADS) {
+    a0 = fp256_add(a0, ld32(&partial[2 * b]));
+    a2 = fp256_add(a2, ld32(&partial[2 * b + 1]));
+  }
+  a0 = block_sum256(a0, sh);
+  a2 = block_sum256(a2, sh);
+  if (threadIdx.x == 0) {
+    st32(&out[0], a0);
+    st32(&out[1], a2);
+  }
+}
+
+// out[i] = in[2i] + r (in[2i+1] - in[2i]); tail: in (1 - r)   (dense.h:70-87, affine.h:26-52)
+__global__ __launch_bounds__(Z_THREADS) void dense_bind256_kernel(size_t n0, E r, const E* __restrict__ in, E* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  if (i >= (n0 + 1) / 2) return;
+  const E f0 = ld32(&in[2 * i]);
+  E v;
+  if (2 * i + 1 < n0) v = fp256_add(f0, fp256_mul(fp256_sub(ld32(&in[2 * i + 1]), f0), r));
+  else v = fp256_sub(f0, fp256_mul(f0, r));
+  st32(&out[i], v);
+}
+
+// HQuad::bind_h as an order-preserving compaction (see sumcheck.hip): a term is the second half of a merged pair iff its
+// predecessor has the same other-hand corner and the even index h - 1
+__device__ __forceinline__ bool is_second256(const uint2* hc, size_t i, int hand) {
+  if (i == 0) return false;
+  const uint2 a = hc[i - 1], b = hc[i];
+  const u32 ah = hand ? a.y : a.x, ao = hand ? a.x : a.y, bh = hand ? b.y : b.x, bo = hand ? b.x : b.y;
+  return ao == bo && (ah >> 1) == (bh >> 1) && bh == ah + 1;
+}
+__global__ __launch_bounds__(Z_THREADS) void hquad_count256_kernel(size_t n, const uint2* __restrict__ hc, int hand, u32* __restrict__ block_counts) {
+  __shared__ u32 cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  const bool head = i < n && !is_second256(hc, i, hand);
+  const u64 mask = __ballot(head);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&cnt, (u32)__popcll(mask));
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = cnt;
+}
+__global__ __launch_bounds__(1024) void scan256_kernel(u32 nblocks, u32* __restrict__ block_counts, u32* __restrict__ total) {
+  __shared__ u32 sh[1024];
+  __shared__ u32 carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (u32 base = 0; base < nblocks; base += 1024) {
+    const u32 i = base + threadIdx.x;
+    const u32 v = i < nblocks ? block_counts[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (u32 off = 1; off < 1024; off <<= 1) {
+      const u32 t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const u32 incl = sh[threadIdx.x];
+    if (i < nblocks) block_counts[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ __launch_bounds__(Z_THREADS) void hquad_emit256_kernel(size_t n, const uint2* __restrict__ hc, const E* __restrict__ vc, E r, int hand,
+                                                                  const u32* __restrict__ block_off, uint2* __restrict__ hc_out, E* __restrict__ vc_out) {
+  __shared__ u32 wave_off[Z_THREADS / 64];
+  const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  const bool head = i < n && !is_second256(hc, i, hand);
+  const u64 mask = __ballot(head);
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_off[wave] = (u32)__popcll(mask);
+  __syncthreads();
+  u32 off = block_off[blockIdx.x];
+  for (u32 w = 0; w < wave; ++w) off += wave_off[w];
+  off += (u32)__popcll(mask & ((1ull << lane) - 1));
+  if (!head) return;
+  uint2 h = hc[i];
+  const u32 hh = hand ? h.y : h.x;
+  const E v0 = ld32(&vc[i]);
+  E v;
+  if (i + 1 < n && is_second256(hc, i + 1, hand)) v = fp256_add(v0, fp256_mul(fp256_sub(ld32(&vc[i + 1]), v0), r));  // affine_interpolation
+  else if ((hh & 1) == 0) v = fp256_sub(v0, fp256_mul(v0, r));                                                         // ..._nz_z
+  else v = fp256_mul(v0, r);                                                                                            // ..._z_nz
+  if (hand) h.y = hh >> 1;
+  else h.x = hh >> 1;
+  hc_out[off] = h;
+  st32(&vc_out[off], v);
+}
+
+// ---- Ligero row combinations (ligero.hip / sumcheck.hip, over 32-byte elements)
+// y[j] += sum_i u[i] T[i][j]: 64 columns x 4 row slices per workgroup
+__global__ __launch_bounds__(256) void rows_axpy256_kernel(u32 nrows, size_t n, E* __restrict__ y, const E* __restrict__ u, const E* __restrict__ T, size_t ld) {
+  __shared__ E part[4][64];
+  const u32 col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const size_t j = (size_t)blockIdx.x * 64 + col;
+  E acc = e32_zero();
+  if (j < n)
+    for (u32 i = slice; i < nrows; i += 4) acc = fp256_add(acc, fp256_mul(ld32(&T[(size_t)i * ld + j]), ld32(&u[i])));
+  part[slice][col] = acc;
+  __syncthreads();
+  if (slice == 0 && j < n) {
+    acc = ld32(&y[j]);
+    for (u32 k = 0; k < 4; ++k) acc = fp256_add(acc, part[k][col]);
+    st32(&y[j], acc);
+  }
+}
+// y[j] = T0[j] + sum_i A[i][j] T[i][j]   (dot_proof, Blas::vaxpy blas.h:71-78)
+__global__ __launch_bounds__(256) void rows_vaxpy256_kernel(u32 nrows, size_t n, const E* __restrict__ T0, const E* __restrict__ A, size_t lda,
+                                                            const E* __restrict__ T, size_t ld, E* __restrict__ y) {
+  __shared__ E part[4][64];
+  const u32 col = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const size_t j = (size_t)blockIdx.x * 64 + col;
+  E acc = e32_zero();
+  if (j < n)
+    for (u32 i = slice; i < nrows; i += 4) acc = fp256_add(acc, fp256_mul(ld32(&T[(size_t)i * ld + j]), ld32(&A[(size_t)i * lda + j])));
+  part[slice][col] = acc;
+  __syncthreads();
+  if (slice == 0 && j < n) {
+    acc = ld32(&T0[j]);
+    for (u32 k = 0; k < 4; ++k) acc = fp256_add(acc, part[k][col]);
+    st32(&y[j], acc);
+  }
+}
+// y[j] = Tq[j] + sum_i u[i] (z_i[j] - x_i[j] y_i[j])   (quadratic_proof :311-333)
+__global__ __launch_bounds__(Z_THREADS) void quad_combo256_kernel(u32 nt, size_t n, const E* __restrict__ Tq, const E* __restrict__ u, const E* __restrict__ X,
+                                                                  const E* __restrict__ Y, const E* __restrict__ Zr, size_t ld, E* __restrict__ y) {
+  const size_t j = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  if (j >= n) return;
+  E acc = ld32(&Tq[j]);
+  for (u32 i = 0; i < nt; ++i) {
+    const E t = fp256_sub(ld32(&Zr[(size_t)i * ld + j]), fp256_mul(ld32(&X[(size_t)i * ld + j]), ld32(&Y[(size_t)i * ld + j])));
+    acc = fp256_add(acc, fp256_mul(ld32(&u[i]), t));
+  }
+  st32(&y[j], acc);
+}
+// rows[i][r + j] = scale * dense[i w + j]; then rows[pos(idx)] += val (inner_product_vector + layout_Aext, ligero_param.h:382-430)
+__global__ __launch_bounds__(Z_THREADS) void a_rows_dense256_kernel(u32 r, u32 w, size_t ld, E scale, const E* __restrict__ dense, size_t n, E* __restrict__ rows) {
+  const size_t t = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  if (t >= n) return;
+  const size_t i = t / w, j = t % w;
+  st32(&rows[i * ld + r + j], fp256_mul(scale, ld32(&dense[t])));
+}
+__global__ __launch_bounds__(Z_THREADS) void a_rows_sparse256_kernel(u32 r, u32 w, size_t ld, const u64* __restrict__ idx, const E* __restrict__ val, size_t n,
+                                                                     E* __restrict__ rows) {
+  const size_t t = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  if (t >= n) return;
+  const size_t i = idx[t] / w, j = idx[t] % w;
+  E* dst = &rows[i * ld + r + j];
+  st32(dst, fp256_add(ld32(dst), ld32(&val[t])));
+}
+__global__ __launch_bounds__(Z_THREADS) void gather_columns256_kernel(u32 nrow, size_t ld, size_t col0, const E* __restrict__ T, const u64* __restrict__ idx,
+                                                                      u32 nreq, E* __restrict__ req) {
+  const u32 t = blockIdx.x * Z_THREADS + threadIdx.x;
+  if (t >= nrow * nreq) return;
+  const u32 i = t / nreq, j = t % nreq;
+  st32(&req[t], ld32(&T[(size_t)i * ld + col0 + idx[j]]));
+}
+
+inline u32 nblk(size_t n, u32 per = Z_THREADS) { return (u32)((n + per - 1) / per ? (n + per - 1) / per : 1); }
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ------------------------------------------------------------------ host field (FpGeneric over the P-256 prime)
+struct F256 {
+  E zero = e32_zero(), one, pts[3], invden[3], rsq;
+  F256() {
+    rsq = h256_rsq();
+    one = h256_of_scalar(1);
+    pts[0] = zero;  // poly_evaluation_points 0, 1, 2 (fp_generic.h:114-121)
+    pts[1] = one;
+    pts[2] = h256_of_scalar(2);
+    for (int i = 0; i < 3; ++i) {
+      E d = one;
+      for (int j = 0; j < 3; ++j)
+        if (j != i) d = fp256_mul(d, fp256_sub(pts[i], pts[j]));
+      invden[i] = h256_inv(d);
+    }
+  }
+  static E add(const E& a, const E& b) { return fp256_add(a, b); }
+  static E sub(const E& a, const E& b) { return fp256_sub(a, b); }
+  static E mul(const E& a, const E& b) { return fp256_mul(a, b); }
+  // Poly<3>::eval_monomial (lib/algebra/poly.h:100-108)
+  E eval_monomial(const E coef[3], const E& x) const { return add(mul(add(mul(coef[2], x), coef[1]), x), coef[0]); }
+  // the quadratic through (pts[i], ev[i]) at x = Poly<3>::eval_lagrange (poly.h:72-98)
+  E eval_lagrange(const E ev[3], const E& x) const {
+    E acc = zero;
+    for (int i = 0; i < 3; ++i) {
+      E num = one;
+      for (int j = 0; j < 3; ++j)
+        if (j != i) num = mul(num, sub(x, pts[j]));
+      acc = add(acc, mul(ev[i], mul(num, invden[i])));
+    }
+    return acc;
+  }
+};
+
+// ------------------------------------------------------------------ device steps
+int raw_eq2_256(lfgpu_ctx* c, const F256& F, size_t logn, size_t n, const E* G0, const E* G1, const E& alpha, E* d_eq) {
+  if (n == 0) return LFGPU_OK;
+  std::vector<E> Gt(4 * logn + 1);
+  for (size_t l = 0; l < logn; ++l) {
+    Gt[l] = G0[l];
+    Gt[logn + l] = G1[l];
+    Gt[2 * logn + l] = F.sub(F.one, G0[l]);
+    Gt[3 * logn + l] = F.sub(F.one, G1[l]);
+  }
+  void* d_G = nullptr;
+  LF_TRY(lf_scratch2(c, Gt.size() * 32 + 64, &d_G));
+  LF_HIP(c, hipMemcpyAsync(d_G, Gt.data(), Gt.size() * 32, hipMemcpyHostToDevice, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));  // Gt is a local
+  hipLaunchKernelGGL(raw_eq2_256_kernel, dim3(nblk(n)), dim3(Z_THREADS), 0, c->stream, (u32)logn, (u32)n, (const E*)d_G, alpha, F.one, d_eq);
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
+typedef void (*round256_fn)(void* user, size_t hand, size_t rnd, const E ev[3], E* chal);
+
+// One layer of the sumcheck (ProverLayers::layer): bind_g, then per round and hand the QW scatter, the two partial sums
+// (one read-back), the caller's transcript step, Dense::bind and HQuad::bind_h.  d_W (the layer's inputs) is left intact:
+// both hands bind into ping-pong buffers.
+int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, const E* G1, const E& alpha, const E& beta, size_t logw, size_t nw,
+                      const E* d_W, const E wc_in[2], round256_fn round, void* user, E wc_out[2], E* g_out /*[2][logw]*/, E* bound_quad) {
+  lfgpu_ctx* c = q->c;
+  if (nw == 0 || logw > 40 || nw > ((size_t)1 << logw) || nw <= q->hmax) return lf_fail(c, LFGPU_ERR_ARG, "sumcheck_layer256: nw must exceed the largest hand index");
+  if (logv > 40 || ((size_t)1 << logv) < q->nv) return lf_fail(c, LFGPU_ERR_ARG, "sumcheck_layer256: 2^logv < nv");
+  const size_t nt = q->n, nh0 = q->nh0, half = (nw + 1) / 2;
+  const u32 nbp = std::min<u32>(nblk(nw / 2), 256);
+  // scratch: eq | run accumulators / QW accumulators | hc[2] | vc[2] | QW | 4 half hand buffers | partials | out
+  const size_t acc_n = std::max(nh0, nw);
+  const size_t bytes = q->nv * 32 + acc_n * 64 + 2 * nh0 * 8 + 2 * nh0 * 32 + nw * 32 + 4 * half * 32 + 2 * 256 * 32 + 64 + 1024;
+  void* sc = nullptr;
+  LF_TRY(lf_scratch(c, bytes, &sc));
+  uint8_t* b = (uint8_t*)sc;
+  E* d_eq = (E*)b;                     b += q->nv * 32;
+  u64* acc = (u64*)b;                  b += acc_n * 64;
+  uint2* hc[2] = {(uint2*)b, (uint2*)(b + nh0 * 8)};  b += 2 * nh0 * 8;
+  b = (uint8_t*)(((uintptr_t)b + 31) & ~(uintptr_t)31);
+  E* vc[2] = {(E*)b, (E*)b + nh0};     b += 2 * nh0 * 32;
+  E* qw = (E*)b;                       b += nw * 32;
+  E* wb[2][2] = {{(E*)b, (E*)b + half}, {(E*)b + 2 * half, (E*)b + 3 * half}};  b += 4 * half * 32;
+  E* partial = (E*)b;                  b += 2 * 256 * 32;
+  E* d_out = (E*)b;
+  // Quad::bind_g
+  LF_TRY(raw_eq2_256(c, F, logv, q->nv, G0, G1, alpha, d_eq));
+  LF_HIP(c, hipMemsetAsync(acc, 0, nh0 * 64, c->stream));
+  hipLaunchKernelGGL(bindg_emit256_kernel, dim3(nblk(nt, BG_THREADS)), dim3(BG_THREADS), 0, c->stream, nt, (const corner4*)q->d_morton, (const E*)q->d_kvec,
+                     (const E*)d_eq, beta, (const u32*)q->d_runoff, hc[0], acc);
+  hipLaunchKernelGGL(limb_normalize256_kernel, dim3(nblk(nh0)), dim3(Z_THREADS), 0, c->stream, nh0, (const u64*)acc, F.rsq, vc[0]);
+  LF_HIP(c, hipGetLastError());
+  size_t nh = nh0;
+  int cur = 0;
+  E sum = F.add(wc_in[0], F.mul(alpha, wc_in[1]));
+  const E* WH[2] = {d_W, d_W};
+  size_t nW[2] = {nw, nw};
+  int wsel[2] = {0, 0};
+  if (q->bind_shape.size() < 2 * logw) q->bind_shape.resize(2 * logw, lfgpu_quad::BindShape{nullptr, 0, 0});
+  E* h_out = (E*)c->mailbox_h;
+  for (size_t rnd = 0; rnd < logw; ++rnd)
+    for (int hand = 0; hand < 2; ++hand) {
+      // QW scatter (prover_layers.h:239-243) + evaluations
+      LF_HIP(c, hipMemsetAsync(acc, 0, nW[hand] * 64, c->stream));
+      if (nh) hipLaunchKernelGGL(qw_scatter256_kernel, dim3(nblk(nh)), dim3(Z_THREADS), 0, c->stream, nh, (const uint2*)hc[cur], (const E*)vc[cur], hand,
+                                 WH[1 - hand], acc);
+      hipLaunchKernelGGL(limb_normalize256_kernel, dim3(nblk(nW[hand])), dim3(Z_THREADS), 0, c->stream, nW[hand], (const u64*)acc, F.rsq, qw);
+      const u32 nb = std::min<u32>(nblk(nW[hand] / 2), nbp ? nbp : 1);
+      hipLaunchKernelGGL(partials256_kernel, dim3(nb), dim3(Z_THREADS), 0, c->stream, nW[hand], (const E*)qw, WH[hand], partial);
+      hipLaunchKernelGGL(partials_final256_kernel, dim3(1), dim3(Z_THREADS), 0, c->stream, nb, (const E*)partial, d_out);
+      LF_HIP(c, hipGetLastError());
+      LF_HIP(c, hipMemcpyAsync(h_out, d_out, 64, hipMemcpyDeviceToHost, c->stream));
+      LF_HIP(c, hipStreamSynchronize(c->stream));
+      // coef[0] = a0, coef[2] = a2, coef[1] from the running sum (prover_layers.h:390-396, logc = 0)
+      E coef[3], ev[3], r;
+      coef[0] = h_out[0];
+      coef[2] = h_out[1];
+      coef[1] = F.sub(F.sub(F.sub(sum, coef[0]), coef[0]), coef[2]);
+      for (int k = 0; k < 3; ++k) ev[k] = F.eval_monomial(coef, F.pts[k]);
+      round(user, (size_t)hand, rnd, ev, &r);
+      g_out[hand * logw + rnd] = r;
+      sum = F.eval_lagrange(ev, r);
+      // Dense::bind of this hand, HQuad::bind_h
+      E* dst = wb[hand][wsel[hand]];
+      hipLaunchKernelGGL(dense_bind256_kernel, dim3(nblk((nW[hand] + 1) / 2)), dim3(Z_THREADS), 0, c->stream, nW[hand], r, WH[hand], dst);
+      WH[hand] = dst;
+      wsel[hand] ^= 1;
+      nW[hand] = (nW[hand] + 1) / 2;
+      if (nh) {  // the merge structure of this round-hand is a circuit constant: kept from the first proof on
+        lfgpu_quad::BindShape& bs = q->bind_shape[2 * rnd + hand];
+        const u32 nbh = nblk(nh);
+        if (!(bs.d_off && bs.n_in == nh)) {
+          if (bs.d_off) (void)hipFree(bs.d_off);
+          bs = lfgpu_quad::BindShape{nullptr, nh, 0};
+          if (hipMalloc((void**)&bs.d_off, (size_t)nbh * 4) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "sumcheck_layer256: bind offsets");
+          u32* total = (u32*)((uint8_t*)c->mailbox_d + 64);
+          hipLaunchKernelGGL(hquad_count256_kernel, dim3(nbh), dim3(Z_THREADS), 0, c->stream, nh, (const uint2*)hc[cur], hand, bs.d_off);
+          hipLaunchKernelGGL(scan256_kernel, dim3(1), dim3(1024), 0, c->stream, nbh, bs.d_off, total);
+          u32 tot = 0;
+          LF_HIP(c, hipMemcpyAsync(&tot, total, 4, hipMemcpyDeviceToHost, c->stream));
+          LF_HIP(c, hipStreamSynchronize(c->stream));
+          bs.n_out = tot;
+        }
+        hipLaunchKernelGGL(hquad_emit256_kernel, dim3(nbh), dim3(Z_THREADS), 0, c->stream, nh, (const uint2*)hc[cur], (const E*)vc[cur], r, hand,
+                           (const u32*)bs.d_off, hc[1 - cur], vc[1 - cur]);
+        nh = bs.n_out;
+        cur = 1 - cur;
+      }
+      LF_HIP(c, hipGetLastError());
+    }
+  // W[0][0], W[1][0] and the bound quad (the HQUAD has shrunk to one entry)
+  if (nh != 1) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: HQUAD did not fold to one entry (%zu)", nh);
+  LF_HIP(c, hipMemcpyAsync(&h_out[0], WH[0], 32, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipMemcpyAsync(&h_out[1], WH[1], 32, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipMemcpyAsync(&h_out[2], vc[cur], 32, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  wc_out[0] = h_out[0];
+  wc_out[1] = h_out[1];
+  if (bound_quad) *bound_quad = h_out[2];
+  return LFGPU_OK;
+}
+}  // namespace
+
+int lf256_eval_quad_async(lfgpu_quad* q, const void* d_W, void* d_V, int* d_fail) {
+  lfgpu_ctx* c = q->c;
+  hipLaunchKernelGGL(eval_quad256_kernel, dim3(nblk(q->nv)), dim3(Z_THREADS), 0, c->stream, (u32)q->nv, (const u32*)q->d_goff, (const corner4*)q->d_bygate,
+                     (const E*)q->d_kvec, (const E*)d_W, (E*)d_V, d_fail);
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
+// ------------------------------------------------------------------ Ligero over 32-byte elements (one GPU holds all rows)
+namespace {
+struct Lig256 {
+  lfgpu_ctx* c = nullptr;
+  lfgpu_ligero_param p{};
+  E* d_T = nullptr;  // [nrow][block_enc]
+  uint8_t* d_layers = nullptr;
+  std::vector<uint8_t> nonces;
+  E* row(size_t i) const { return d_T + i * p.block_enc; }
+  ~Lig256() {
+    if (d_T) {  // the tableau holds the witness, the pads and the blinding rows: scrub it
+      (void)hipMemsetAsync(d_T, 0, p.nrow * p.block_enc * 32, c->stream);
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(d_T);
+    }
+    if (d_layers) (void)hipFree(d_layers);
+  }
+};
+
+// the host half of LigeroProver::commit (ligero_prover.h:171-270 + merkle_commitment.h:52-54): every RandomEngine draw in the
+// reference's order (FpGeneric::sample and sample_subfield are the same function, fp_generic.h:360-376)
+int lig256_layout(const lfgpu_ligero_param& p, const E* W, const size_t* lqc, lfgpu_rng_fn rng, void* user, E* H, uint8_t* nonces, char* err) {
+  const size_t hw = p.dblock;
+  auto draw = [&] { return h256_sample([&](uint8_t* b, size_t n) { rng(user, b, n); }); };
+  auto elts = [&](E* out, size_t n) {
+    for (size_t i = 0; i < n; ++i) out[i] = draw();
+  };
+  auto row = [&](size_t i) { return H + i * hw; };
+  std::fill(H, H + p.nrow * hw, e32_zero());
+  elts(row(p.ildt), p.block);  // layout_blinding_rows (:171-205)
+  {
+    E* d = row(p.idot);
+    elts(d, p.dblock);
+    E sum = e32_zero();
+    for (size_t j = 0; j < p.w; ++j) sum = fp256_add(sum, d[p.r + j]);
+    d[p.r] = fp256_sub(d[p.r], sum);
+  }
+  {
+    E* q = row(p.iquad);
+    elts(q, p.dblock);
+    for (size_t j = 0; j < p.w; ++j) q[p.r + j] = e32_zero();
+  }
+  for (size_t i = 0; i < p.nwrow; ++i) {  // layout_witness_rows (:207-231)
+    E* t = row(i + p.iw);
+    elts(t, p.r);
+    const size_t max_col = std::min(p.w, p.nw - i * p.w);
+    for (size_t j = 0; j < max_col; ++j) t[p.r + j] = W[i * p.w + j];
+  }
+  const size_t iqx = p.iq, iqy = iqx + p.nqtriples, iqz = iqy + p.nqtriples;  // layout_quadratic_rows (:233-270)
+  for (size_t i = 0; i < p.nqtriples; ++i) {
+    elts(row(iqx + i), p.r);
+    elts(row(iqy + i), p.r);
+    elts(row(iqz + i), p.r);
+    for (size_t j = 0; j < p.w && j + i * p.w < p.nq; ++j) {
+      const size_t* l = &lqc[3 * (j + i * p.w)];
+      if (l[0] >= p.nw || l[1] >= p.nw || l[2] >= p.nw) {
+        snprintf(err, 256, "ligero_commit: lqc index >= nw");
+        return LFGPU_ERR_ARG;
+      }
+      if (!e32_eq(fp256_mul(W[l[0]], W[l[1]]), W[l[2]])) {
+        snprintf(err, 256, "ligero_commit: invalid quadratic constraints (ligero_prover.h:259-260)");
+        return LFGPU_ERR_ASSERT;
+      }
+      row(iqx + i)[j + p.r] = W[l[0]];
+      row(iqy + i)[j + p.r] = W[l[1]];
+      row(iqz + i)[j + p.r] = W[l[2]];
+    }
+  }
+  rng(user, nonces, 32 * p.block_ext);  // MerkleCommitment::commit: one nonce per leaf, after the layout
+  return LFGPU_OK;
+}
+
+int lig256_commit(lfgpu_ctx* c, const lfgpu_ligero_param& p, const E* W, const size_t* lqc, lfgpu_rng_fn rng, void* user, uint8_t root[32], Lig256** out) {
+  if (p.ildt != 0 || p.idot != 1 || p.iquad != 2 || p.iw != 3) return lf_fail(c, LFGPU_ERR_ARG, "ligero256: row order");
+  std::unique_ptr<Lig256> L(new Lig256());
+  L->c = c;
+  L->p = p;
+  L->nonces.resize(32 * p.block_ext);
+  std::vector<E> H(p.nrow * p.dblock);
+  char err[256] = {0};
+  const int rc = lig256_layout(p, W, lqc, rng, user, H.data(), L->nonces.data(), err);
+  if (rc) return lf_fail(c, rc, "%s", err);
+  const size_t ld = p.block_enc;
+  if (hipMalloc((void**)&L->d_T, p.nrow * ld * 32) != hipSuccess || hipMalloc((void**)&L->d_layers, 2 * p.block_ext * 32) != hipSuccess)
+    return lf_fail(c, LFGPU_ERR_NOMEM, "ligero256: tableau alloc");
+  LF_HIP(c, hipMemcpy2DAsync(L->d_T, ld * 32, H.data(), p.dblock * 32, p.dblock * 32, p.nrow, hipMemcpyHostToDevice, c->stream));
+  // rows IDOT / IQUAD carry dblock values, every other row block (ligero_prover.h:175,184,203,210,237)
+  LF_TRY(lfgpu_fp256_rs_encode_rows(c, 1, p.block, p.block_enc, L->row(0), ld));
+  LF_TRY(lfgpu_fp256_rs_encode_rows(c, 2, p.dblock, p.block_enc, L->row(1), ld));
+  LF_TRY(lfgpu_fp256_rs_encode_rows(c, p.nrow - 3, p.block, p.block_enc, L->row(3), ld));
+  void* d_non = nullptr;
+  LF_TRY(lf_scratch3(c, p.block_ext * 32, &d_non));
+  LF_HIP(c, hipMemcpyAsync(d_non, L->nonces.data(), p.block_ext * 32, hipMemcpyHostToDevice, c->stream));
+  LF_TRY(lfgpu_column_commit(c, LFGPU_FIELD_P256, p.nrow, ld, p.dblock, p.block_ext, L->d_T, d_non, L->d_layers, root));
+  LF_HIP(c, hipStreamSynchronize(c->stream));  // H is a local
+  *out = L.release();
+  return LFGPU_OK;
+}
+
+int lig256_low_degree(Lig256* L, const E* u, E* y) {  // low_degree_proof (:281-291)
+  lfgpu_ctx* c = L->c;
+  const lfgpu_ligero_param& p = L->p;
+  void *dy = nullptr, *du = nullptr;
+  LF_TRY(lf_scratch3(c, p.block * 32, &dy));
+  LF_TRY(lf_scratch2(c, p.nwqrow * 32 + 64, &du));
+  LF_HIP(c, hipMemcpyAsync(dy, L->row(p.ildt), p.block * 32, hipMemcpyDeviceToDevice, c->stream));
+  LF_HIP(c, hipMemcpyAsync(du, u, p.nwqrow * 32, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(rows_axpy256_kernel, dim3(nblk(p.block, 64)), dim3(256), 0, c->stream, (u32)p.nwqrow, p.block, (E*)dy, (const E*)du,
+                     (const E*)L->row(p.iw), p.block_enc);
+  LF_HIP(c, hipGetLastError());
+  return lfgpu_memcpy_d2h(c, y, dy, p.block * 32);
+}
+
+// dot_proof (:293-309) with A given as inner_product_vector builds it: a dense block scale * dense[0..ndense) over the first
+// flat positions plus sparse (index, value) terms (strictly increasing indices)
+int lig256_dot(Lig256* L, const E* d_dense, size_t ndense, const E& scale, const uint64_t* idx, const E* val, size_t nsparse, E* y) {
+  lfgpu_ctx* c = L->c;
+  const lfgpu_ligero_param& p = L->p;
+  const size_t lda = p.dblock;
+  void* sc = nullptr;
+  LF_TRY(lf_scratch3(c, (p.nwqrow * lda + p.dblock) * 32 + 64, &sc));
+  E* dA = (E*)sc;
+  E* dy = dA + p.nwqrow * lda;
+  LF_HIP(c, hipMemsetAsync(dA, 0, p.nwqrow * lda * 32, c->stream));
+  if (ndense) hipLaunchKernelGGL(a_rows_dense256_kernel, dim3(nblk(ndense)), dim3(Z_THREADS), 0, c->stream, (u32)p.r, (u32)p.w, lda, scale, d_dense, ndense, dA);
+  if (nsparse) {
+    void* d_sp = nullptr;
+    LF_TRY(lf_scratch2(c, nsparse * 40 + 64, &d_sp));
+    E* d_val = (E*)d_sp;
+    u64* d_idx = (u64*)(d_val + nsparse);
+    LF_HIP(c, hipMemcpyAsync(d_val, val, nsparse * 32, hipMemcpyHostToDevice, c->stream));
+    LF_HIP(c, hipMemcpyAsync(d_idx, idx, nsparse * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(a_rows_sparse256_kernel, dim3(nblk(nsparse)), dim3(Z_THREADS), 0, c->stream, (u32)p.r, (u32)p.w, lda, (const u64*)d_idx, (const E*)d_val,
+                       nsparse, dA);
+    LF_HIP(c, hipGetLastError());
+    LF_HIP(c, hipStreamSynchronize(c->stream));  // the staging area is the Reed-Solomon encoder's work space next
+  }
+  LF_TRY(lfgpu_fp256_rs_encode_rows(c, p.nwqrow, p.block, p.dblock, dA, lda));
+  hipLaunchKernelGGL(rows_vaxpy256_kernel, dim3(nblk(p.dblock, 64)), dim3(256), 0, c->stream, (u32)p.nwqrow, p.dblock, (const E*)L->row(p.idot), (const E*)dA, lda,
+                     (const E*)L->row(p.iw), p.block_enc, dy);
+  LF_HIP(c, hipGetLastError());
+  return lfgpu_memcpy_d2h(c, y, dy, p.dblock * 32);
+}
+
+int lig256_quadratic(Lig256* L, const E* u, E* y0, E* y2) {  // quadratic_proof (:311-344)
+  lfgpu_ctx* c = L->c;
+  const lfgpu_ligero_param& p = L->p;
+  void* sc = nullptr;
+  LF_TRY(lf_scratch3(c, (p.nqtriples + 1 + p.dblock) * 32 + 64, &sc));
+  E* du = (E*)sc;
+  E* dy = du + p.nqtriples + 1;
+  if (p.nqtriples) LF_HIP(c, hipMemcpyAsync(du, u, p.nqtriples * 32, hipMemcpyHostToDevice, c->stream));
+  const size_t ld = p.block_enc;
+  const E* X = L->row(p.iq);
+  const E* Y = X + p.nqtriples * ld;
+  const E* Zr = Y + p.nqtriples * ld;
+  hipLaunchKernelGGL(quad_combo256_kernel, dim3(nblk(p.dblock)), dim3(Z_THREADS), 0, c->stream, (u32)p.nqtriples, p.dblock, (const E*)L->row(p.iquad), (const E*)du, X,
+                     Y, Zr, ld, dy);
+  LF_HIP(c, hipGetLastError());
+  std::vector<E> y(p.dblock);
+  LF_TRY(lfgpu_memcpy_d2h(c, y.data(), dy, p.dblock * 32));
+  for (size_t j = 0; j < p.w; ++j)
+    if (!e32_is_zero(y[p.r + j])) return lf_fail(c, LFGPU_ERR_ASSERT, "quadratic_proof: W part is nonzero");
+  memcpy(y0, y.data(), p.r * 32);
+  memcpy(y2, y.data() + p.block, (p.dblock - p.block) * 32);
+  return LFGPU_OK;
+}
+
+int lig256_open(Lig256* L, const size_t* idx, E* req, uint8_t* nonces, uint8_t* path, size_t path_cap, size_t* npath) {  // compute_req + MerkleCommitment::open
+  lfgpu_ctx* c = L->c;
+  const lfgpu_ligero_param& p = L->p;
+  for (size_t i = 0; i < p.nreq; ++i)
+    if (idx[i] >= p.block_ext) return lf_fail(c, LFGPU_ERR_ARG, "ligero_open: index out of range");
+  void *dreq = nullptr, *di = nullptr;
+  LF_TRY(lf_scratch3(c, p.nrow * p.nreq * 32, &dreq));
+  LF_TRY(lf_scratch2(c, p.nreq * 8 + 64, &di));
+  std::vector<u64> ix(idx, idx + p.nreq);
+  LF_HIP(c, hipMemcpyAsync(di, ix.data(), p.nreq * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(gather_columns256_kernel, dim3(nblk(p.nrow * p.nreq)), dim3(Z_THREADS), 0, c->stream, (u32)p.nrow, p.block_enc, p.dblock, (const E*)L->d_T,
+                     (const u64*)di, (u32)p.nreq, (E*)dreq);
+  LF_HIP(c, hipGetLastError());
+  LF_TRY(lfgpu_memcpy_d2h(c, req, dreq, p.nrow * p.nreq * 32));
+  for (size_t i = 0; i < p.nreq; ++i) memcpy(nonces + 32 * i, &L->nonces[32 * idx[i]], 32);
+  return lfgpu_merkle_open(c, p.block_ext, L->d_layers, idx, p.nreq, path, path_cap, npath);
+}
+}  // namespace
+
+// ------------------------------------------------------------------ ZkProver<Fp256Base>
+struct Zk256 {
+  lfgpu_ctx* c = nullptr;
+  const lfgpu_circuit* C = nullptr;
+  lfgpu_ligero_param param{};
+  size_t npub = 0, n_witness = 0, pad_size = 0;
+  struct LayerPad {  // Proof-shaped pad (zk_prover.h:152-188): hp[hand][2 round + {0, 1}] = {p(0), p(2)}, wc[2]
+    std::vector<E> hp[2];
+    E wc[2];
+  };
+  std::vector<LayerPad> pad, proof;
+  std::vector<E> aux;  // ProofAux::bound_quad per layer
+  std::vector<size_t> lqc;
+  Lig256* lp = nullptr;
+  uint8_t root[32] = {0};
+  std::vector<E> y_ldt, y_dot, y_q0, y_q2, req;
+  std::vector<uint8_t> nonces, path;
+  size_t npath = 0;
+  bool have_proof = false;
+  std::vector<void*> d_in;  // the layers' inputs (eval_circuit), resident for the sumcheck
+  void* d_V = nullptr;
+  void* h_V = nullptr;  // pinned: outputs then the assert-zero flag
+  void* d_eq = nullptr;  // EQ table of the input constraint
+  double ms[6] = {0, 0, 0, 0, 0, 0};
+  ~Zk256() {
+    delete lp;
+    for (void* p : d_in)
+      if (p) (void)hipFree(p);
+    if (d_V) (void)hipFree(d_V);
+    if (d_eq) (void)hipFree(d_eq);
+    if (h_V) (void)hipHostFree(h_V);
+  }
+};
+
+namespace {
+constexpr size_t kMaxBindings256 = 40;  // Proof::kMaxBindings (lib/sumcheck/circuit.h:84)
+inline size_t layer_size256(size_t logw) { return 4 * logw + 3; }  // PadLayout::layer_size (zk_common.h:210-222)
+
+struct Ts256 {  // the caller's transcript seen through the hooks
+  const lfgpu_transcript_ops* o;
+  void* u;
+  void write_bytes(const uint8_t* d, size_t n) const { o->write_bytes(u, d, n); }
+  void write_elt(const E& e) const {
+    uint8_t b[32];
+    h256_to_bytes(e, b);
+    o->write_elt_sized(u, b, 32);
+  }
+  void write_array(const E* e, size_t n) const {
+    std::vector<uint8_t> b(32 * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i) h256_to_bytes(e[i], &b[32 * i]);
+    o->write_elt_array_sized(u, b.data(), n, 32);
+  }
+  E elt() const {
+    return h256_sample([&](uint8_t* b, size_t n) { o->gen_bytes(u, b, n); });
+  }
+  size_t nat(size_t n) const {  // RandomEngine::nat (lib/random/random.h:57-87)
+    size_t l = 0, mask = 0;
+    for (size_t nn = n; nn; nn >>= 8) ++l;
+    while ((n & mask) != n) mask = (mask << 1) | 1;
+    for (;;) {
+      uint8_t b[8] = {0};
+      o->gen_bytes(u, b, l);
+      size_t r = 0;
+      for (size_t i = 0; i < l; ++i) r |= (size_t)b[i] << (8 * i);
+      r &= mask;
+      if (r < n) return r;
+    }
+  }
+  void choose(size_t n, size_t k, size_t* res) const {  // RandomEngine::choose (:89-105)
+    std::vector<size_t> A(n);
+    for (size_t i = 0; i < n; ++i) A[i] = i;
+    for (size_t i = 0; i < k; ++i) {
+      const size_t j = i + nat(n - i);
+      std::swap(A[i], A[j]);
+      res[i] = A[i];
+    }
+  }
+};
+
+struct Round256 {  // round_h of the padded prover (prover_layers.h:320-329): transmit poly - pad
+  const Ts256* tst;
+  const Zk256::LayerPad* pad;
+  Zk256::LayerPad* out;
+};
+void zk256_round_cb(void* user, size_t hand, size_t rnd, const E ev[3], E* chal) {
+  Round256* r = (Round256*)user;
+  const E t0 = fp256_sub(ev[0], r->pad->hp[hand][2 * rnd]), t2 = fp256_sub(ev[2], r->pad->hp[hand][2 * rnd + 1]);
+  r->out->hp[hand][2 * rnd] = t0;
+  r->out->hp[hand][2 * rnd + 1] = t2;
+  r->tst->write_elt(t0);
+  r->tst->write_elt(t2);
+  *chal = r->tst->elt();
+}
+
+// ZkCommon::verifier_constraints (zk_common.h:49-136) + input_constraint (:406-439) on the prover's side (aux = the bound
+// quads the sumcheck recorded): the sparse rows of A, b, and the EQ vector of the input constraint on the device
+struct LinTerm256 {
+  size_t c, w;
+  E k;
+};
+struct Constraints256 {
+  std::vector<LinTerm256> a;
+  std::vector<E> b;
+  size_t n = 0;
+};
+int build_constraints256(Zk256* z, const F256& F, const Ts256& ts, const E* pub, Constraints256& out) {
+  lfgpu_ctx* c = z->c;
+  const lfgpu_circuit* C = z->C;
+  const lfgpu_circuit_info& I = C->info;
+  const size_t nl = C->layers.size(), npub = I.npub_in;
+  std::vector<E> gh[2];
+  for (size_t i = 0; i < 2 * kMaxBindings256; ++i) (void)ts.elt();  // begin_circuit: Q, then G (only the verifier's bind uses them)
+  size_t ci = 0, pi = I.ninputs - npub;
+  E claims[2] = {F.zero, F.zero};
+  std::vector<E> sym;
+  for (size_t ly = 0; ly < nl; ++ly) {
+    const size_t logw = C->layers[ly].logw;
+    const E alpha = ts.elt(), beta = ts.elt();
+    (void)beta;
+    const size_t n = 3 + layer_size256(logw);
+    E known = F.zero;
+    sym.assign(n, F.zero);
+    auto axpy = [&](size_t var, const E& kv, const E& k) {  // Expression::axpy
+      known = F.add(known, F.mul(k, kv));
+      sym[var] = F.add(sym[var], k);
+    };
+    auto axmy = [&](size_t var, const E& kv, const E& k) {  // Expression::axmy
+      known = F.sub(known, F.mul(k, kv));
+      sym[var] = F.sub(sym[var], k);
+    };
+    axpy(0, claims[0], F.one);  // ConstraintBuilder::first
+    axpy(1, claims[1], alpha);
+    gh[0].assign(logw ? logw : 1, F.zero);
+    gh[1].assign(logw ? logw : 1, F.zero);
+    const auto& P = z->proof[ly];
+    for (size_t rnd = 0; rnd < logw; ++rnd)
+      for (int hand = 0; hand < 2; ++hand) {
+        const size_t r = 2 * rnd + hand;
+        const E t0e = P.hp[hand][2 * rnd], t2e = P.hp[hand][2 * rnd + 1];
+        ts.write_elt(t0e);
+        ts.write_elt(t2e);
+        const E chal = ts.elt();
+        gh[hand][rnd] = chal;
+        E lag[3];  // dot_interpolation: p(chal) = sum_i lag[i] p(P_i)
+        for (int i = 0; i < 3; ++i) {
+          E num = F.one;
+          for (int j = 0; j < 3; ++j)
+            if (j != i) num = F.mul(num, F.sub(chal, F.pts[j]));
+          lag[i] = F.mul(num, F.invden[i]);
+        }
+        axmy(3 + 2 * r, t0e, F.one);   // ConstraintBuilder::next: p(1) = claim - p(0)
+        known = F.mul(known, lag[1]);  // scale
+        for (auto& s : sym)
+          if (!e32_is_zero(s)) s = F.mul(s, lag[1]);
+        axpy(3 + 2 * r, t0e, lag[0]);
+        axpy(3 + 2 * r + 1, t2e, lag[2]);
+      }
+    const E eqq = z->aux[ly];  // EQ[Q,C] QUAD[R,L], recorded by the sumcheck prover
+    const size_t cp = 3 + 4 * logw, skip = ly == 0 ? 3 : 0;  // ConstraintBuilder::finalize
+    out.b.push_back(F.sub(F.mul(eqq, F.mul(P.wc[0], P.wc[1])), known));
+    sym[cp] = F.sub(sym[cp], F.mul(eqq, P.wc[1]));
+    sym[cp + 1] = F.sub(sym[cp + 1], F.mul(eqq, P.wc[0]));
+    sym[cp + 2] = F.sub(sym[cp + 2], eqq);
+    for (size_t i = skip; i < n; ++i) out.a.push_back({ci, pi + i - 3, sym[i]});
+    ++ci;
+    ts.write_array(P.wc, 2);
+    claims[0] = P.wc[0];
+    claims[1] = P.wc[1];
+    pi += layer_size256(logw);
+  }
+  const E alpha = ts.elt();
+  out.a.push_back({ci, pi - 3, F.sub(F.zero, F.one)});  // input_constraint: -1, -alpha on the input layer's claim pads
+  out.a.push_back({ci, pi - 2, F.sub(F.zero, alpha)});
+  out.n = ci + 1;
+  const size_t logn = C->layers[nl - 1].logw;
+  LF_TRY(raw_eq2_256(c, F, logn, I.ninputs, gh[0].data(), gh[1].data(), alpha, (E*)z->d_eq));
+  std::vector<E> eq_in(npub ? npub : 1);
+  if (npub) LF_TRY(lfgpu_memcpy_d2h(c, eq_in.data(), z->d_eq, npub * 32));
+  const auto& P = z->proof[nl - 1];
+  E pub_binding = F.zero;
+  for (size_t i = 0; i < npub; ++i) pub_binding = F.add(pub_binding, F.mul(eq_in[i], pub[i]));
+  out.b.push_back(F.sub(F.add(P.wc[0], F.mul(alpha, P.wc[1])), pub_binding));
+  return LFGPU_OK;
+}
+
+// LigeroCommon::inner_product_vector (ligero_param.h:382-421), host share: the sparse terms of A as (flat index, value),
+// sorted with duplicates folded (the dense private-input block is built on the device)
+void inner_product_sparse256(const F256& F, const lfgpu_ligero_param& p, const Constraints256& cs, const std::vector<E>& alphal, const std::vector<size_t>& lqc,
+                             const std::vector<E>& alphaq, std::vector<uint64_t>& idx, std::vector<E>& val) {
+  std::vector<std::pair<uint64_t, E>> t;
+  t.reserve(cs.a.size() + 6 * p.nq);
+  for (const LinTerm256& l : cs.a) t.emplace_back((uint64_t)l.w, F.mul(l.k, alphal[l.c]));
+  const size_t base = p.nwrow * p.w;
+  const size_t Ax = base, Ay = base + p.nqtriples * p.w, Az = base + 2 * p.nqtriples * p.w;
+  for (size_t iw = 0; iw < p.nq; ++iw) {
+    const size_t off[3] = {Ax + iw, Ay + iw, Az + iw};
+    for (int j = 0; j < 3; ++j) {
+      const E aq = alphaq[3 * iw + j];
+      t.emplace_back((uint64_t)off[j], aq);
+      t.emplace_back((uint64_t)lqc[3 * iw + j], F.sub(F.zero, aq));
+    }
+  }
+  std::stable_sort(t.begin(), t.end(), [](const std::pair<uint64_t, E>& a, const std::pair<uint64_t, E>& b) { return a.first < b.first; });
+  idx.clear();
+  val.clear();
+  for (const auto& e : t) {
+    if (!idx.empty() && idx.back() == e.first) val.back() = F.add(val.back(), e.second);
+    else {
+      idx.push_back(e.first);
+      val.push_back(e.second);
+    }
+  }
+}
+}  // namespace
+
+int zk256_new(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc, Zk256** out) {
+  std::unique_ptr<Zk256> z(new Zk256());
+  z->c = c;
+  z->C = C;
+  z->npub = C->info.npub_in;
+  z->n_witness = C->info.ninputs - C->info.npub_in;
+  for (const auto& l : C->layers) z->pad_size += layer_size256(l.logw);
+  LF_TRY(lfgpu_ligero_param_init(&z->param, LFGPU_FIELD_P256, 0, z->n_witness + z->pad_size, C->info.nl, rateinv, nreq, block_enc));
+  LF_HIP(c, hipSetDevice(c->device));
+  z->d_in.assign(C->layers.size(), nullptr);
+  for (size_t l = 0; l < C->layers.size(); ++l)
+    if (hipMalloc(&z->d_in[l], C->layers[l].nw * 32) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "zk256: layer %zu inputs", l);
+  if (hipMalloc(&z->d_V, C->info.nv * 32) != hipSuccess || hipMalloc(&z->d_eq, C->info.ninputs * 32) != hipSuccess)
+    return lf_fail(c, LFGPU_ERR_NOMEM, "zk256: outputs");
+  if (hipHostMalloc(&z->h_V, C->info.nv * 32 + 16, hipHostMallocDefault) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "zk256: pinned outputs");
+  *out = z.release();
+  return LFGPU_OK;
+}
+int zk256_param(const Zk256* z, lfgpu_ligero_param* p) {
+  *p = z->param;
+  return LFGPU_OK;
+}
+void zk256_free(Zk256* z) { delete z; }
+int zk256_timings(const Zk256* z, double ms[6]) {
+  memcpy(ms, z->ms, sizeof(z->ms));
+  return LFGPU_OK;
+}
+
+static int ts256_ok(lfgpu_ctx* c, const lfgpu_transcript_ops* ts) {
+  if (!ts->write_elt_sized || !ts->write_elt_array_sized)
+    return lf_fail(c, LFGPU_ERR_ARG, "zk256: the transcript hooks lack write_elt_sized / write_elt_array_sized (32-byte elements)");
+  return LFGPU_OK;
+}
+
+// ZkProver::commit (zk_prover.h:72-96): fill_pad from rng, Ligero-commit witness || pad, root -> transcript
+int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, const lfgpu_transcript_ops* ts, uint8_t root_out[32]) {
+  lfgpu_ctx* c = z->c;
+  LF_TRY(ts256_ok(c, ts));
+  const double t0 = now_ms();
+  const lfgpu_circuit* C = z->C;
+  const size_t nl = C->layers.size();
+  LF_HIP(c, hipSetDevice(c->device));
+  auto draw = [&] { return h256_sample([&](uint8_t* b, size_t n) { rng(rng_user, b, n); }); };
+  std::vector<E> Wv(z->param.nw);
+  memcpy(Wv.data(), (const E*)h_W + z->npub, z->n_witness * 32);
+  z->pad.assign(nl, {});
+  z->lqc.assign(3 * nl, 0);
+  size_t pi = z->n_witness;
+  for (size_t ly = 0; ly < nl; ++ly) {  // fill_pad (zk_prover.h:152-188, logc = 0)
+    const size_t logw = C->layers[ly].logw;
+    auto& P = z->pad[ly];
+    P.hp[0].resize(2 * logw);
+    P.hp[1].resize(2 * logw);
+    size_t w = pi;
+    for (size_t j = 0; j < logw; ++j)
+      for (int h = 0; h < 2; ++h) {
+        P.hp[h][2 * j] = draw();
+        P.hp[h][2 * j + 1] = draw();
+        Wv[w++] = P.hp[h][2 * j];
+        Wv[w++] = P.hp[h][2 * j + 1];
+      }
+    P.wc[0] = draw();
+    P.wc[1] = draw();
+    Wv[w++] = P.wc[0];
+    Wv[w++] = P.wc[1];
+    Wv[w++] = fp256_mul(P.wc[0], P.wc[1]);
+    const size_t cp = pi + 4 * logw;  // setup_lqc (zk_common.h:149-160)
+    z->lqc[3 * ly] = cp;
+    z->lqc[3 * ly + 1] = cp + 1;
+    z->lqc[3 * ly + 2] = cp + 2;
+    pi += layer_size256(logw);
+  }
+  if (pi != z->param.nw) return lf_fail(c, LFGPU_ERR_ASSERT, "zk256_commit: witness layout");
+  delete z->lp;
+  z->lp = nullptr;
+  z->have_proof = false;
+  LF_TRY(lig256_commit(c, z->param, Wv.data(), z->lqc.data(), rng, rng_user, z->root, &z->lp));
+  ts->write_bytes(ts->user, z->root, 32);  // LigeroTranscript::write_commitment
+  if (root_out) memcpy(root_out, z->root, 32);
+  z->ms[0] = now_ms() - t0;
+  return LFGPU_OK;
+}
+
+// ZkProver::prove (zk_prover.h:98-149)
+int zk256_prove(Zk256* z, const void* h_W, const lfgpu_transcript_ops* tso, int* ok) {
+  lfgpu_ctx* c = z->c;
+  LF_TRY(ts256_ok(c, tso));
+  if (!z->lp) return lf_fail(c, LFGPU_ERR_ARG, "zk256_prove: must run commit before prove");
+  const double t_start = now_ms();
+  const lfgpu_circuit* C = z->C;
+  const lfgpu_circuit_info& I = C->info;
+  const size_t nl = C->layers.size();
+  const E* W = (const E*)h_W;
+  const F256 F;
+  const Ts256 ts{tso, tso->user};
+  *ok = 0;
+  z->have_proof = false;
+  LF_HIP(c, hipSetDevice(c->device));
+
+  // eval_circuit (prover_layers.h:52-104): all layers back to back while the host hashes the Fiat-Shamir preamble
+  double t0 = now_ms();
+  const E* V = (const E*)z->h_V;
+  const int* failed = (const int*)((const uint8_t*)z->h_V + I.nv * 32);
+  {
+    LF_HIP(c, hipMemcpyAsync(z->d_in[nl - 1], W, I.ninputs * 32, hipMemcpyHostToDevice, c->stream));
+    int* d_fail = (int*)((uint8_t*)c->mailbox_d + 128);
+    LF_HIP(c, hipMemsetAsync(d_fail, 0, 4, c->stream));
+    for (size_t l = nl; l-- > 0;) LF_TRY(lf256_eval_quad_async(C->layers[l].q, z->d_in[l], l ? z->d_in[l - 1] : z->d_V, d_fail));
+    LF_HIP(c, hipMemcpyAsync(z->h_V, z->d_V, I.nv * 32, hipMemcpyDeviceToHost, c->stream));
+    LF_HIP(c, hipMemcpyAsync((uint8_t*)z->h_V + I.nv * 32, d_fail, 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  const double t_enq = now_ms() - t0;
+  // initialize_sumcheck_fiat_shamir (zk_common.h:163-180)
+  ts.write_bytes(I.id, 32);
+  for (size_t i = 0; i < z->npub; ++i) ts.write_elt(W[i]);
+  ts.write_elt(F.zero);
+  {
+    std::vector<uint8_t> zb(I.nterms, 0);
+    ts.write_bytes(zb.data(), zb.size());
+  }
+  void* cl = tso->clone(tso->user);
+  if (!cl) {
+    (void)hipStreamSynchronize(c->stream);
+    return lf_fail(c, LFGPU_ERR_NOMEM, "zk256_prove: transcript clone");
+  }
+  struct CloneGuard {
+    const lfgpu_transcript_ops* o;
+    void* u;
+    ~CloneGuard() { o->free_clone(u); }
+  } cg{tso, cl};
+  const Ts256 tst{tso, cl};
+  t0 = now_ms();
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  if (*failed) return LFGPU_OK;  // an assert-zero term is non-zero: eval_circuit returns nullptr
+  for (size_t i = 0; i < I.nv; ++i)
+    if (!e32_is_zero(V[i])) return LFGPU_OK;
+  z->ms[2] = t_enq + now_ms() - t0;
+
+  // padded sumcheck (ProverLayers::prove with pad, on the transcript copy)
+  t0 = now_ms();
+  z->proof.assign(nl, {});
+  z->aux.assign(nl, F.zero);
+  std::vector<E> G[2];
+  {
+    for (size_t i = 0; i < kMaxBindings256; ++i) (void)tst.elt();  // begin_circuit: Q then G (transcript_sumcheck.h:49-52)
+    G[0].resize(kMaxBindings256);
+    for (size_t i = 0; i < kMaxBindings256; ++i) G[0][i] = tst.elt();
+    G[1] = G[0];
+  }
+  size_t logv = I.logv;
+  E WC[2] = {F.zero, F.zero};
+  std::vector<E> gout;
+  for (size_t ly = 0; ly < nl; ++ly) {
+    const auto& L = C->layers[ly];
+    const E alpha = tst.elt(), beta = tst.elt();
+    auto& P = z->proof[ly];
+    P.hp[0].resize(2 * L.logw);
+    P.hp[1].resize(2 * L.logw);
+    Round256 rc{&tst, &z->pad[ly], &P};
+    gout.assign(2 * L.logw + 1, F.zero);
+    E wc_out[2], bq;
+    LF_TRY(sumcheck_layer256(L.q, F, logv, G[0].data(), G[1].data(), alpha, beta, L.logw, L.nw, (const E*)z->d_in[ly], WC, zk256_round_cb, &rc, wc_out,
+                             gout.data(), &bq));
+    P.wc[0] = F.sub(wc_out[0], z->pad[ly].wc[0]);  // end_layer (:331-344): transmit wc - pad
+    P.wc[1] = F.sub(wc_out[1], z->pad[ly].wc[1]);
+    tst.write_array(P.wc, 2);
+    z->aux[ly] = bq;
+    WC[0] = wc_out[0];
+    WC[1] = wc_out[1];
+    for (int h = 0; h < 2; ++h) {
+      G[h].assign(kMaxBindings256, F.zero);
+      for (size_t r = 0; r < L.logw; ++r) G[h][r] = gout[h * L.logw + r];
+    }
+    logv = L.logw;
+  }
+  z->ms[3] = now_ms() - t0;
+
+  // verifier_constraints with aux: replay the verifier symbolically on the ORIGINAL transcript
+  t0 = now_ms();
+  Constraints256 cs;
+  LF_TRY(build_constraints256(z, F, ts, W, cs));
+  const lfgpu_ligero_param& p = z->param;
+  z->ms[4] = now_ms() - t0;
+
+  // LigeroProver::prove (ligero_prover.h:84-146)
+  t0 = now_ms();
+  {
+    uint8_t hash_of_A[32] = {0xde, 0xad, 0xbe, 0xef};  // zk_prover.h:143
+    ts.write_bytes(hash_of_A, 32);
+    std::vector<E> u_ldt(p.nwqrow);
+    for (auto& e : u_ldt) e = ts.elt();
+    z->y_ldt.assign(p.block, F.zero);
+    LF_TRY(lig256_low_degree(z->lp, u_ldt.data(), z->y_ldt.data()));
+    std::vector<E> alphal(cs.n), alphaq(3 * p.nq);
+    for (auto& e : alphal) e = ts.elt();
+    for (auto& e : alphaq) e = ts.elt();
+    std::vector<uint64_t> a_idx;
+    std::vector<E> a_val;
+    inner_product_sparse256(F, p, cs, alphal, z->lqc, alphaq, a_idx, a_val);
+    z->y_dot.assign(p.dblock, F.zero);
+    LF_TRY(lig256_dot(z->lp, (const E*)z->d_eq + z->npub, z->n_witness, alphal[cs.n - 1], a_idx.data(), a_val.data(), a_idx.size(), z->y_dot.data()));
+    std::vector<E> u_quad(p.nqtriples ? p.nqtriples : 1);
+    for (size_t i = 0; i < p.nqtriples; ++i) u_quad[i] = ts.elt();
+    z->y_q0.assign(p.r, F.zero);
+    z->y_q2.assign(p.dblock - p.block, F.zero);
+    LF_TRY(lig256_quadratic(z->lp, u_quad.data(), z->y_q0.data(), z->y_q2.data()));
+    ts.write_array(z->y_ldt.data(), z->y_ldt.size());
+    ts.write_array(z->y_dot.data(), z->y_dot.size());
+    ts.write_array(z->y_q0.data(), z->y_q0.size());
+    ts.write_array(z->y_q2.data(), z->y_q2.size());
+    std::vector<size_t> idx(p.nreq);
+    ts.choose(p.block_ext, p.nreq, idx.data());
+    z->req.assign(p.nrow * p.nreq, F.zero);
+    z->nonces.assign(p.nreq * 32, 0);
+    const size_t cap = p.nreq * p.mc_pathlen + 1;
+    z->path.assign(cap * 32, 0);
+    LF_TRY(lig256_open(z->lp, idx.data(), z->req.data(), z->nonces.data(), z->path.data(), cap, &z->npath));
+  }
+  z->ms[5] = now_ms() - t0;
+  z->ms[1] = now_ms() - t_start;
+  z->have_proof = true;
+  *ok = 1;
+  return LFGPU_OK;
+}
+
+// ZkProof::write (zk_proof.h:90-185); the subfield of a prime field is the field, so the opened columns are one
+// "subfield" run after an empty full-field run
+int zk256_proof_write(const Zk256* z, uint8_t* buf, size_t cap, size_t* nbytes) {
+  if (!z->have_proof) return lf_fail(z->c, LFGPU_ERR_ARG, "zk_proof_write: no proof");
+  std::vector<uint8_t> o;
+  auto pute = [&](const E& e) {
+    uint8_t b[32];
+    h256_to_bytes(e, b);
+    o.insert(o.end(), b, b + 32);
+  };
+  auto putsz = [&](size_t g) {
+    for (int i = 0; i < 4; ++i) o.push_back((uint8_t)(g >> (8 * i)));
+  };
+  o.insert(o.end(), z->root, z->root + 32);
+  for (size_t ly = 0; ly < z->proof.size(); ++ly) {
+    const auto& P = z->proof[ly];
+    const size_t logw = z->C->layers[ly].logw;
+    for (size_t wi = 0; wi < logw; ++wi)
+      for (int k = 0; k < 2; ++k) {
+        pute(P.hp[0][2 * wi + k]);
+        pute(P.hp[1][2 * wi + k]);
+      }
+    pute(P.wc[0]);
+    pute(P.wc[1]);
+  }
+  for (const E& e : z->y_ldt) pute(e);
+  for (const E& e : z->y_dot) pute(e);
+  for (const E& e : z->y_q0) pute(e);
+  for (const E& e : z->y_q2) pute(e);
+  o.insert(o.end(), z->nonces.begin(), z->nonces.end());
+  constexpr size_t kMaxRunLen = (size_t)1 << 25;
+  const size_t nreq_elts = z->req.size();
+  size_t ci = 0;
+  bool subfield_run = false;
+  while (ci < nreq_elts) {
+    size_t runlen = 0;
+    if (subfield_run) runlen = std::min(nreq_elts - ci, kMaxRunLen);  // in_subfield(e) is true for every element
+    putsz(runlen);
+    for (size_t i = ci; i < ci + runlen; ++i) pute(z->req[i]);
+    ci += runlen;
+    subfield_run = !subfield_run;
+  }
+  putsz(z->npath);
+  o.insert(o.end(), z->path.begin(), z->path.begin() + 32 * z->npath);
+  *nbytes = o.size();
+  if (buf) {
+    if (cap < o.size()) return lf_fail(z->c, LFGPU_ERR_ARG, "zk_proof_write: buffer too small (%zu < %zu)", cap, o.size());
+    memcpy(buf, o.data(), o.size());
+  }
+  return LFGPU_OK;
+}

@@ -96,3 +96,8 @@ extern "C" void hf_p256_add(const elt32_t* a, const elt32_t* b, elt32_t* o) { *o
 extern "C" void hf_p256_sub(const elt32_t* a, const elt32_t* b, elt32_t* o) { *o = fp256_sub(*a, *b); }
 extern "C" void hf_p256_canon(const elt32_t* a, elt32_t* o) { *o = fp256_canon(*a); }
 extern "C" void hf_p256_c2mul(const fp2_t* a, const fp2_t* b, fp2_t* o) { *o = fp2_mul(*a, *b); }
+// limb accumulators of the P-256 sumcheck sums (zk256.hip) and the host helpers next to them
+extern "C" void hf_p256_reduce_limbs(const u64* acc, elt32_t* o) { *o = fp256_reduce_limbs(acc, h256_rsq()); }
+extern "C" void hf_p256_of_scalar(u64 u, elt32_t* o) { *o = h256_of_scalar(u); }
+extern "C" void hf_p256_inv(const elt32_t* a, elt32_t* o) { *o = h256_inv(*a); }
+extern "C" int hf_p256_of_bytes(const uint8_t* b, elt32_t* o) { return h256_of_bytes(b, *o) ? 1 : 0; }

@@ -166,3 +166,42 @@ def test_p256_ops_match_oracle_and_big_integers():
         out = np.zeros(8, dtype=np.uint64)
         L.hf_p256_c2mul(P(x), P(y), P(out))
         assert to_int(out[:4]) == (a * c - b * d) * Rinv % p and to_int(out[4:]) == (a * d + b * c) * Rinv % p
+
+
+def test_p256_limb_accumulators_and_host_helpers():
+    """fp256_reduce_limbs (the reduction of the eight 64-bit limb accumulators the P-256 sumcheck kernels sum canonical
+    residues into, csrc/zk256.hip) against Python integers -- up to 2^32 - 1 addends per limb; h256_of_scalar / inv / of_bytes"""
+    import ctypes as C
+    L = _lib()
+    p, R = ol.P256_P, 1 << 256
+    rng = np.random.default_rng(7)
+
+    def to_int(a):
+        return sum(int(a[i]) << (64 * i) for i in range(4))
+
+    cases = [[0] * 8, [2**64 - 1] * 8, [2**32 - 1] * 8, [1] + [0] * 7, [0] * 7 + [2**64 - 1]]
+    cases += [[int(x) for x in rng.integers(0, 2**64, size=8, dtype=np.uint64)] for _ in range(300)]
+    # sums of real residues: n copies of limbs of (p - 1)
+    w = [((p - 1) >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
+    cases += [[n * x for x in w] for n in (1, 2, 1000, 2**32 - 1)]
+    for acc in cases:
+        a = np.array(acc, dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        L.hf_p256_reduce_limbs(P(a), P(out))
+        assert to_int(out) == sum(v << (32 * k) for k, v in enumerate(acc)) % p, acc
+    for u in (0, 1, 2, 10, 2**64 - 1):
+        out = np.zeros(4, dtype=np.uint64)
+        L.hf_p256_of_scalar(C.c_uint64(u), P(out))
+        assert to_int(out) == u * R % p
+    for _ in range(5):
+        x = int.from_bytes(rng.bytes(32), "little") % p or 1
+        a = np.array([(x * R % p >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+        out = np.zeros(4, dtype=np.uint64)
+        L.hf_p256_inv(P(a), P(out))
+        assert to_int(out) == pow(x, -1, p) * R % p
+    for v, fits in ((0, 1), (p - 1, 1), (p, 0), (2**256 - 1, 0), (12345, 1)):
+        b = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8).copy()
+        out = np.zeros(4, dtype=np.uint64)
+        assert L.hf_p256_of_bytes(b.ctypes.data_as(C.c_void_p), P(out)) == fits
+        if fits:
+            assert to_int(out) == v * R % p
