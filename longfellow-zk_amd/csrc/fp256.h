@@ -7,6 +7,8 @@
 #pragma once
 #include <string.h>
 
+#include <vector>
+
 #include "fields.h"
 
 struct alignas(16) elt32_t {
@@ -250,5 +252,20 @@ inline elt32_t h256_sample(Fill fill) {
     fill(b, 32);
     elt32_t e;
     if (h256_of_bytes(b, e)) return e;
+  }
+}
+// n consecutive samples with few calls of the byte source: the reference draws 32 bytes per attempt and a rejected
+// attempt is followed by the next 32 bytes of the same stream, so for every byte-stream RandomEngine (LCG test engines,
+// Transcript/FSPRF, SecureRandomEngine) the accepted chunks of one long draw are the same elements in the same order.
+template <class Fill>
+inline void h256_sample_many(elt32_t* out, size_t n, Fill fill) {
+  std::vector<uint8_t> buf;
+  size_t have = 0;
+  while (have < n) {
+    const size_t want = n - have;
+    buf.resize(32 * want);
+    fill(buf.data(), buf.size());
+    for (size_t i = 0; i < want; ++i)
+      if (h256_of_bytes(&buf[32 * i], out[have])) ++have;
   }
 }

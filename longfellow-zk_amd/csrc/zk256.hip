@@ -34,32 +34,63 @@ __device__ __forceinline__ void limbs_atomic_add(u64* a, const E& v) {
     atomicAdd(&a[2 * k + 1], v.l[k] >> 32);
   }
 }
-__global__ __launch_bounds__(Z_THREADS) void limb_normalize256_kernel(size_t n, const u64* __restrict__ acc, E rsq, E* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
-  if (i >= n) return;
+// One term per lane; runs of equal keys among consecutive lanes (canonical order keeps equal hand pairs, and mostly also the
+// hot target -- the constant wire 0 -- adjacent) are summed inside the wave first, so that a run costs 8 atomics per wave
+// instead of 8 per term: the signature circuit has runs of 3e4 terms and one wire that 1e5 terms of a layer read.
+// key 0xffffffff marks an idle lane.  Every lane of the wave must call this.
+__device__ __forceinline__ void run_fold_commit256(u32 key, E t, u64* __restrict__ acc) {
+  const u32 lane = threadIdx.x & 63;
+  const u32 pkey = __shfl_up(key, 1, 64);
+  const bool head = lane == 0 || pkey != key;
+  const u64 hmask = __ballot(head);
+  if (hmask != ~0ull) {  // wave-uniform: some neighbours share a key
+    const u32 rid = (u32)__popcll(hmask & ((2ull << lane) - 1));  // monotone, so equal ids = one contiguous run
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      E o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o.l[k] = __shfl_down(t.l[k], off, 64);
+      const u32 orid = __shfl_down(rid, off, 64);
+      if (lane + off < 64 && orid == rid) t = fp256_add(t, o);
+    }
+  }
+  if (head && key != 0xffffffffu) limbs_atomic_add(acc + 8 * (size_t)key, t);
+}
+__device__ __forceinline__ E take_acc256(u64* __restrict__ acc, size_t i, const E& rsq) {
   u64 a[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = acc[8 * i + k];
-  st32(&out[i], fp256_reduce_limbs(a, rsq));
+  for (int k = 0; k < 8; ++k) {
+    a[k] = acc[8 * i + k];
+    acc[8 * i + k] = 0;
+  }
+  return fp256_reduce_limbs(a, rsq);
+}
+// out[i] = the field element of accumulator i; the accumulators are left zeroed (they serve the next sum)
+__global__ __launch_bounds__(Z_THREADS) void limb_normalize256_kernel(size_t n, u64* __restrict__ acc, E rsq, E* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  if (i >= n) return;
+  st32(&out[i], take_acc256(acc, i, rsq));
 }
 
-// K11: V[g] = sum_{terms of g} kvec[vi] * W[h1] * W[h0]; assert-zero terms must vanish
-__global__ __launch_bounds__(Z_THREADS) void eval_quad256_kernel(u32 nv, const u32* __restrict__ goff, const corner4* __restrict__ terms,
-                                                                 const E* __restrict__ kvec, const E* __restrict__ W, E* __restrict__ V,
-                                                                 int* __restrict__ fail) {
-  const u32 g = blockIdx.x * Z_THREADS + threadIdx.x;
-  if (g >= nv) return;
-  E acc = e32_zero();
-  bool bad = false;
-  for (u32 t = goff[g]; t < goff[g + 1]; ++t) {
-    const corner4 cr = terms[t];
+// K11: V[g] = sum_{terms of g} kvec[vi] * W[h1] * W[h0]; assert-zero terms must vanish.  One term per lane over the
+// by-gate order (a gate's terms are contiguous: one gate of the signature circuit has 769), summed as above.
+__global__ __launch_bounds__(Z_THREADS) void eval_quad256_kernel(size_t n, const corner4* __restrict__ terms, const E* __restrict__ kvec,
+                                                                 const E* __restrict__ W, u64* __restrict__ acc, int* __restrict__ fail) {
+  const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  u32 key = 0xffffffffu;
+  E t = e32_zero();
+  if (i < n) {
+    const corner4 cr = terms[i];
+    key = cr.g;
     const E v = ld32(&kvec[cr.vi]);
     const E p = fp256_mul(ld32(&W[cr.h1]), ld32(&W[cr.h0]));
-    if (e32_is_zero(v)) bad |= !e32_is_zero(p);
-    else acc = fp256_add(acc, fp256_mul(v, p));
+    if (e32_is_zero(v)) {
+      if (!e32_is_zero(p)) atomicOr(fail, 1);
+    } else {
+      t = fp256_mul(v, p);
+    }
   }
-  st32(&V[g], acc);
-  if (bad) atomicOr(fail, 1);
+  run_fold_commit256(key, t, acc);
 }
 
 // eq[i] = EQ(G0, i) + alpha EQ(G1, i), EQ(G, i) = prod_l (bit_l(i) ? G[l] : 1 - G[l]); G = G0 | G1 | 1-G0 | 1-G1
@@ -89,26 +120,32 @@ __global__ __launch_bounds__(BG_THREADS) void bindg_emit256_kernel(size_t n, con
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) wave_off[wave] = (u32)__popcll(mask);
   __syncthreads();
-  if (!valid) return;
   u32 ri = block_off[blockIdx.x];
   for (u32 w = 0; w < wave; ++w) ri += wave_off[w];
   ri += (u32)__popcll(mask & ((2ull << lane) - 1)) - 1;
-  const corner4 c0 = t[i];
-  E v = ld32(&kvec[c0.vi]);
-  if (e32_is_zero(v)) v = beta;
-  const E pv = fp256_mul(v, ld32(&eq[c0.g]));
-  if (head) hc_out[ri] = make_uint2(c0.h0, c0.h1);
-  limbs_atomic_add(acc + 8 * (size_t)ri, pv);
+  E pv = e32_zero();
+  if (valid) {
+    const corner4 c0 = t[i];
+    E v = ld32(&kvec[c0.vi]);
+    if (e32_is_zero(v)) v = beta;
+    pv = fp256_mul(v, ld32(&eq[c0.g]));
+    if (head) hc_out[ri] = make_uint2(c0.h0, c0.h1);
+  }
+  run_fold_commit256(valid ? ri : 0xffffffffu, pv, acc);
 }
 
 // QW[h[hand]] += v * Wother[h[1-hand]]
 __global__ __launch_bounds__(Z_THREADS) void qw_scatter256_kernel(size_t n, const uint2* __restrict__ hc, const E* __restrict__ vc, int hand,
                                                                   const E* __restrict__ Wo, u64* __restrict__ acc) {
   const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
-  if (i >= n) return;
-  const uint2 h = hc[i];
-  const u32 p0 = hand ? h.y : h.x, p1 = hand ? h.x : h.y;
-  limbs_atomic_add(acc + 8 * (size_t)p0, fp256_mul(ld32(&vc[i]), ld32(&Wo[p1])));
+  u32 key = 0xffffffffu;
+  E t = e32_zero();
+  if (i < n) {
+    const uint2 h = hc[i];
+    key = hand ? h.y : h.x;
+    t = fp256_mul(ld32(&vc[i]), ld32(&Wo[hand ? h.x : h.y]));
+  }
+  run_fold_commit256(key, t, acc);
 }
 
 __device__ __forceinline__ E block_sum256(E v, E* sh) {
@@ -122,46 +159,34 @@ __device__ __forceinline__ E block_sum256(E v, E* sh) {
   __syncthreads();
   return r;
 }
-// partial[2b] = a0 part, partial[2b+1] = a2 part of block b (ProverLayers::evaluations :357-402)
-__global__ __launch_bounds__(Z_THREADS) void partials256_kernel(size_t n, const E* __restrict__ QW, const E* __restrict__ W, E* __restrict__ partial) {
+// The two sums of a round (ProverLayers::evaluations :357-402), a0 = sum QW[2i] W[2i] and
+// a2 = sum (QW[2i+1] - QW[2i]) (W[2i+1] - W[2i]), straight from the scatter's limb accumulators: every accumulator is
+// reduced to its field element here and zeroed for the next round-hand; the block sums go, again as limbs, into 16 words
+// the host reads back and reduces (out[0..8) = a0, out[8..16) = a2; zeroed by the bind kernel that follows the read).
+__global__ __launch_bounds__(Z_THREADS) void partials256_kernel(size_t n, u64* __restrict__ acc, E rsq, const E* __restrict__ W, u64* __restrict__ out) {
   __shared__ E sh[Z_THREADS];
   const size_t nodd = n / 2;
   E a0 = e32_zero(), a2 = e32_zero();
   for (size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x; i < nodd; i += (size_t)gridDim.x * Z_THREADS) {
-    const E q0 = ld32(&QW[2 * i]), q1 = ld32(&QW[2 * i + 1]), w0 = ld32(&W[2 * i]), w1 = ld32(&W[2 * i + 1]);
+    const E q0 = take_acc256(acc, 2 * i, rsq), q1 = take_acc256(acc, 2 * i + 1, rsq), w0 = ld32(&W[2 * i]), w1 = ld32(&W[2 * i + 1]);
     a0 = fp256_add(a0, fp256_mul(q0, w0));
     a2 = fp256_add(a2, fp256_mul(fp256_sub(q1, q0), fp256_sub(w1, w0)));
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && 2 * nodd < n) {  // odd tail (:381-388)
-    const E t = fp256_mul(ld32(&QW[2 * nodd]), ld32(&W[2 * nodd]));
+    const E t = fp256_mul(take_acc256(acc, 2 * nodd, rsq), ld32(&W[2 * nodd]));
     a0 = fp256_add(a0, t);
     a2 = fp256_add(a2, t);
   }
   a0 = block_sum256(a0, sh);
   a2 = block_sum256(a2, sh);
   if (threadIdx.x == 0) {
-    st32(&partial[2 * blockIdx.x], a0);
-    st32(&partial[2 * blockIdx.x + 1], a2);
-  }
-}
-__global__ __launch_bounds__(Z_THREADS) void partials_final256_kernel(u32 nblocks, const E* __restrict__ partial, E* __restrict__ out) {
-  __shared__ E sh[Z_THREADS];
-  E a0 = e32_zero(), a2 = e32_zero();
-  for (u32 b = threadIdx.x; b < nblocks; b += Z_THREADS) {
-    a0 = fp256_add(a0, ld32(&partial[2 * b]));
-    a2 = fp256_add(a2, ld32(&partial[2 * b + 1]));
-  }
-  a0 = block_sum256(a0, sh);
-  a2 = block_sum256(a2, sh);
-  if (threadIdx.x == 0) {
-    st32(&out[0], a0);
-    st32(&out[1], a2);
+    limbs_atomic_add(out, a0);
+    limbs_atomic_add(out + 8, a2);
   }
 }
 
 // out[i] = in[2i] + r (in[2i+1] - in[2i]); tail: in (1 - r)   (dense.h:70-87, affine.h:26-52)
-__global__ __launch_bounds__(Z_THREADS) void dense_bind256_kernel(size_t n0, E r, const E* __restrict__ in, E* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+__device__ __forceinline__ void dense_bind256(size_t i, size_t n0, const E& r, const E* __restrict__ in, E* __restrict__ out) {
   if (i >= (n0 + 1) / 2) return;
   const E f0 = ld32(&in[2 * i]);
   E v;
@@ -213,16 +238,26 @@ __global__ __launch_bounds__(1024) void scan256_kernel(u32 nblocks, u32* __restr
   }
   if (threadIdx.x == 0) *total = carry;
 }
-__global__ __launch_bounds__(Z_THREADS) void hquad_emit256_kernel(size_t n, const uint2* __restrict__ hc, const E* __restrict__ vc, E r, int hand,
-                                                                  const u32* __restrict__ block_off, uint2* __restrict__ hc_out, E* __restrict__ vc_out) {
+// Dense::bind of the hand that just received its challenge (blocks [0, nbd)) and HQuad::bind_h (the blocks after them) in
+// one launch; block 0 also clears the words the host has just read the round's sums from
+__global__ __launch_bounds__(Z_THREADS) void bind256_kernel(u32 nbd, size_t n0, const E* __restrict__ win, E* __restrict__ wout, size_t n,
+                                                            const uint2* __restrict__ hc, const E* __restrict__ vc, E r, int hand,
+                                                            const u32* __restrict__ block_off, uint2* __restrict__ hc_out, E* __restrict__ vc_out,
+                                                            u64* __restrict__ sums) {
   __shared__ u32 wave_off[Z_THREADS / 64];
-  const size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 16) sums[threadIdx.x] = 0;
+  if (blockIdx.x < nbd) {
+    dense_bind256((size_t)blockIdx.x * Z_THREADS + threadIdx.x, n0, r, win, wout);
+    return;
+  }
+  const u32 blk = blockIdx.x - nbd;
+  const size_t i = (size_t)blk * Z_THREADS + threadIdx.x;
   const bool head = i < n && !is_second256(hc, i, hand);
   const u64 mask = __ballot(head);
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) wave_off[wave] = (u32)__popcll(mask);
   __syncthreads();
-  u32 off = block_off[blockIdx.x];
+  u32 off = block_off[blk];
   for (u32 w = 0; w < wave; ++w) off += wave_off[w];
   off += (u32)__popcll(mask & ((1ull << lane) - 1));
   if (!head) return;
@@ -357,8 +392,12 @@ int raw_eq2_256(lfgpu_ctx* c, const F256& F, size_t logn, size_t n, const E* G0,
   }
   void* d_G = nullptr;
   LF_TRY(lf_scratch2(c, Gt.size() * 32 + 64, &d_G));
-  LF_HIP(c, hipMemcpyAsync(d_G, Gt.data(), Gt.size() * 32, hipMemcpyHostToDevice, c->stream));
-  LF_HIP(c, hipStreamSynchronize(c->stream));  // Gt is a local
+  if (Gt.size() * 32 <= LF_STAGE_SLOT) {  // 4 logn + 1 <= 128 elements: through the pinned ring, no synchronisation
+    LF_TRY(lf_stage_upload(c, d_G, Gt.data(), Gt.size() * 32));
+  } else {
+    LF_HIP(c, hipMemcpyAsync(d_G, Gt.data(), Gt.size() * 32, hipMemcpyHostToDevice, c->stream));
+    LF_HIP(c, hipStreamSynchronize(c->stream));  // Gt is a local
+  }
   hipLaunchKernelGGL(raw_eq2_256_kernel, dim3(nblk(n)), dim3(Z_THREADS), 0, c->stream, (u32)logn, (u32)n, (const E*)d_G, alpha, F.one, d_eq);
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
@@ -375,10 +414,10 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   if (nw == 0 || logw > 40 || nw > ((size_t)1 << logw) || nw <= q->hmax) return lf_fail(c, LFGPU_ERR_ARG, "sumcheck_layer256: nw must exceed the largest hand index");
   if (logv > 40 || ((size_t)1 << logv) < q->nv) return lf_fail(c, LFGPU_ERR_ARG, "sumcheck_layer256: 2^logv < nv");
   const size_t nt = q->n, nh0 = q->nh0, half = (nw + 1) / 2;
-  const u32 nbp = std::min<u32>(nblk(nw / 2), 256);
-  // scratch: eq | run accumulators / QW accumulators | hc[2] | vc[2] | QW | 4 half hand buffers | partials | out
+  // scratch: eq | limb accumulators (bind_g runs, then the QW of every round-hand; self-cleaning) | hc[2] | vc[2] |
+  // 4 half hand buffers | the round's two sums as limbs
   const size_t acc_n = std::max(nh0, nw);
-  const size_t bytes = q->nv * 32 + acc_n * 64 + 2 * nh0 * 8 + 2 * nh0 * 32 + nw * 32 + 4 * half * 32 + 2 * 256 * 32 + 64 + 1024;
+  const size_t bytes = q->nv * 32 + acc_n * 64 + 2 * nh0 * 8 + 2 * nh0 * 32 + 4 * half * 32 + 128 + 1024;
   void* sc = nullptr;
   LF_TRY(lf_scratch(c, bytes, &sc));
   uint8_t* b = (uint8_t*)sc;
@@ -387,16 +426,15 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   uint2* hc[2] = {(uint2*)b, (uint2*)(b + nh0 * 8)};  b += 2 * nh0 * 8;
   b = (uint8_t*)(((uintptr_t)b + 31) & ~(uintptr_t)31);
   E* vc[2] = {(E*)b, (E*)b + nh0};     b += 2 * nh0 * 32;
-  E* qw = (E*)b;                       b += nw * 32;
   E* wb[2][2] = {{(E*)b, (E*)b + half}, {(E*)b + 2 * half, (E*)b + 3 * half}};  b += 4 * half * 32;
-  E* partial = (E*)b;                  b += 2 * 256 * 32;
-  E* d_out = (E*)b;
+  u64* d_sums = (u64*)b;
   // Quad::bind_g
   LF_TRY(raw_eq2_256(c, F, logv, q->nv, G0, G1, alpha, d_eq));
-  LF_HIP(c, hipMemsetAsync(acc, 0, nh0 * 64, c->stream));
+  LF_HIP(c, hipMemsetAsync(acc, 0, acc_n * 64, c->stream));
+  LF_HIP(c, hipMemsetAsync(d_sums, 0, 128, c->stream));
   hipLaunchKernelGGL(bindg_emit256_kernel, dim3(nblk(nt, BG_THREADS)), dim3(BG_THREADS), 0, c->stream, nt, (const corner4*)q->d_morton, (const E*)q->d_kvec,
                      (const E*)d_eq, beta, (const u32*)q->d_runoff, hc[0], acc);
-  hipLaunchKernelGGL(limb_normalize256_kernel, dim3(nblk(nh0)), dim3(Z_THREADS), 0, c->stream, nh0, (const u64*)acc, F.rsq, vc[0]);
+  hipLaunchKernelGGL(limb_normalize256_kernel, dim3(nblk(nh0)), dim3(Z_THREADS), 0, c->stream, nh0, acc, F.rsq, vc[0]);
   LF_HIP(c, hipGetLastError());
   size_t nh = nh0;
   int cur = 0;
@@ -405,56 +443,53 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   size_t nW[2] = {nw, nw};
   int wsel[2] = {0, 0};
   if (q->bind_shape.size() < 2 * logw) q->bind_shape.resize(2 * logw, lfgpu_quad::BindShape{nullptr, 0, 0});
+  u64* h_sums = (u64*)c->mailbox_h;
   E* h_out = (E*)c->mailbox_h;
   for (size_t rnd = 0; rnd < logw; ++rnd)
     for (int hand = 0; hand < 2; ++hand) {
-      // QW scatter (prover_layers.h:239-243) + evaluations
-      LF_HIP(c, hipMemsetAsync(acc, 0, nW[hand] * 64, c->stream));
+      // QW scatter (prover_layers.h:239-243) + evaluations: two launches, one read-back
       if (nh) hipLaunchKernelGGL(qw_scatter256_kernel, dim3(nblk(nh)), dim3(Z_THREADS), 0, c->stream, nh, (const uint2*)hc[cur], (const E*)vc[cur], hand,
                                  WH[1 - hand], acc);
-      hipLaunchKernelGGL(limb_normalize256_kernel, dim3(nblk(nW[hand])), dim3(Z_THREADS), 0, c->stream, nW[hand], (const u64*)acc, F.rsq, qw);
-      const u32 nb = std::min<u32>(nblk(nW[hand] / 2), nbp ? nbp : 1);
-      hipLaunchKernelGGL(partials256_kernel, dim3(nb), dim3(Z_THREADS), 0, c->stream, nW[hand], (const E*)qw, WH[hand], partial);
-      hipLaunchKernelGGL(partials_final256_kernel, dim3(1), dim3(Z_THREADS), 0, c->stream, nb, (const E*)partial, d_out);
+      hipLaunchKernelGGL(partials256_kernel, dim3(std::min<u32>(nblk(nW[hand] / 2), 256)), dim3(Z_THREADS), 0, c->stream, nW[hand], acc, F.rsq, WH[hand], d_sums);
       LF_HIP(c, hipGetLastError());
-      LF_HIP(c, hipMemcpyAsync(h_out, d_out, 64, hipMemcpyDeviceToHost, c->stream));
+      LF_HIP(c, hipMemcpyAsync(h_sums, d_sums, 128, hipMemcpyDeviceToHost, c->stream));
       LF_HIP(c, hipStreamSynchronize(c->stream));
       // coef[0] = a0, coef[2] = a2, coef[1] from the running sum (prover_layers.h:390-396, logc = 0)
       E coef[3], ev[3], r;
-      coef[0] = h_out[0];
-      coef[2] = h_out[1];
+      coef[0] = fp256_reduce_limbs(h_sums, F.rsq);
+      coef[2] = fp256_reduce_limbs(h_sums + 8, F.rsq);
       coef[1] = F.sub(F.sub(F.sub(sum, coef[0]), coef[0]), coef[2]);
       for (int k = 0; k < 3; ++k) ev[k] = F.eval_monomial(coef, F.pts[k]);
       round(user, (size_t)hand, rnd, ev, &r);
       g_out[hand * logw + rnd] = r;
       sum = F.eval_lagrange(ev, r);
-      // Dense::bind of this hand, HQuad::bind_h
+      // Dense::bind of this hand + HQuad::bind_h: one launch.  The merge structure of a round-hand is a circuit constant:
+      // counted at the first proof, kept with the layer from then on
+      lfgpu_quad::BindShape& bs = q->bind_shape[2 * rnd + hand];
+      const u32 nbh = nh ? nblk(nh) : 0, nbd = nblk((nW[hand] + 1) / 2);
+      if (nh && !(bs.d_off && bs.n_in == nh)) {
+        if (bs.d_off) (void)hipFree(bs.d_off);
+        bs = lfgpu_quad::BindShape{nullptr, nh, 0};
+        if (hipMalloc((void**)&bs.d_off, (size_t)nbh * 4) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "sumcheck_layer256: bind offsets");
+        u32* total = (u32*)((uint8_t*)c->mailbox_d + 64);
+        hipLaunchKernelGGL(hquad_count256_kernel, dim3(nbh), dim3(Z_THREADS), 0, c->stream, nh, (const uint2*)hc[cur], hand, bs.d_off);
+        hipLaunchKernelGGL(scan256_kernel, dim3(1), dim3(1024), 0, c->stream, nbh, bs.d_off, total);
+        u32 tot = 0;
+        LF_HIP(c, hipMemcpyAsync(&tot, total, 4, hipMemcpyDeviceToHost, c->stream));
+        LF_HIP(c, hipStreamSynchronize(c->stream));
+        bs.n_out = tot;
+      }
       E* dst = wb[hand][wsel[hand]];
-      hipLaunchKernelGGL(dense_bind256_kernel, dim3(nblk((nW[hand] + 1) / 2)), dim3(Z_THREADS), 0, c->stream, nW[hand], r, WH[hand], dst);
+      hipLaunchKernelGGL(bind256_kernel, dim3(nbd + nbh), dim3(Z_THREADS), 0, c->stream, nbd, nW[hand], WH[hand], dst, nh, (const uint2*)hc[cur],
+                         (const E*)vc[cur], r, hand, (const u32*)bs.d_off, hc[1 - cur], vc[1 - cur], d_sums);
+      LF_HIP(c, hipGetLastError());
       WH[hand] = dst;
       wsel[hand] ^= 1;
       nW[hand] = (nW[hand] + 1) / 2;
-      if (nh) {  // the merge structure of this round-hand is a circuit constant: kept from the first proof on
-        lfgpu_quad::BindShape& bs = q->bind_shape[2 * rnd + hand];
-        const u32 nbh = nblk(nh);
-        if (!(bs.d_off && bs.n_in == nh)) {
-          if (bs.d_off) (void)hipFree(bs.d_off);
-          bs = lfgpu_quad::BindShape{nullptr, nh, 0};
-          if (hipMalloc((void**)&bs.d_off, (size_t)nbh * 4) != hipSuccess) return lf_fail(c, LFGPU_ERR_NOMEM, "sumcheck_layer256: bind offsets");
-          u32* total = (u32*)((uint8_t*)c->mailbox_d + 64);
-          hipLaunchKernelGGL(hquad_count256_kernel, dim3(nbh), dim3(Z_THREADS), 0, c->stream, nh, (const uint2*)hc[cur], hand, bs.d_off);
-          hipLaunchKernelGGL(scan256_kernel, dim3(1), dim3(1024), 0, c->stream, nbh, bs.d_off, total);
-          u32 tot = 0;
-          LF_HIP(c, hipMemcpyAsync(&tot, total, 4, hipMemcpyDeviceToHost, c->stream));
-          LF_HIP(c, hipStreamSynchronize(c->stream));
-          bs.n_out = tot;
-        }
-        hipLaunchKernelGGL(hquad_emit256_kernel, dim3(nbh), dim3(Z_THREADS), 0, c->stream, nh, (const uint2*)hc[cur], (const E*)vc[cur], r, hand,
-                           (const u32*)bs.d_off, hc[1 - cur], vc[1 - cur]);
+      if (nh) {
         nh = bs.n_out;
         cur = 1 - cur;
       }
-      LF_HIP(c, hipGetLastError());
     }
   // W[0][0], W[1][0] and the bound quad (the HQUAD has shrunk to one entry)
   if (nh != 1) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: HQUAD did not fold to one entry (%zu)", nh);
@@ -471,8 +506,12 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
 
 int lf256_eval_quad_async(lfgpu_quad* q, const void* d_W, void* d_V, int* d_fail) {
   lfgpu_ctx* c = q->c;
-  hipLaunchKernelGGL(eval_quad256_kernel, dim3(nblk(q->nv)), dim3(Z_THREADS), 0, c->stream, (u32)q->nv, (const u32*)q->d_goff, (const corner4*)q->d_bygate,
-                     (const E*)q->d_kvec, (const E*)d_W, (E*)d_V, d_fail);
+  void* acc = nullptr;
+  LF_TRY(lf_scratch2(c, q->nv * 64 + 64, &acc));
+  LF_HIP(c, hipMemsetAsync(acc, 0, q->nv * 64, c->stream));
+  hipLaunchKernelGGL(eval_quad256_kernel, dim3(nblk(q->n)), dim3(Z_THREADS), 0, c->stream, q->n, (const corner4*)q->d_bygate, (const E*)q->d_kvec, (const E*)d_W,
+                     (u64*)acc, d_fail);
+  hipLaunchKernelGGL(limb_normalize256_kernel, dim3(nblk(q->nv)), dim3(Z_THREADS), 0, c->stream, q->nv, (u64*)acc, h256_rsq(), (E*)d_V);
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
 }
@@ -500,10 +539,7 @@ struct Lig256 {
 // reference's order (FpGeneric::sample and sample_subfield are the same function, fp_generic.h:360-376)
 int lig256_layout(const lfgpu_ligero_param& p, const E* W, const size_t* lqc, lfgpu_rng_fn rng, void* user, E* H, uint8_t* nonces, char* err) {
   const size_t hw = p.dblock;
-  auto draw = [&] { return h256_sample([&](uint8_t* b, size_t n) { rng(user, b, n); }); };
-  auto elts = [&](E* out, size_t n) {
-    for (size_t i = 0; i < n; ++i) out[i] = draw();
-  };
+  auto elts = [&](E* out, size_t n) { h256_sample_many(out, n, [&](uint8_t* b, size_t nb) { rng(user, b, nb); }); };
   auto row = [&](size_t i) { return H + i * hw; };
   std::fill(H, H + p.nrow * hw, e32_zero());
   elts(row(p.ildt), p.block);  // layout_blinding_rows (:171-205)
@@ -921,7 +957,10 @@ int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, co
   const lfgpu_circuit* C = z->C;
   const size_t nl = C->layers.size();
   LF_HIP(c, hipSetDevice(c->device));
-  auto draw = [&] { return h256_sample([&](uint8_t* b, size_t n) { rng(rng_user, b, n); }); };
+  std::vector<E> pads(z->pad_size - nl);  // every element fill_pad draws (the product wc0 * wc1 is computed), in order
+  h256_sample_many(pads.data(), pads.size(), [&](uint8_t* b, size_t n) { rng(rng_user, b, n); });
+  size_t pd = 0;
+  auto draw = [&] { return pads[pd++]; };
   std::vector<E> Wv(z->param.nw);
   memcpy(Wv.data(), (const E*)h_W + z->npub, z->n_witness * 32);
   z->pad.assign(nl, {});
