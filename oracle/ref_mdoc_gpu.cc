@@ -1,0 +1,180 @@
+// ref_mdoc_gpu.cc -- BASELINE config 5 end to end, EXECUTED with the library in the reference's place: the body of
+// run_mdoc_prover (lib/circuits/mdoc/mdoc_zk.cc:398-546) on the reference's own example (kZkSpecs[0], mdoc_tests[0],
+// age_over_18 -- mdoc_zk_test.cc:652-685) twice over the same witness and the same deterministic RandomEngine:
+//   (a) with the reference's ZkProver<f_128, RSFactory> / ZkProver<Fp256Base, RSFactory_b>                (one CPU thread)
+//   (b) with lfgpu::GpuZkProver<f_128, ReadBuffer> / lfgpu::GpuZkProver<Fp256Base, ReadBuffer>            (liblfgpu.so)
+// Everything else -- circuit generation and parsing, CBOR/mdoc witness filling, the shared transcript, the MAC key drawn
+// from it between the commits and the proofs, update_macs, ZkProof::write of both proofs into the mdoc proof string -- is
+// the reference's code in both runs.  Prints the SHA-256 of the two proof strings (they must be equal), the reference
+// verifier's verdict on (b), and wall times.  Built by oracle/Makefile (_ref/mdoc_gpu) in the build container from the
+// reference sources where they lie; runs on the GPU box.
+#include <chrono>
+#include <cstdio>
+#include <string>
+
+#include "circuits/mdoc/mdoc_zk.cc"
+
+#include "circuits/mdoc/mdoc_examples.h"
+#include "circuits/mdoc/mdoc_test_attributes.h"
+
+#include "lfgpu_zk_adapters.h"
+
+namespace proofs {
+class LcgRng : public RandomEngine {
+ public:
+  explicit LcgRng(uint64_t seed) : s_(seed) {}
+  void bytes(uint8_t* buf, size_t n) override {
+    for (size_t i = 0; i < n; ++i) {
+      s_ = s_ * 6364136223846793005ull + 1442695040888963407ull;
+      buf[i] = static_cast<uint8_t>(s_ >> 32);
+    }
+  }
+
+ private:
+  uint64_t s_;
+};
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static std::string sha_hex(const std::vector<uint8_t>& b) {
+  uint8_t dg[32];
+  SHA256 sha;
+  sha.Update(b.data(), b.size());
+  sha.DigestData(dg);
+  char s[65];
+  for (int i = 0; i < 32; ++i) snprintf(s + 2 * i, 3, "%02x", dg[i]);
+  return s;
+}
+
+// mdoc_zk.cc:494-538 with the two provers as parameters
+template <class HashProver, class SigProver>
+static bool prove_both(HashProver& hash_p, SigProver& sig_p, const Circuit<f_128>& c_hash, const Circuit<Fp256Base>& c_sig, const Dense<f_128>& W_hash0,
+                       const Dense<Fp256Base>& W_sig0, const MdocTests* test, const ZkSpecStruct* zk_spec, const ProverState& state, size_t attrs_len, const f_128& Fs,
+                       std::vector<uint8_t>& buf, double ms[2]) {
+  auto W_hash_p = W_hash0.clone();  // update_macs writes into the witnesses: every run starts from the same ones
+  auto W_sig_p = W_sig0.clone();
+  Dense<f_128>& W_hash = *W_hash_p;
+  Dense<Fp256Base>& W_sig = *W_sig_p;
+  Transcript tp(test->transcript, test->transcript_size, zk_spec->version);
+  LcgRng rng(42);
+  const size_t r = zk_spec->version < 7 ? kLigeroRate : kLigeroRatev7;
+  const size_t req = zk_spec->version < 7 ? kLigeroNreq : kLigeroNreqv7;
+  ZkProof<f_128> h_zk(c_hash, r, req, zk_spec->block_enc_hash);
+  ZkProof<Fp256Base> sig_zk(c_sig, r, req, zk_spec->block_enc_sig);
+  const double t0 = now_ms();
+  hash_p.commit(h_zk, W_hash, tp, rng);
+  sig_p.commit(sig_zk, W_sig, tp, rng);
+  const double t1 = now_ms();
+  gf2k av = generate_mac_key(tp), macs[6];
+  uint8_t macs_b[6 * f_128::kBytes];
+  compute_macs(3, state.common, macs, macs_b, state.ap, av);
+  update_macs(W_sig, W_hash, kSigMacIndex, getHashMacIndex(attrs_len, zk_spec->version), macs, av, Fs);
+  const double t2 = now_ms();
+  if (!hash_p.prove(h_zk, W_hash, tp)) return false;
+  if (!sig_p.prove(sig_zk, W_sig, tp)) return false;
+  const double t3 = now_ms();
+  ms[0] = t1 - t0;
+  ms[1] = t3 - t2;
+  buf.clear();
+  buf.insert(buf.begin(), macs_b, macs_b + 6 * f_128::kBytes);  // [6 mac values] [hash proof] [sig proof]
+  h_zk.write(buf, Fs);
+  sig_zk.write(buf, p256_base);
+  return true;
+}
+
+int mdoc_gpu(int reps, bool with_ref) {
+  set_log_level(ERROR);
+  const ZkSpecStruct* zk_spec = &kZkSpecs[0];
+  uint8_t* bcp;
+  size_t bcsz;
+  const double tg0 = now_ms();
+  if (generate_circuit(zk_spec, &bcp, &bcsz) != CIRCUIT_GENERATION_SUCCESS) return 3;
+  const double tg1 = now_ms();
+  const MdocTests* test = &mdoc_tests[0];
+  const RequestedAttribute attrs[] = {test::age_over_18};
+  const size_t attrs_len = 1;
+  Elt pkX, pkY;
+  if (!parsePk(test->pkx.as_pointer, test->pky.as_pointer, pkX, pkY)) return 4;
+  const f2_p256 p256_2(p256_base);
+  const f_128 Fs;
+  std::unique_ptr<Circuit<Fp256Base>> c_sig;
+  std::unique_ptr<Circuit<f_128>> c_hash;
+  std::vector<uint8_t> bytes(kCircuitSizeMax);
+  const size_t full_size = decompress(bytes, bcp, bcsz);
+  if (full_size == 0) return 5;
+  size_t sig_len, hash_len;
+  double t_parse_ref;
+  {
+    const double t0 = now_ms();
+    ReadBuffer rb(bytes.data(), full_size);
+    CircuitReader<Fp256Base> cr_s(p256_base, P256_ID);
+    c_sig = cr_s.from_bytes(rb, false);
+    sig_len = full_size - rb.remaining();
+    CircuitReader<f_128> cr_h(Fs, GF2_128_ID);
+    c_hash = cr_h.from_bytes(rb, false);
+    hash_len = full_size - rb.remaining() - sig_len;
+    if (!c_sig || !c_hash) return 6;
+    t_parse_ref = now_ms() - t0;
+  }
+  auto W_sig = Dense<Fp256Base>(1, c_sig->ninputs);
+  auto W_hash = Dense<f_128>(1, c_hash->ninputs);
+  DenseFiller<Fp256Base> sig_filler(W_sig);
+  DenseFiller<f_128> hash_filler(W_hash);
+  SecureRandomEngine srng;  // fill_witness takes this concrete type (MAC key shares): both runs below share the witness it makes
+  ProverState state;
+  const double tw0 = now_ms();
+  if (fill_witness(sig_filler, hash_filler, test->mdoc, test->mdoc_size, pkX, pkY, test->transcript, test->transcript_size, attrs, attrs_len,
+                   (const uint8_t*)test->now, state, srng, Fs, zk_spec->version) != MDOC_PROVER_SUCCESS)
+    return 7;
+  const double t_witness = now_ms() - tw0;
+
+  // (a) the reference's provers
+  std::vector<uint8_t> proof_ref;
+  double ms_ref[2] = {0, 0};
+  if (with_ref) {
+    const Elt2 omega = p256_2.of_string(kRootX, kRootY);
+    const FftExtConvolutionFactory fft_b(p256_base, p256_2, omega, 1ull << 31);
+    const RSFactory_b rsf_b(fft_b, p256_base);
+    const RSFactory rsf(Fs);
+    ZkProver<f_128, RSFactory> hash_p(*c_hash, Fs, rsf);
+    ZkProver<Fp256Base, RSFactory_b> sig_p(*c_sig, p256_base, rsf_b);
+    if (!prove_both(hash_p, sig_p, *c_hash, *c_sig, W_hash, W_sig, test, zk_spec, state, attrs_len, Fs, proof_ref, ms_ref)) return 8;
+  }
+
+  // (b) the library's provers behind the same two calls
+  std::vector<uint8_t> proof_gpu;
+  double ms_gpu[2] = {0, 0}, t_upload;
+  {
+    lfgpu::Context ctx(0);
+    const double t0 = now_ms();
+    lfgpu::GpuZkProver<Fp256Base, ReadBuffer> sig_p(ctx, bytes.data(), sig_len, p256_base);
+    lfgpu::GpuZkProver<f_128, ReadBuffer> hash_p(ctx, bytes.data() + sig_len, hash_len, Fs);
+    t_upload = now_ms() - t0;
+    for (int rep = 0; rep < reps; ++rep)  // the last repetition is the one reported (tables, twiddles and bind structure cached)
+      if (!prove_both(hash_p, sig_p, *c_hash, *c_sig, W_hash, W_sig, test, zk_spec, state, attrs_len, Fs, proof_gpu, ms_gpu)) return 9;
+  }
+
+  // the reference's verifier on the library's proof string
+  const double tv0 = now_ms();
+  const MdocVerifierErrorCode vr =
+      run_mdoc_verifier(bcp, bcsz, test->pkx.as_pointer, test->pky.as_pointer, test->transcript, test->transcript_size, attrs, attrs_len,
+                        (const char*)test->now, proof_gpu.data(), proof_gpu.size(), test->doc_type, zk_spec);
+  const double t_verify = now_ms() - tv0;
+  printf(
+      "{\"proof_bytes\": %zu, \"gpu_sha256\": \"%s\", \"ref_sha256\": \"%s\", \"identical\": %s, \"reference_verifier_accepts_gpu_proof\": %s, "
+      "\"gpu_ms\": {\"commit\": %.2f, \"prove\": %.2f, \"total\": %.2f}, \"ref_ms\": {\"commit\": %.2f, \"prove\": %.2f, \"total\": %.2f}, "
+      "\"host_ms\": {\"generate_circuit\": %.1f, \"reference_parse\": %.1f, \"fill_witness\": %.1f, \"gpu_parse_upload\": %.1f, \"reference_verify\": %.1f}, "
+      "\"circuit_bytes\": {\"sig\": %zu, \"hash\": %zu}}\n",
+      proof_gpu.size(), sha_hex(proof_gpu).c_str(), with_ref ? sha_hex(proof_ref).c_str() : "", with_ref && proof_ref == proof_gpu ? "true" : "false",
+      vr == MDOC_VERIFIER_SUCCESS ? "true" : "false", ms_gpu[0], ms_gpu[1], ms_gpu[0] + ms_gpu[1], ms_ref[0], ms_ref[1], ms_ref[0] + ms_ref[1], tg1 - tg0,
+      t_parse_ref, t_witness, t_upload, t_verify, sig_len, hash_len);
+  free(bcp);
+  if (with_ref && proof_ref != proof_gpu) return 10;
+  return vr == MDOC_VERIFIER_SUCCESS ? 0 : 11;
+}
+}  // namespace proofs
+
+int main(int argc, char** argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 2;
+  const bool with_ref = !(argc > 2 && std::string(argv[2]) == "--no-ref");
+  return proofs::mdoc_gpu(reps < 1 ? 1 : reps, with_ref);
+}
