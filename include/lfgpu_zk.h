@@ -114,6 +114,13 @@ int lfgpu_zk_verify(lfgpu_ctx* ctx, const lfgpu_circuit* c, size_t rateinv, size
                     const uint8_t* proof, size_t proof_len, const void* h_pub, const lfgpu_transcript_ops* ts, int* ok,
                     const char** why);
 
+/* The same with ZkVerifier::recv_commitment already done by the caller (the commitment root -- the first 32 proof bytes --
+ * written to the transcript with write_bytes): the reference keeps the two calls apart, and run_mdoc_verifier receives both
+ * commitments and draws its MAC key before it verifies either proof (lib/circuits/mdoc/mdoc_zk.cc:676-681,704-705). */
+int lfgpu_zk_verify_committed(lfgpu_ctx* ctx, const lfgpu_circuit* c, size_t rateinv, size_t nreq, size_t block_enc,
+                              const uint8_t* proof, size_t proof_len, const void* h_pub, const lfgpu_transcript_ops* ts,
+                              int* ok, const char** why);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,8 @@
 // engine stay the CALLER's objects, reached through hooks, so the bytes written to / drawn from them are the reference's.
 // The proof comes back through ZkProof::read on the wire bytes, i.e. in exactly the form a verifier would receive it.
 //
+// lfgpu::GpuZkVerifier<Field> does the same for ZkVerifier (recv_commitment / verify).
+//
 // `lfc1` = the circuit in the reference's own serialisation (CircuitWriter::to_bytes, or the span of the decompressed
 // circuit file that CircuitReader::from_bytes consumed for this circuit).  This header includes no reference header.
 #ifndef LFGPU_ZK_ADAPTERS_H_
@@ -132,6 +134,48 @@ class GpuZkProver {
   const Field& f_;
   lfgpu_circuit* circuit_ = nullptr;
   lfgpu_zk_prover* zk_ = nullptr;
+};
+
+// Drop-in for ZkVerifier<Field, ReedSolomonFactory> (lib/zk/zk_verifier.h:42-94; call sites lib/circuits/mdoc/mdoc_zk.cc:669-705):
+// recv_commitment writes the commitment to the caller's transcript exactly as LigeroTranscript::write_commitment does,
+// verify serialises the caller's ZkProof with its own ZkProof::write and hands the wire bytes to lfgpu_zk_verify_committed.
+template <class Field>
+class GpuZkVerifier {
+ public:
+  GpuZkVerifier(const Context& ctx, const uint8_t* lfc1, size_t len, size_t rate, size_t nreq, size_t block_enc, const Field& F)
+      : c_(ctx), f_(F), rate_(rate), nreq_(nreq), block_enc_(block_enc) {
+    check(c_.get(), lfgpu_circuit_from_lfc1(c_.get(), lfc1, len, &circuit_), "lfgpu_circuit_from_lfc1");
+  }
+  ~GpuZkVerifier() {
+    if (circuit_) lfgpu_circuit_free(circuit_);
+  }
+  GpuZkVerifier(const GpuZkVerifier&) = delete;
+  GpuZkVerifier& operator=(const GpuZkVerifier&) = delete;
+
+  template <class ZkProofT, class TranscriptT>
+  void recv_commitment(const ZkProofT& zk, TranscriptT& t) const {
+    t.write(zk.com.root.data, 32);
+  }
+  template <class ZkProofT, class DenseT, class TranscriptT>
+  bool verify(const ZkProofT& zk, const DenseT& pub, TranscriptT& tv) const {
+    std::vector<uint8_t> wire;
+    zk.write(wire, f_);
+    detail::TranscriptHook<Field, TranscriptT> hook{&tv, &f_, nullptr};
+    const lfgpu_transcript_ops ops = hook.ops();
+    int ok = 0;
+    const char* why = nullptr;
+    check(c_.get(),
+          lfgpu_zk_verify_committed(c_.get(), circuit_, rate_, nreq_, block_enc_, wire.data(), wire.size(), pub.v_.data(), &ops, &ok, &why),
+          "lfgpu_zk_verify_committed");
+    if (!ok && why) std::fprintf(stderr, "lfgpu: verify failed: %s\n", why);
+    return ok != 0;
+  }
+
+ private:
+  const Context& c_;
+  const Field& f_;
+  size_t rate_, nreq_, block_enc_;
+  lfgpu_circuit* circuit_ = nullptr;
 };
 
 }  // namespace lfgpu

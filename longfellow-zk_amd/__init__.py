@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "lfgpu_transcript_write_elt", "lfgpu_transcript_write_elt_array", "lfgpu_transcript_bytes", "lfgpu_sha256",
     "lfgpu_aes256_ecb_block", "lfgpu_host_gf2128_mul", "lfgpu_crypto_hw", "lfgpu_circuit_from_lfc1", "lfgpu_circuit_get_info", "lfgpu_circuit_layer_info",
     "lfgpu_circuit_free", "lfgpu_zk_prover_new", "lfgpu_zk_prover_param", "lfgpu_zk_commit", "lfgpu_zk_prove",
-    "lfgpu_zk_proof_write", "lfgpu_zk_timings", "lfgpu_zk_prover_free", "lfgpu_zk_verify",
+    "lfgpu_zk_proof_write", "lfgpu_zk_timings", "lfgpu_zk_prover_free", "lfgpu_zk_verify", "lfgpu_zk_verify_committed",
 ]
 
 
@@ -151,6 +151,7 @@ def load_library():
         "lfgpu_zk_timings": [vp, C.POINTER(C.c_double)],
         "lfgpu_zk_prover_free": [vp],
         "lfgpu_zk_verify": [vp, vp, sz, sz, sz, vp, sz, vp, C.POINTER(TranscriptOps), C.POINTER(ci), C.POINTER(C.c_char_p)],
+        "lfgpu_zk_verify_committed": [vp, vp, sz, sz, sz, vp, sz, vp, C.POINTER(TranscriptOps), C.POINTER(ci), C.POINTER(C.c_char_p)],
         "lfgpu_crypto_hw": [ci],
     }
     for name, args in sig.items():
@@ -637,13 +638,15 @@ class ZkProver:
             self.h = None
 
 
-def zk_verify(gpu, circuit, proof, pub, transcript, rate=7, nreq=132, block_enc=0):
-    """ZkVerifier::recv_commitment + verify over the wire bytes -> (accepted, reason)"""
+def zk_verify(gpu, circuit, proof, pub, transcript, rate=7, nreq=132, block_enc=0, committed=False):
+    """ZkVerifier::recv_commitment + verify over the wire bytes -> (accepted, reason); committed=True: the caller has already
+    written the commitment root to the transcript (ZkVerifier::recv_commitment as a separate step, as in run_mdoc_verifier)"""
     import numpy as np
     pub = np.ascontiguousarray(pub)
     ok, why = C.c_int(), C.c_char_p()
     ops = transcript.ops()
     raw = bytes(proof)
-    gpu._ck(gpu.L.lfgpu_zk_verify(gpu.h, circuit.h, rate, nreq, block_enc, raw, len(raw), C.c_void_p(pub.ctypes.data) if pub.size else None,
-                                  C.byref(ops), C.byref(ok), C.byref(why)))
+    fn = gpu.L.lfgpu_zk_verify_committed if committed else gpu.L.lfgpu_zk_verify
+    gpu._ck(fn(gpu.h, circuit.h, rate, nreq, block_enc, raw, len(raw), C.c_void_p(pub.ctypes.data) if pub.size else None,
+               C.byref(ops), C.byref(ok), C.byref(why)))
     return bool(ok.value), (why.value or b"").decode()

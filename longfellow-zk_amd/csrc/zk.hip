@@ -1039,7 +1039,9 @@ bool parse_proof(const lfgpu_circuit* C, const lfgpu_ligero_param& p, const GfHo
   return !rd.bad;
 }
 
-void hash2(const uint8_t* a, const uint8_t* b, uint8_t out[32]) {  // Digest::hash2: SHA-256(left || right)
+}  // namespace
+
+static void hash2(const uint8_t* a, const uint8_t* b, uint8_t out[32]) {  // Digest::hash2: SHA-256(left || right)
   Sha256 s;
   s.update(a, 32);
   s.update(b, 32);
@@ -1047,7 +1049,7 @@ void hash2(const uint8_t* a, const uint8_t* b, uint8_t out[32]) {  // Digest::ha
 }
 
 // MerkleTreeVerifier::verify_compressed_proof (merkle_tree.h:160-209)
-bool merkle_verify(size_t n, const uint8_t root[32], const uint8_t* path, size_t npath, const uint8_t* leaves, const size_t* pos, size_t np) {
+bool lf_merkle_verify(size_t n, const uint8_t root[32], const uint8_t* path, size_t npath, const uint8_t* leaves, const size_t* pos, size_t np) {
   std::vector<uint8_t> layers(2 * n * 32, 0);
   std::vector<bool> defined(2 * n, false), tree(2 * n, false);
   for (size_t ip = 0; ip < np; ++ip) {
@@ -1079,15 +1081,24 @@ bool merkle_verify(size_t n, const uint8_t root[32], const uint8_t* path, size_t
     }
   return defined[1] && memcmp(root, &layers[32], 32) == 0;
 }
-}  // namespace
 
+static int zk_verify_impl(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc, const uint8_t* proof, size_t proof_len,
+                          const void* h_pub, const lfgpu_transcript_ops* tso, bool committed, int* ok, const char** why_out);
 extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc, const uint8_t* proof,
                                size_t proof_len, const void* h_pub, const lfgpu_transcript_ops* tso, int* ok, const char** why_out) {
+  return zk_verify_impl(c, C, rateinv, nreq, block_enc, proof, proof_len, h_pub, tso, false, ok, why_out);
+}
+extern "C" int lfgpu_zk_verify_committed(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc, const uint8_t* proof,
+                                         size_t proof_len, const void* h_pub, const lfgpu_transcript_ops* tso, int* ok, const char** why_out) {
+  return zk_verify_impl(c, C, rateinv, nreq, block_enc, proof, proof_len, h_pub, tso, true, ok, why_out);
+}
+static int zk_verify_impl(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc, const uint8_t* proof, size_t proof_len,
+                          const void* h_pub, const lfgpu_transcript_ops* tso, bool committed, int* ok, const char** why_out) {
   static const char* kWhy[] = {"ok", "proof does not parse", "merkle_check failed", "low_degree_check failed", "dot_check failed",
                                "wrong dot product", "quadratic_check failed"};
   if (!c || !C || C->c != c || !proof || !tso || !ok || (C->info.npub_in && !h_pub)) return LFGPU_ERR_ARG;
   *ok = 0;
-  if (C->info.field == LFGPU_FIELD_P256) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "zk_verify: no verifier for Fp256Base circuits yet (the prover is zk256.hip)");
+  if (C->info.field == LFGPU_FIELD_P256) return zk256_verify(c, C, rateinv, nreq, block_enc, proof, proof_len, h_pub, tso, committed, ok, why_out);
   auto fail = [&](int w) {
     if (why_out) *why_out = kWhy[w];
     return LFGPU_OK;
@@ -1111,8 +1122,9 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
   const Ts ts{tso, tso->user, field};
   const elt_t* pub = (const elt_t*)h_pub;
 
-  // recv_commitment, initialize_sumcheck_fiat_shamir
-  ts.write_bytes(pr.root, 32);
+  // recv_commitment (unless the caller has done it: ZkVerifier::recv_commitment and verify are separate calls, and the mdoc
+  // verifier draws its MAC key between them, mdoc_zk.cc:676-681), initialize_sumcheck_fiat_shamir
+  if (!committed) ts.write_bytes(pr.root, 32);
   ts.write_bytes(I.id, 32);
   for (size_t i = 0; i < npub; ++i) ts.write_elt(pub[i]);
   ts.write_elt(elt_t{0, 0});
@@ -1165,7 +1177,7 @@ extern "C" int lfgpu_zk_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rate
       }
       s.digest(&leaves[32 * r]);
     }
-    if (!merkle_verify(p.block_ext, pr.root, pr.path.data(), pr.npath, leaves.data(), idx.data(), p.nreq)) return fail(2);
+    if (!lf_merkle_verify(p.block_ext, pr.root, pr.path.data(), pr.npath, leaves.data(), idx.data(), p.nreq)) return fail(2);
   }
 
   tv[3] = now_ms();

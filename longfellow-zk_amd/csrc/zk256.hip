@@ -12,14 +12,15 @@
 //                           lib/zk/zk_prover.h:72-188, lib/zk/zk_common.h:49-136,406-439, lib/zk/zk_proof.h:90-185
 // Sums over many terms (run sums of bind_g, the QW scatter) add the 32-bit limbs of canonical residues into 64-bit integer
 // accumulators with atomics and reduce once (fp256_reduce_limbs): exact and independent of arrival order, as for Fp128.
-// Row extension and column hashing are csrc/p256.hip.  No verifier for this field yet (the parity test compares the wire
-// bytes with the reference prover's).
+// Row extension and column hashing are csrc/p256.hip.  The verifier (ZkVerifier::verify, lib/zk/zk_verifier.h:68-94) is at
+// the end of the file.
 #include <algorithm>
 #include <chrono>
 #include <memory>
 #include <string>
 
 #include "fp256.h"
+#include "fs_crypto.h"
 #include "zkint.h"
 
 typedef elt32_t E;
@@ -341,6 +342,24 @@ __global__ __launch_bounds__(Z_THREADS) void gather_columns256_kernel(u32 nrow, 
   if (t >= nrow * nreq) return;
   const u32 i = t / nreq, j = t % nreq;
   st32(&req[t], ld32(&T[(size_t)i * ld + col0 + idx[j]]));
+}
+
+// Quad::bind_gh_all (lib/sumcheck/quad.h:188-210), the verifier's combined bind: the sum over all corners of
+// prep_v(v, beta) (EQ(G0,g) + alpha EQ(G1,g)) EQ(H0,h0) EQ(H1,h1); block sums go as limbs into 8 words
+__global__ __launch_bounds__(Z_THREADS) void bind_gh_all256_kernel(size_t n, const corner4* __restrict__ t, const E* __restrict__ kvec, const E* __restrict__ eqg,
+                                                                   const E* __restrict__ eqh0, const E* __restrict__ eqh1, E beta, u64* __restrict__ acc) {
+  __shared__ E sh[Z_THREADS];
+  E s = e32_zero();
+  for (size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * Z_THREADS) {
+    const corner4 cr = t[i];
+    E v = ld32(&kvec[cr.vi]);
+    if (e32_is_zero(v)) v = beta;  // prep_v: assert-zero terms carry beta (quad.h:213-220)
+    E qv = fp256_mul(v, ld32(&eqg[cr.g]));
+    qv = fp256_mul(qv, ld32(&eqh0[cr.h0]));
+    s = fp256_add(s, fp256_mul(qv, ld32(&eqh1[cr.h1])));
+  }
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) limbs_atomic_add(acc, s);
 }
 
 inline u32 nblk(size_t n, u32 per = Z_THREADS) { return (u32)((n + per - 1) / per ? (n + per - 1) / per : 1); }
@@ -805,20 +824,47 @@ struct Constraints256 {
   std::vector<E> b;
   size_t n = 0;
 };
-int build_constraints256(Zk256* z, const F256& F, const Ts256& ts, const E* pub, Constraints256& out) {
-  lfgpu_ctx* c = z->c;
-  const lfgpu_circuit* C = z->C;
+int bind_gh_all256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, const E* G1, const E& alpha, const E& beta, size_t logw, size_t nw, const E* H0,
+                   const E* H1, E* out) {
+  lfgpu_ctx* c = q->c;
+  if (logv > 40 || logw > 40 || ((size_t)1 << logv) < q->nv || nw == 0 || ((size_t)1 << logw) < nw || nw <= q->hmax)
+    return lf_fail(c, LFGPU_ERR_ARG, "bind_gh_all256: table sizes (nw must exceed the largest hand index %zu)", q->hmax);
+  void* sc = nullptr;
+  LF_TRY(lf_scratch3(c, (q->nv + 2 * nw) * 32 + 128, &sc));
+  E* d_eqg = (E*)sc;
+  E* d_eqh0 = d_eqg + q->nv;
+  E* d_eqh1 = d_eqh0 + nw;
+  u64* d_acc = (u64*)(d_eqh1 + nw);
+  LF_TRY(raw_eq2_256(c, F, logv, q->nv, G0, G1, alpha, d_eqg));
+  LF_TRY(raw_eq2_256(c, F, logw, nw, H0, H0, F.zero, d_eqh0));  // EQ(H0, i) + 0 * (...)
+  LF_TRY(raw_eq2_256(c, F, logw, nw, H1, H1, F.zero, d_eqh1));
+  LF_HIP(c, hipMemsetAsync(d_acc, 0, 64, c->stream));
+  hipLaunchKernelGGL(bind_gh_all256_kernel, dim3(std::min<u32>(nblk(q->n), 1024)), dim3(Z_THREADS), 0, c->stream, q->n, (const corner4*)q->d_morton,
+                     (const E*)q->d_kvec, (const E*)d_eqg, (const E*)d_eqh0, (const E*)d_eqh1, beta, d_acc);
+  LF_HIP(c, hipGetLastError());
+  u64 w[8];
+  LF_TRY(lfgpu_memcpy_d2h(c, w, d_acc, 64));
+  *out = fp256_reduce_limbs(w, F.rsq);
+  return LFGPU_OK;
+}
+
+// aux = the bound quads the prover's sumcheck recorded, or nullptr (verifier): Quad::bind_gh_all on the device per layer
+int build_constraints256(lfgpu_ctx* c, const lfgpu_circuit* C, const F256& F, const Ts256& ts, const std::vector<Zk256::LayerPad>& proof,
+                         const std::vector<E>* aux, const E* pub, E* d_eq, Constraints256& out) {
   const lfgpu_circuit_info& I = C->info;
   const size_t nl = C->layers.size(), npub = I.npub_in;
-  std::vector<E> gh[2];
-  for (size_t i = 0; i < 2 * kMaxBindings256; ++i) (void)ts.elt();  // begin_circuit: Q, then G (only the verifier's bind uses them)
+  std::vector<E> gh[2], G[2];
+  for (size_t i = 0; i < kMaxBindings256; ++i) (void)ts.elt();  // begin_circuit: Q (unused for logc = 0), then G
+  G[0].resize(kMaxBindings256);
+  for (size_t i = 0; i < kMaxBindings256; ++i) G[0][i] = ts.elt();
+  G[1] = G[0];
+  size_t logv = I.logv;
   size_t ci = 0, pi = I.ninputs - npub;
   E claims[2] = {F.zero, F.zero};
   std::vector<E> sym;
   for (size_t ly = 0; ly < nl; ++ly) {
     const size_t logw = C->layers[ly].logw;
     const E alpha = ts.elt(), beta = ts.elt();
-    (void)beta;
     const size_t n = 3 + layer_size256(logw);
     E known = F.zero;
     sym.assign(n, F.zero);
@@ -834,7 +880,7 @@ int build_constraints256(Zk256* z, const F256& F, const Ts256& ts, const E* pub,
     axpy(1, claims[1], alpha);
     gh[0].assign(logw ? logw : 1, F.zero);
     gh[1].assign(logw ? logw : 1, F.zero);
-    const auto& P = z->proof[ly];
+    const auto& P = proof[ly];
     for (size_t rnd = 0; rnd < logw; ++rnd)
       for (int hand = 0; hand < 2; ++hand) {
         const size_t r = 2 * rnd + hand;
@@ -857,7 +903,9 @@ int build_constraints256(Zk256* z, const F256& F, const Ts256& ts, const E* pub,
         axpy(3 + 2 * r, t0e, lag[0]);
         axpy(3 + 2 * r + 1, t2e, lag[2]);
       }
-    const E eqq = z->aux[ly];  // EQ[Q,C] QUAD[R,L], recorded by the sumcheck prover
+    E eqq;  // EQ[Q,C] QUAD[R,L] (Eq::eval with logc = 0 is 1)
+    if (aux) eqq = (*aux)[ly];
+    else LF_TRY(bind_gh_all256(C->layers[ly].q, F, logv, G[0].data(), G[1].data(), alpha, beta, logw, C->layers[ly].nw, gh[0].data(), gh[1].data(), &eqq));
     const size_t cp = 3 + 4 * logw, skip = ly == 0 ? 3 : 0;  // ConstraintBuilder::finalize
     out.b.push_back(F.sub(F.mul(eqq, F.mul(P.wc[0], P.wc[1])), known));
     sym[cp] = F.sub(sym[cp], F.mul(eqq, P.wc[1]));
@@ -868,6 +916,11 @@ int build_constraints256(Zk256* z, const F256& F, const Ts256& ts, const E* pub,
     ts.write_array(P.wc, 2);
     claims[0] = P.wc[0];
     claims[1] = P.wc[1];
+    for (int h = 0; h < 2; ++h) {
+      G[h].assign(kMaxBindings256, F.zero);
+      for (size_t r = 0; r < logw; ++r) G[h][r] = gh[h][r];
+    }
+    logv = logw;
     pi += layer_size256(logw);
   }
   const E alpha = ts.elt();
@@ -875,10 +928,10 @@ int build_constraints256(Zk256* z, const F256& F, const Ts256& ts, const E* pub,
   out.a.push_back({ci, pi - 2, F.sub(F.zero, alpha)});
   out.n = ci + 1;
   const size_t logn = C->layers[nl - 1].logw;
-  LF_TRY(raw_eq2_256(c, F, logn, I.ninputs, gh[0].data(), gh[1].data(), alpha, (E*)z->d_eq));
+  LF_TRY(raw_eq2_256(c, F, logn, I.ninputs, gh[0].data(), gh[1].data(), alpha, d_eq));
   std::vector<E> eq_in(npub ? npub : 1);
-  if (npub) LF_TRY(lfgpu_memcpy_d2h(c, eq_in.data(), z->d_eq, npub * 32));
-  const auto& P = z->proof[nl - 1];
+  if (npub) LF_TRY(lfgpu_memcpy_d2h(c, eq_in.data(), d_eq, npub * 32));
+  const auto& P = proof[nl - 1];
   E pub_binding = F.zero;
   for (size_t i = 0; i < npub; ++i) pub_binding = F.add(pub_binding, F.mul(eq_in[i], pub[i]));
   out.b.push_back(F.sub(F.add(P.wc[0], F.mul(alpha, P.wc[1])), pub_binding));
@@ -1098,7 +1151,7 @@ int zk256_prove(Zk256* z, const void* h_W, const lfgpu_transcript_ops* tso, int*
   // verifier_constraints with aux: replay the verifier symbolically on the ORIGINAL transcript
   t0 = now_ms();
   Constraints256 cs;
-  LF_TRY(build_constraints256(z, F, ts, W, cs));
+  LF_TRY(build_constraints256(c, C, F, ts, z->proof, &z->aux, W, (E*)z->d_eq, cs));
   const lfgpu_ligero_param& p = z->param;
   z->ms[4] = now_ms() - t0;
 
@@ -1193,4 +1246,235 @@ int zk256_proof_write(const Zk256* z, uint8_t* buf, size_t cap, size_t* nbytes) 
     memcpy(buf, o.data(), o.size());
   }
   return LFGPU_OK;
+}
+
+// ------------------------------------------------------------------ ZkVerifier<Fp256Base>
+// ZkVerifier::recv_commitment + verify (lib/zk/zk_verifier.h:68-94) over the wire bytes, as zk.hip does for the 16-byte
+// fields: ZkProof::read (zk_proof.h:107-112,218-345), verifier_constraints with aux == nullptr (Quad::bind_gh_all on the
+// device), LigeroVerifier::verify (lib/ligero/ligero_verifier.h:42-270: Reed-Solomon extension of the rows of A and of the
+// three y vectors on the device, checks at the opened columns on the host), MerkleCommitmentVerifier::verify.
+namespace {
+struct Parsed256 {
+  uint8_t root[32];
+  std::vector<Zk256::LayerPad> sc;
+  std::vector<E> y_ldt, y_dot, y_q0, y_q2, req;
+  std::vector<uint8_t> nonces, path;
+  size_t npath = 0;
+};
+bool parse_proof256(const lfgpu_circuit* C, const lfgpu_ligero_param& p, const uint8_t* buf, size_t len, Parsed256& pr) {
+  const uint8_t* q = buf;
+  size_t left = len;
+  bool bad = false;
+  auto have = [&](size_t n) { return left >= n; };
+  auto next = [&](size_t n) {
+    const uint8_t* r = q;
+    q += n;
+    left -= n;
+    return r;
+  };
+  auto elt = [&] {
+    E e = e32_zero();
+    if (!h256_of_bytes(next(32), e)) bad = true;  // of_bytes_field: value >= p
+    return e;
+  };
+  auto size4 = [&] {
+    const uint8_t* b = next(4);
+    return (size_t)b[0] | (size_t)b[1] << 8 | (size_t)b[2] << 16 | (size_t)b[3] << 24;
+  };
+  if (!have(32)) return false;
+  memcpy(pr.root, next(32), 32);
+  pr.sc.assign(C->layers.size(), {});
+  for (size_t ly = 0; ly < C->layers.size(); ++ly) {
+    const size_t logw = C->layers[ly].logw;
+    if (!have((logw * 4 + 2) * 32)) return false;
+    auto& P = pr.sc[ly];
+    P.hp[0].resize(2 * logw);
+    P.hp[1].resize(2 * logw);
+    for (size_t wi = 0; wi < logw; ++wi)
+      for (int k = 0; k < 2; ++k) {
+        P.hp[0][2 * wi + k] = elt();
+        P.hp[1][2 * wi + k] = elt();
+      }
+    P.wc[0] = elt();
+    P.wc[1] = elt();
+  }
+  auto vec = [&](std::vector<E>& v, size_t n) {
+    if (!have(n * 32)) return false;
+    v.resize(n);
+    for (auto& e : v) e = elt();
+    return true;
+  };
+  if (!vec(pr.y_ldt, p.block) || !vec(pr.y_dot, p.dblock) || !vec(pr.y_q0, p.r) || !vec(pr.y_q2, p.dblock - p.block)) return false;
+  if (!have(p.nreq * 32)) return false;
+  pr.nonces.assign(q, q + p.nreq * 32);
+  next(p.nreq * 32);
+  const size_t total = p.nreq * p.nrow;
+  constexpr size_t kMaxRunLen = (size_t)1 << 25, kMaxNumDigests = (size_t)1 << 25;
+  pr.req.assign(total, e32_zero());
+  size_t ci = 0;
+  while (ci < total) {  // alternating full-field / subfield runs; both are 32-byte images for a prime field
+    if (!have(4)) return false;
+    const size_t runlen = size4();
+    if (runlen >= kMaxRunLen || ci + runlen > total || !have(runlen * 32)) return false;
+    for (size_t i = ci; i < ci + runlen; ++i) pr.req[i] = elt();
+    ci += runlen;
+  }
+  if (!have(4)) return false;
+  const size_t sz = size4();
+  if (sz < p.nreq || sz >= kMaxNumDigests || sz > p.nreq * p.mc_pathlen || !have(sz * 32)) return false;
+  pr.npath = sz;
+  pr.path.assign(q, q + sz * 32);
+  next(sz * 32);
+  return !bad;
+}
+}  // namespace
+
+int zk256_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc, const uint8_t* proof, size_t proof_len, const void* h_pub,
+                 const lfgpu_transcript_ops* tso, bool committed, int* ok, const char** why_out) {
+  static const char* kWhy[] = {"ok", "proof does not parse", "merkle_check failed", "low_degree_check failed", "dot_check failed", "wrong dot product",
+                               "quadratic_check failed"};
+  *ok = 0;
+  LF_TRY(ts256_ok(c, tso));
+  auto fail = [&](int w) {
+    if (why_out) *why_out = kWhy[w];
+    return LFGPU_OK;
+  };
+  const lfgpu_circuit_info& I = C->info;
+  const size_t nl = C->layers.size(), npub = I.npub_in, n_witness = I.ninputs - npub;
+  size_t pad_size = 0;
+  for (const auto& l : C->layers) pad_size += layer_size256(l.logw);
+  lfgpu_ligero_param p{};
+  LF_TRY(lfgpu_ligero_param_init(&p, LFGPU_FIELD_P256, 0, n_witness + pad_size, nl, rateinv, nreq, block_enc));
+  Parsed256 pr;
+  if (!parse_proof256(C, p, proof, proof_len, pr)) return fail(1);
+  LF_HIP(c, hipSetDevice(c->device));
+  const F256 F;
+  const Ts256 ts{tso, tso->user};
+  const E* pub = (const E*)h_pub;
+  // recv_commitment (unless the caller did it), initialize_sumcheck_fiat_shamir
+  if (!committed) ts.write_bytes(pr.root, 32);
+  ts.write_bytes(I.id, 32);
+  for (size_t i = 0; i < npub; ++i) ts.write_elt(pub[i]);
+  ts.write_elt(F.zero);
+  {
+    std::vector<uint8_t> zb(I.nterms, 0);
+    ts.write_bytes(zb.data(), zb.size());
+  }
+  // device buffers: EQ table of the input constraint | rows [0, nwqrow) = [0^r | A_i], then y_ldt, y_dot, y_quad | gathered columns
+  const size_t nrows_dev = p.nwqrow + 3, ld = p.block_enc;
+  void* dv = nullptr;
+  LF_TRY(lf_scratch4(c, (I.ninputs + nrows_dev * ld + nrows_dev * p.nreq) * 32 + 256, &dv));
+  E* d_eq = (E*)dv;
+  E* d_T = d_eq + I.ninputs;
+  E* d_req = d_T + nrows_dev * ld;
+  Constraints256 cs;
+  LF_TRY(build_constraints256(c, C, F, ts, pr.sc, nullptr, pub, d_eq, cs));
+  std::vector<size_t> lqc(3 * nl);
+  {
+    size_t pi = n_witness;
+    for (size_t ly = 0; ly < nl; ++ly) {  // setup_lqc (zk_common.h:149-160)
+      const size_t cp = pi + 4 * C->layers[ly].logw;
+      lqc[3 * ly] = cp;
+      lqc[3 * ly + 1] = cp + 1;
+      lqc[3 * ly + 2] = cp + 2;
+      pi += layer_size256(C->layers[ly].logw);
+    }
+  }
+  // LigeroVerifier::verify: replay the challenges
+  uint8_t hash_of_A[32] = {0xde, 0xad, 0xbe, 0xef};
+  ts.write_bytes(hash_of_A, 32);
+  std::vector<E> u_ldt(p.nwqrow), alphal(cs.n), alphaq(3 * p.nq), u_quad(p.nqtriples ? p.nqtriples : 1);
+  for (auto& e : u_ldt) e = ts.elt();
+  for (auto& e : alphal) e = ts.elt();
+  for (auto& e : alphaq) e = ts.elt();
+  for (size_t i = 0; i < p.nqtriples; ++i) u_quad[i] = ts.elt();
+  ts.write_array(pr.y_ldt.data(), pr.y_ldt.size());
+  ts.write_array(pr.y_dot.data(), pr.y_dot.size());
+  ts.write_array(pr.y_q0.data(), pr.y_q0.size());
+  ts.write_array(pr.y_q2.data(), pr.y_q2.size());
+  std::vector<size_t> idx(p.nreq);
+  ts.choose(p.block_ext, p.nreq, idx.data());
+  auto req_at = [&](size_t i, size_t j) -> const E& { return pr.req[i * p.nreq + j]; };
+  {  // merkle_check: leaf r = SHA-256(nonce_r || column r of the opening)
+    std::vector<uint8_t> leaves(p.nreq * 32);
+    for (size_t r = 0; r < p.nreq; ++r) {
+      Sha256 sh;
+      sh.update(&pr.nonces[32 * r], 32);
+      for (size_t i = 0; i < p.nrow; ++i) {
+        uint8_t eb[32];
+        h256_to_bytes(req_at(i, r), eb);
+        sh.update(eb, 32);
+      }
+      sh.digest(&leaves[32 * r]);
+    }
+    if (!lf_merkle_verify(p.block_ext, pr.root, pr.path.data(), pr.npath, leaves.data(), idx.data(), p.nreq)) return fail(2);
+  }
+  // rows of A (inner_product_vector + layout_Aext), y vectors; extension to block_enc; the opened columns
+  std::vector<uint64_t> a_idx;
+  std::vector<E> a_val;
+  inner_product_sparse256(F, p, cs, alphal, lqc, alphaq, a_idx, a_val);
+  LF_HIP(c, hipMemset2DAsync(d_T, ld * 32, 0, p.dblock * 32, nrows_dev, c->stream));
+  hipLaunchKernelGGL(a_rows_dense256_kernel, dim3(nblk(n_witness)), dim3(Z_THREADS), 0, c->stream, (u32)p.r, (u32)p.w, ld, alphal[cs.n - 1], (const E*)d_eq + npub,
+                     n_witness, d_T);
+  if (!a_idx.empty()) {
+    void* d_sp = nullptr;
+    LF_TRY(lf_scratch2(c, a_idx.size() * 40 + 64, &d_sp));
+    E* d_val = (E*)d_sp;
+    u64* d_idx = (u64*)(d_val + a_idx.size());
+    LF_HIP(c, hipMemcpyAsync(d_val, a_val.data(), a_idx.size() * 32, hipMemcpyHostToDevice, c->stream));
+    LF_HIP(c, hipMemcpyAsync(d_idx, a_idx.data(), a_idx.size() * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(a_rows_sparse256_kernel, dim3(nblk(a_idx.size())), dim3(Z_THREADS), 0, c->stream, (u32)p.r, (u32)p.w, ld, (const u64*)d_idx, (const E*)d_val,
+                       a_idx.size(), d_T);
+  }
+  LF_HIP(c, hipGetLastError());
+  LF_HIP(c, hipMemcpyAsync(d_T + (p.nwqrow + 0) * ld, pr.y_ldt.data(), p.block * 32, hipMemcpyHostToDevice, c->stream));
+  LF_HIP(c, hipMemcpyAsync(d_T + (p.nwqrow + 1) * ld, pr.y_dot.data(), p.dblock * 32, hipMemcpyHostToDevice, c->stream));
+  E* yq = d_T + (p.nwqrow + 2) * ld;  // y_quad = y_quad_0 | 0^w | y_quad_2
+  LF_HIP(c, hipMemcpyAsync(yq, pr.y_q0.data(), p.r * 32, hipMemcpyHostToDevice, c->stream));
+  LF_HIP(c, hipMemcpyAsync(yq + p.block, pr.y_q2.data(), (p.dblock - p.block) * 32, hipMemcpyHostToDevice, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));  // the staging area is the Reed-Solomon encoder's work space next
+  LF_TRY(lfgpu_fp256_rs_encode_rows(c, p.nwqrow + 1, p.block, p.block_enc, d_T, ld));                    // A rows and y_ldt
+  LF_TRY(lfgpu_fp256_rs_encode_rows(c, 2, p.dblock, p.block_enc, d_T + (p.nwqrow + 1) * ld, ld));         // y_dot, y_quad
+  {
+    void* di = nullptr;
+    LF_TRY(lf_scratch2(c, p.nreq * 8 + 64, &di));
+    std::vector<u64> ix(idx.begin(), idx.end());
+    LF_HIP(c, hipMemcpyAsync(di, ix.data(), p.nreq * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(gather_columns256_kernel, dim3(nblk(nrows_dev * p.nreq)), dim3(Z_THREADS), 0, c->stream, (u32)nrows_dev, ld, p.dblock, (const E*)d_T,
+                       (const u64*)di, (u32)p.nreq, d_req);
+    LF_HIP(c, hipGetLastError());
+    LF_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  std::vector<E> ext(nrows_dev * p.nreq);
+  LF_TRY(lfgpu_memcpy_d2h(c, ext.data(), d_req, ext.size() * 32));
+  auto ext_at = [&](size_t row, size_t j) -> const E& { return ext[row * p.nreq + j]; };
+  for (size_t j = 0; j < p.nreq; ++j) {  // low_degree_check
+    E yc = req_at(p.ildt, j);
+    for (size_t i = 0; i < p.nwqrow; ++i) yc = F.add(yc, F.mul(u_ldt[i], req_at(i + p.iw, j)));
+    if (!e32_eq(yc, ext_at(p.nwqrow, j))) return fail(3);
+  }
+  for (size_t j = 0; j < p.nreq; ++j) {  // dot_check
+    E yc = req_at(p.idot, j);
+    for (size_t i = 0; i < p.nwqrow; ++i) yc = F.add(yc, F.mul(ext_at(i, j), req_at(i + p.iw, j)));
+    if (!e32_eq(yc, ext_at(p.nwqrow + 1, j))) return fail(4);
+  }
+  {  // the putative value of the inner product
+    E want = F.zero, got = F.zero;
+    for (size_t k = 0; k < cs.n; ++k) want = F.add(want, F.mul(cs.b[k], alphal[k]));
+    for (size_t j = 0; j < p.w; ++j) got = F.add(got, pr.y_dot[p.r + j]);
+    if (!e32_eq(want, got)) return fail(5);
+  }
+  {  // quadratic_check
+    const size_t iqx = p.iq, iqy = iqx + p.nqtriples, iqz = iqy + p.nqtriples;
+    for (size_t j = 0; j < p.nreq; ++j) {
+      E yc = req_at(p.iquad, j);
+      for (size_t i = 0; i < p.nqtriples; ++i) {
+        const E tmp = F.sub(req_at(iqz + i, j), F.mul(req_at(iqx + i, j), req_at(iqy + i, j)));  // z - x y
+        yc = F.add(yc, F.mul(u_quad[i], tmp));
+      }
+      if (!e32_eq(yc, ext_at(p.nwqrow + 2, j))) return fail(6);
+    }
+  }
+  *ok = 1;
+  return fail(0);
 }

@@ -30,5 +30,9 @@ int zk256_prove(Zk256* z, const void* h_W, const lfgpu_transcript_ops* ts, int* 
 int zk256_proof_write(const Zk256* z, uint8_t* buf, size_t cap, size_t* nbytes);
 int zk256_timings(const Zk256* z, double ms[6]);
 void zk256_free(Zk256* z);
+int zk256_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc, const uint8_t* proof, size_t proof_len, const void* h_pub,
+                 const lfgpu_transcript_ops* ts, bool committed, int* ok, const char** why);
+// MerkleTreeVerifier::verify_compressed_proof (lib/merkle/merkle_tree.h:160-209), host (zk.hip)
+bool lf_merkle_verify(size_t n, const uint8_t root[32], const uint8_t* path, size_t npath, const uint8_t* leaves, const size_t* pos, size_t np);
 // K11 over 32-byte elements (quad.hip forwards field 1 here)
 int lf256_eval_quad_async(lfgpu_quad* q, const void* d_W, void* d_V, int* d_fail);

@@ -3,6 +3,7 @@
 // age_over_18 -- mdoc_zk_test.cc:652-685) twice over the same witness and the same deterministic RandomEngine:
 //   (a) with the reference's ZkProver<f_128, RSFactory> / ZkProver<Fp256Base, RSFactory_b>                (one CPU thread)
 //   (b) with lfgpu::GpuZkProver<f_128, ReadBuffer> / lfgpu::GpuZkProver<Fp256Base, ReadBuffer>            (liblfgpu.so)
+// and then the body of run_mdoc_verifier (:548-712) with lfgpu::GpuZkVerifier in the place of both ZkVerifiers.
 // Everything else -- circuit generation and parsing, CBOR/mdoc witness filling, the shared transcript, the MAC key drawn
 // from it between the commits and the proofs, update_macs, ZkProof::write of both proofs into the mdoc proof string -- is
 // the reference's code in both runs.  Prints the SHA-256 of the two proof strings (they must be equal), the reference
@@ -81,6 +82,39 @@ static bool prove_both(HashProver& hash_p, SigProver& sig_p, const Circuit<f_128
   return true;
 }
 
+// mdoc_zk.cc:632-712 (proof parsing, both recv_commitment, MAC key, public inputs, both verify) with the two verifiers as
+// parameters; returns 1 accept, 0 reject, < 0 parse / input failure
+template <class HashVerifier, class SigVerifier>
+static int verify_both(HashVerifier& hash_v, SigVerifier& sig_v, const Circuit<f_128>& c_hash, const Circuit<Fp256Base>& c_sig, const std::vector<uint8_t>& zbuf,
+                       const MdocTests* test, const RequestedAttribute* attrs, size_t attrs_len, const Elt& pkX, const Elt& pkY, const ZkSpecStruct* zk_spec,
+                       const f_128& Fs, double* ms) {
+  const size_t r = zk_spec->version < 7 ? kLigeroRate : kLigeroRatev7;
+  const size_t req = zk_spec->version < 7 ? kLigeroNreq : kLigeroNreqv7;
+  ZkProof<f_128> pr_hash(c_hash, r, req, zk_spec->block_enc_hash);
+  ZkProof<Fp256Base> pr_sig(c_sig, r, req, zk_spec->block_enc_sig);
+  ReadBuffer rb(zbuf);
+  gf2k macs[6];
+  for (size_t i = 0; i < 6; ++i) macs[i] = Fs.of_bytes_field(rb.next(f_128::kBytes)).value();
+  if (!pr_hash.read(rb, Fs) || !pr_sig.read(rb, p256_base) || rb.remaining() != 0) return -1;
+  const double t0 = now_ms();
+  class Transcript tv(test->transcript, test->transcript_size, zk_spec->version);
+  hash_v.recv_commitment(pr_hash, tv);
+  sig_v.recv_commitment(pr_sig, tv);
+  gf2k av = generate_mac_key(tv);
+  auto pub_hash = Dense<f_128>(1, c_hash.npub_in);
+  auto pub_sig = Dense<Fp256Base>(1, c_sig.npub_in);
+  DenseFiller<f_128> hash_filler(pub_hash);
+  DenseFiller<Fp256Base> sig_filler(pub_sig);
+  if (!fill_public_inputs(sig_filler, hash_filler, pkX, pkY, test->transcript, test->transcript_size, attrs, attrs_len, (const uint8_t*)test->now,
+                          (const uint8_t*)test->doc_type, strlen(test->doc_type), macs, av, Fs, zk_spec->version))
+    return -2;
+  if (hash_filler.size() != c_hash.npub_in || sig_filler.size() != c_sig.npub_in) return -3;
+  const bool ok = hash_v.verify(pr_hash, pub_hash, tv);
+  const bool ok2 = sig_v.verify(pr_sig, pub_sig, tv);
+  *ms = now_ms() - t0;
+  return ok && ok2 ? 1 : 0;
+}
+
 int mdoc_gpu(int reps, bool with_ref) {
   set_log_level(ERROR);
   const ZkSpecStruct* zk_spec = &kZkSpecs[0];
@@ -140,9 +174,10 @@ int mdoc_gpu(int reps, bool with_ref) {
     if (!prove_both(hash_p, sig_p, *c_hash, *c_sig, W_hash, W_sig, test, zk_spec, state, attrs_len, Fs, proof_ref, ms_ref)) return 8;
   }
 
-  // (b) the library's provers behind the same two calls
+  // (b) the library's provers behind the same two calls; then the library's verifiers behind ZkVerifier's calls
   std::vector<uint8_t> proof_gpu;
-  double ms_gpu[2] = {0, 0}, t_upload;
+  double ms_gpu[2] = {0, 0}, t_upload, ms_gpu_verify = 0, ms_ref_verify_body = 0;
+  int gpu_verdict = -9, gpu_verdict_bad = -9, ref_verdict = -9;
   {
     lfgpu::Context ctx(0);
     const double t0 = now_ms();
@@ -151,6 +186,27 @@ int mdoc_gpu(int reps, bool with_ref) {
     t_upload = now_ms() - t0;
     for (int rep = 0; rep < reps; ++rep)  // the last repetition is the one reported (tables, twiddles and bind structure cached)
       if (!prove_both(hash_p, sig_p, *c_hash, *c_sig, W_hash, W_sig, test, zk_spec, state, attrs_len, Fs, proof_gpu, ms_gpu)) return 9;
+    const size_t r = zk_spec->version < 7 ? kLigeroRate : kLigeroRatev7;
+    const size_t req = zk_spec->version < 7 ? kLigeroNreq : kLigeroNreqv7;
+    lfgpu::GpuZkVerifier<Fp256Base> sig_v(ctx, bytes.data(), sig_len, r, req, zk_spec->block_enc_sig, p256_base);
+    lfgpu::GpuZkVerifier<f_128> hash_v(ctx, bytes.data() + sig_len, hash_len, r, req, zk_spec->block_enc_hash, Fs);
+    for (int rep = 0; rep < reps; ++rep)
+      gpu_verdict = verify_both(hash_v, sig_v, *c_hash, *c_sig, proof_gpu, test, attrs, attrs_len, pkX, pkY, zk_spec, Fs, &ms_gpu_verify);
+    std::vector<uint8_t> bad = proof_gpu;  // one flipped bit in the signature proof's sumcheck section
+    bad[bad.size() - 150000] ^= 1;
+    double dummy;
+    gpu_verdict_bad = verify_both(hash_v, sig_v, *c_hash, *c_sig, bad, test, attrs, attrs_len, pkX, pkY, zk_spec, Fs, &dummy);
+  }
+  {  // the same verifier body with the reference's ZkVerifiers (timing beside it)
+    const Elt2 omega = p256_2.of_string(kRootX, kRootY);
+    const FftExtConvolutionFactory fft_b(p256_base, p256_2, omega, 1ull << 31);
+    const RSFactory_b rsf_b(fft_b, p256_base);
+    const RSFactory rsf(Fs);
+    const size_t r = zk_spec->version < 7 ? kLigeroRate : kLigeroRatev7;
+    const size_t req = zk_spec->version < 7 ? kLigeroNreq : kLigeroNreqv7;
+    ZkVerifier<f_128, RSFactory> hash_v(*c_hash, rsf, r, req, zk_spec->block_enc_hash, Fs);
+    ZkVerifier<Fp256Base, RSFactory_b> sig_v(*c_sig, rsf_b, r, req, zk_spec->block_enc_sig, p256_base);
+    ref_verdict = verify_both(hash_v, sig_v, *c_hash, *c_sig, proof_gpu, test, attrs, attrs_len, pkX, pkY, zk_spec, Fs, &ms_ref_verify_body);
   }
 
   // the reference's verifier on the library's proof string
@@ -163,12 +219,15 @@ int mdoc_gpu(int reps, bool with_ref) {
       "{\"proof_bytes\": %zu, \"gpu_sha256\": \"%s\", \"ref_sha256\": \"%s\", \"identical\": %s, \"reference_verifier_accepts_gpu_proof\": %s, "
       "\"gpu_ms\": {\"commit\": %.2f, \"prove\": %.2f, \"total\": %.2f}, \"ref_ms\": {\"commit\": %.2f, \"prove\": %.2f, \"total\": %.2f}, "
       "\"host_ms\": {\"generate_circuit\": %.1f, \"reference_parse\": %.1f, \"fill_witness\": %.1f, \"gpu_parse_upload\": %.1f, \"reference_verify\": %.1f}, "
+      "\"verify\": {\"gpu_verifiers_accept\": %s, \"gpu_verifiers_reject_flipped_bit\": %s, \"reference_verifiers_accept\": %s, \"gpu_ms\": %.2f, \"ref_ms\": %.2f}, "
       "\"circuit_bytes\": {\"sig\": %zu, \"hash\": %zu}}\n",
       proof_gpu.size(), sha_hex(proof_gpu).c_str(), with_ref ? sha_hex(proof_ref).c_str() : "", with_ref && proof_ref == proof_gpu ? "true" : "false",
       vr == MDOC_VERIFIER_SUCCESS ? "true" : "false", ms_gpu[0], ms_gpu[1], ms_gpu[0] + ms_gpu[1], ms_ref[0], ms_ref[1], ms_ref[0] + ms_ref[1], tg1 - tg0,
-      t_parse_ref, t_witness, t_upload, t_verify, sig_len, hash_len);
+      t_parse_ref, t_witness, t_upload, t_verify, gpu_verdict == 1 ? "true" : "false", gpu_verdict_bad == 0 ? "true" : "false",
+      ref_verdict == 1 ? "true" : "false", ms_gpu_verify, ms_ref_verify_body, sig_len, hash_len);
   free(bcp);
   if (with_ref && proof_ref != proof_gpu) return 10;
+  if (gpu_verdict != 1 || gpu_verdict_bad != 0 || ref_verdict != 1) return 12;
   return vr == MDOC_VERIFIER_SUCCESS ? 0 : 11;
 }
 }  // namespace proofs

@@ -75,7 +75,8 @@ def test_mdoc_end_to_end_with_gpu_provers_in_run_mdoc_prover():
     prove, ZkProof::write of both proofs) with lfgpu::GpuZkProver (include/lfgpu_zk_adapters.h) in the place of
     ZkProver<f_128, .> AND ZkProver<Fp256Base, .> -- every commit and prove on the device -- against the same body with the
     reference's own provers, same witness, same deterministic RandomEngine (oracle/ref_mdoc_gpu.cc).  The two mdoc proof
-    strings must be byte-identical and the reference's run_mdoc_verifier must accept the library's."""
+    strings must be byte-identical and the reference's run_mdoc_verifier must accept the library's; then the verifier's body
+    with lfgpu::GpuZkVerifier for both circuits must accept that proof and reject it with one bit flipped."""
     exe = os.path.join(ROOT, "oracle", "_ref", "mdoc_gpu")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/mdoc_gpu not built (needs the reference sources and zstd.h: make -C oracle ref in the build container)")
@@ -85,3 +86,6 @@ def test_mdoc_end_to_end_with_gpu_provers_in_run_mdoc_prover():
     print("mdoc end to end:", res)
     assert res["identical"] is True and res["gpu_sha256"] == res["ref_sha256"]
     assert res["reference_verifier_accepts_gpu_proof"] is True
+    # the body of run_mdoc_verifier (mdoc_zk.cc:548-712) with lfgpu::GpuZkVerifier in the place of both ZkVerifiers
+    v = res["verify"]
+    assert v["gpu_verifiers_accept"] is True and v["gpu_verifiers_reject_flipped_bit"] is True and v["reference_verifiers_accept"] is True

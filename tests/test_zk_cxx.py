@@ -490,8 +490,8 @@ def test_zk_mdoc_signature_circuit_matches_reference():
     481 833 terms, 900 public inputs, 32-byte elements; Ligero block_enc 4096, 19 rows) with the witness of the reference's
     own example, proved by the library's P-256 ZK driver (csrc/zk256.hip over csrc/p256.hip): commitment root and wire
     bytes identical to the reference's ZkProver<Fp256Base, ReedSolomonFactory<Fp256Base, FFTExtConvolutionFactory>> under
-    the same transcript and RandomEngine (oracle/ref_mdoc.cc -> oracle/gen_mdoc_fixture.py).  The reference verifier's
-    verdict on these bytes is implied by the identity; the library has no Fp256Base verifier yet and says so."""
+    the same transcript and RandomEngine (oracle/ref_mdoc.cc -> oracle/gen_mdoc_fixture.py); then the library's verifier for
+    this field on those bytes and on tampered copies."""
     import gpu_util as G
     import ligero_fixture as lf
     info = json.load(open(os.path.join(GOLD, "mdoc.json")))
@@ -525,9 +525,29 @@ def test_zk_mdoc_signature_circuit_matches_reference():
     zk.commit(Wbad, lf.LcgRng(100).bytes, ts)
     assert zk.prove(Wbad, ts) is False
     ts.close()
-    tv = G.pkg.FsTranscript(b"test")
-    with pytest.raises(G.pkg.LfGpuError):
-        G.pkg.zk_verify(gpu, circ, wire, W[:ci.npub_in], tv, rate, nreq, info["block_enc"])
-    tv.close()
+    # the library's verifier for this field (csrc/zk256.hip): accepts the proof -- which is the reference's, byte for byte --
+    # and rejects a flipped bit in every section and a wrong public input, with the reference's reasons
+    def verify(w, pub):
+        tv = G.pkg.FsTranscript(b"test")
+        try:
+            return G.pkg.zk_verify(gpu, circ, w, pub, tv, rate, nreq, info["block_enc"])
+        finally:
+            tv.close()
+    pub = W[:ci.npub_in]
+    assert verify(wire, pub) == (True, "ok")
+    p = zk.param
+    sc_bytes = sum(4 * circ.layer(i)["logw"] + 2 for i in range(ci.nl)) * 32
+    offs = {"root": 5, "sumcheck": 32 + sc_bytes // 2, "y_ldt": 32 + sc_bytes + 40, "y_dot": 32 + sc_bytes + 32 * p.block + 40,
+            "y_quad": 32 + sc_bytes + 32 * (p.block + p.dblock) + 8, "nonce": 32 + sc_bytes + 32 * (p.block + 2 * p.dblock - p.w) + 3,
+            "opened column": 32 + sc_bytes + 32 * (p.block + 2 * p.dblock - p.w) + 32 * p.nreq + 8 + 32 * 77, "merkle path": len(wire) - 9}
+    for name, off in offs.items():
+        bad = bytearray(wire)
+        bad[off] ^= 0x04
+        okv, why = verify(bytes(bad), pub)
+        assert okv is False, name
+    pub_bad = pub.copy()
+    pub_bad[3, 0] ^= np.uint64(1)
+    assert verify(wire, pub_bad)[0] is False
+    assert verify(wire[:-5], pub) == (False, "proof does not parse")
     zk.close()
     circ.close()
