@@ -1,7 +1,9 @@
 // adapters_compile_check.cc -- build-container-only check that include/lfgpu_adapters.h
 // satisfies the reference's template seams: the reference's own LigeroProver is instantiated
 // with lfgpu::GpuReedSolomonFactory as its InterpolatorFactory (the swap shown in
-// INTEGRATION.md).  Compiled with `g++ -c` against /root/reference/lib; never run.
+// INTEGRATION.md), and include/lfgpu_zk_adapters.h (GpuZkProver / GpuZkVerifier) is instantiated with the reference's
+// ZkProof, Dense, Transcript, RandomEngine and ReadBuffer for GF2_128 and Fp256Base.  Compiled with `g++ -c` against
+// /root/reference/lib; never run (the executed versions are oracle/ref_zk_adapters.cc and oracle/ref_mdoc_gpu.cc).
 #include "algebra/fp_p128.h"
 #include "gf2k/gf2_128.h"
 #include "ligero/ligero_param.h"
@@ -9,7 +11,14 @@
 #include "random/random.h"
 #include "random/transcript.h"
 
+#include "algebra/fp_p256.h"
+#include "arrays/dense.h"
+#include "sumcheck/circuit.h"
+#include "util/readbuffer.h"
+#include "zk/zk_proof.h"
+
 #include "lfgpu_adapters.h"
+#include "lfgpu_zk_adapters.h"
 
 namespace {
 using GF = proofs::GF2_128<>;
@@ -31,7 +40,31 @@ void commit_with_gpu_factory(const Field& F, const lfgpu::Context& ctx, const ty
 }
 }  // namespace
 
+// the prover-level drop-ins (include/lfgpu_zk_adapters.h) with the reference's ZkProof / Dense / Transcript / RandomEngine
+template <class Field>
+bool zk_with_gpu_prover_and_verifier(const Field& F, const lfgpu::Context& ctx, const proofs::Circuit<Field>& c, const uint8_t* lfc1, size_t len,
+                                     proofs::RandomEngine& rng) {
+  proofs::ZkProof<Field> zkp(c, 7, 132);
+  proofs::Dense<Field> W(1, c.ninputs);
+  proofs::Transcript tp((const uint8_t*)"test", 4), tv((const uint8_t*)"test", 4);
+  lfgpu::GpuZkProver<Field, proofs::ReadBuffer> prover(ctx, lfc1, len, F);
+  prover.commit(zkp, W, tp, rng);
+  if (!prover.prove(zkp, W, tp)) return false;
+  lfgpu::GpuZkVerifier<Field> verifier(ctx, lfc1, len, 7, 132, 0, F);
+  verifier.recv_commitment(zkp, tv);
+  return verifier.verify(zkp, W, tv);
+}
+
 void lfgpu_adapters_compile_check(const lfgpu::Context& ctx, proofs::RandomEngine& rng) {
+  {
+    static const proofs::Fp256<true> p256;  // Fp256Base
+    const proofs::Circuit<GF>* cg = nullptr;
+    const proofs::Circuit<proofs::Fp256<true>>* cp = nullptr;
+    if (cg) (void)zk_with_gpu_prover_and_verifier<GF>(GF(), ctx, *cg, nullptr, 0, rng);
+    if (cp) (void)zk_with_gpu_prover_and_verifier<proofs::Fp256<true>>(p256, ctx, *cp, nullptr, 0, rng);
+    lfgpu::GpuReedSolomonFactory<proofs::Fp256<true>> rs256(ctx);
+    (void)rs256.make(455, 4096);
+  }
   static const GF gf;
   static const FP fp;
   commit_with_gpu_factory<GF>(gf, ctx, nullptr, rng);
