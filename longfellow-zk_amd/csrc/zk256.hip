@@ -163,9 +163,13 @@ __device__ __forceinline__ E block_sum256(E v, E* sh) {
 // The two sums of a round (ProverLayers::evaluations :357-402), a0 = sum QW[2i] W[2i] and
 // a2 = sum (QW[2i+1] - QW[2i]) (W[2i+1] - W[2i]), straight from the scatter's limb accumulators: every accumulator is
 // reduced to its field element here and zeroed for the next round-hand; the block sums go, again as limbs, into 16 words
-// the host reads back and reduces (out[0..8) = a0, out[8..16) = a2; zeroed by the bind kernel that follows the read).
-__global__ __launch_bounds__(Z_THREADS) void partials256_kernel(size_t n, u64* __restrict__ acc, E rsq, const E* __restrict__ W, u64* __restrict__ out) {
+// (out[0..8) = a0, out[8..16) = a2) that the host reduces.
+// post != nullptr: the block that finishes last copies the 16 words to coherent pinned host memory (post[0..16)), clears
+// them and publishes `seq` at post[16] -- the host spins on that word instead of a copy + stream synchronisation.
+__global__ __launch_bounds__(Z_THREADS) void partials256_kernel(size_t n, u64* __restrict__ acc, E rsq, const E* __restrict__ W, u64* __restrict__ out,
+                                                                u32* __restrict__ done, volatile u64* __restrict__ post, u64 seq) {
   __shared__ E sh[Z_THREADS];
+  __shared__ u32 s_last;
   const size_t nodd = n / 2;
   E a0 = e32_zero(), a2 = e32_zero();
   for (size_t i = (size_t)blockIdx.x * Z_THREADS + threadIdx.x; i < nodd; i += (size_t)gridDim.x * Z_THREADS) {
@@ -183,6 +187,22 @@ __global__ __launch_bounds__(Z_THREADS) void partials256_kernel(size_t n, u64* _
   if (threadIdx.x == 0) {
     limbs_atomic_add(out, a0);
     limbs_atomic_add(out + 8, a2);
+    s_last = 0;
+    if (post) {
+      __threadfence();
+      s_last = atomicAdd(done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x < 64) {  // every block's adds are visible (each fenced before its increment); 16 lanes of one wave read,
+    if (threadIdx.x < 16) {          // clear and copy one word each (the round trips overlap), lane 0 then publishes
+      post[threadIdx.x] = __hip_atomic_exchange(&out[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+    }
+    if (threadIdx.x == 0) {
+      *done = 0;
+      __hip_atomic_store((u64*)&post[16], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -240,13 +260,11 @@ __global__ __launch_bounds__(1024) void scan256_kernel(u32 nblocks, u32* __restr
   if (threadIdx.x == 0) *total = carry;
 }
 // Dense::bind of the hand that just received its challenge (blocks [0, nbd)) and HQuad::bind_h (the blocks after them) in
-// one launch; block 0 also clears the words the host has just read the round's sums from
+// one launch
 __global__ __launch_bounds__(Z_THREADS) void bind256_kernel(u32 nbd, size_t n0, const E* __restrict__ win, E* __restrict__ wout, size_t n,
                                                             const uint2* __restrict__ hc, const E* __restrict__ vc, E r, int hand,
-                                                            const u32* __restrict__ block_off, uint2* __restrict__ hc_out, E* __restrict__ vc_out,
-                                                            u64* __restrict__ sums) {
+                                                            const u32* __restrict__ block_off, uint2* __restrict__ hc_out, E* __restrict__ vc_out) {
   __shared__ u32 wave_off[Z_THREADS / 64];
-  if (blockIdx.x == 0 && threadIdx.x < 16) sums[threadIdx.x] = 0;
   if (blockIdx.x < nbd) {
     dense_bind256((size_t)blockIdx.x * Z_THREADS + threadIdx.x, n0, r, win, wout);
     return;
@@ -436,7 +454,7 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   // scratch: eq | limb accumulators (bind_g runs, then the QW of every round-hand; self-cleaning) | hc[2] | vc[2] |
   // 4 half hand buffers | the round's two sums as limbs
   const size_t acc_n = std::max(nh0, nw);
-  const size_t bytes = q->nv * 32 + acc_n * 64 + 2 * nh0 * 8 + 2 * nh0 * 32 + 4 * half * 32 + 128 + 1024;
+  const size_t bytes = q->nv * 32 + acc_n * 64 + 2 * nh0 * 8 + 2 * nh0 * 32 + 4 * half * 32 + 256 + 1024;
   void* sc = nullptr;
   LF_TRY(lf_scratch(c, bytes, &sc));
   uint8_t* b = (uint8_t*)sc;
@@ -447,10 +465,12 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   E* vc[2] = {(E*)b, (E*)b + nh0};     b += 2 * nh0 * 32;
   E* wb[2][2] = {{(E*)b, (E*)b + half}, {(E*)b + 2 * half, (E*)b + 3 * half}};  b += 4 * half * 32;
   u64* d_sums = (u64*)b;
+  u32* d_done = (u32*)(d_sums + 16);
+  volatile u64* post = c->poll_h + 256;  // coherent pinned words a running kernel writes and the host polls (ctx.h)
   // Quad::bind_g
   LF_TRY(raw_eq2_256(c, F, logv, q->nv, G0, G1, alpha, d_eq));
   LF_HIP(c, hipMemsetAsync(acc, 0, acc_n * 64, c->stream));
-  LF_HIP(c, hipMemsetAsync(d_sums, 0, 128, c->stream));
+  LF_HIP(c, hipMemsetAsync(d_sums, 0, 192, c->stream));  // the 16 sum words + the block counter
   hipLaunchKernelGGL(bindg_emit256_kernel, dim3(nblk(nt, BG_THREADS)), dim3(BG_THREADS), 0, c->stream, nt, (const corner4*)q->d_morton, (const E*)q->d_kvec,
                      (const E*)d_eq, beta, (const u32*)q->d_runoff, hc[0], acc);
   hipLaunchKernelGGL(limb_normalize256_kernel, dim3(nblk(nh0)), dim3(Z_THREADS), 0, c->stream, nh0, acc, F.rsq, vc[0]);
@@ -462,17 +482,31 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   size_t nW[2] = {nw, nw};
   int wsel[2] = {0, 0};
   if (q->bind_shape.size() < 2 * logw) q->bind_shape.resize(2 * logw, lfgpu_quad::BindShape{nullptr, 0, 0});
-  u64* h_sums = (u64*)c->mailbox_h;
+  u64 h_sums[16];
   E* h_out = (E*)c->mailbox_h;
   for (size_t rnd = 0; rnd < logw; ++rnd)
     for (int hand = 0; hand < 2; ++hand) {
       // QW scatter (prover_layers.h:239-243) + evaluations: two launches, one read-back
       if (nh) hipLaunchKernelGGL(qw_scatter256_kernel, dim3(nblk(nh)), dim3(Z_THREADS), 0, c->stream, nh, (const uint2*)hc[cur], (const E*)vc[cur], hand,
                                  WH[1 - hand], acc);
-      hipLaunchKernelGGL(partials256_kernel, dim3(std::min<u32>(nblk(nW[hand] / 2), 256)), dim3(Z_THREADS), 0, c->stream, nW[hand], acc, F.rsq, WH[hand], d_sums);
+      const u64 seq = ++c->poll_seq;
+      hipLaunchKernelGGL(partials256_kernel, dim3(std::min<u32>(nblk(nW[hand] / 2), 256)), dim3(Z_THREADS), 0, c->stream, nW[hand], acc, F.rsq, WH[hand], d_sums,
+                         d_done, post, seq);
       LF_HIP(c, hipGetLastError());
-      LF_HIP(c, hipMemcpyAsync(h_sums, d_sums, 128, hipMemcpyDeviceToHost, c->stream));
-      LF_HIP(c, hipStreamSynchronize(c->stream));
+      {  // wait for the post (bounded: if the kernel is over without posting, something is wrong)
+        u64 spins = 0;
+        while (__atomic_load_n((const u64*)&post[16], __ATOMIC_ACQUIRE) != seq) {
+          if ((++spins & 0xfff) == 0) {
+            const hipError_t qe = hipStreamQuery(c->stream);
+            if (qe == hipSuccess) {
+              if (__atomic_load_n((const u64*)&post[16], __ATOMIC_ACQUIRE) == seq) break;
+              return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: kernel finished without posting");
+            }
+            if (qe != hipErrorNotReady) return lf_fail(c, LFGPU_ERR_HIP, "sumcheck_layer256: %s", hipGetErrorString(qe));
+          }
+        }
+        for (int k = 0; k < 16; ++k) h_sums[k] = post[k];
+      }
       // coef[0] = a0, coef[2] = a2, coef[1] from the running sum (prover_layers.h:390-396, logc = 0)
       E coef[3], ev[3], r;
       coef[0] = fp256_reduce_limbs(h_sums, F.rsq);
@@ -500,7 +534,7 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
       }
       E* dst = wb[hand][wsel[hand]];
       hipLaunchKernelGGL(bind256_kernel, dim3(nbd + nbh), dim3(Z_THREADS), 0, c->stream, nbd, nW[hand], WH[hand], dst, nh, (const uint2*)hc[cur],
-                         (const E*)vc[cur], r, hand, (const u32*)bs.d_off, hc[1 - cur], vc[1 - cur], d_sums);
+                         (const E*)vc[cur], r, hand, (const u32*)bs.d_off, hc[1 - cur], vc[1 - cur]);
       LF_HIP(c, hipGetLastError());
       WH[hand] = dst;
       wsel[hand] ^= 1;

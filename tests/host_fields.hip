@@ -101,3 +101,23 @@ extern "C" void hf_p256_reduce_limbs(const u64* acc, elt32_t* o) { *o = fp256_re
 extern "C" void hf_p256_of_scalar(u64 u, elt32_t* o) { *o = h256_of_scalar(u); }
 extern "C" void hf_p256_inv(const elt32_t* a, elt32_t* o) { *o = h256_inv(*a); }
 extern "C" int hf_p256_of_bytes(const uint8_t* b, elt32_t* o) { return h256_of_bytes(b, *o) ? 1 : 0; }
+// bulk sampling vs one attempt at a time over the same byte stream (FpGeneric::sample, fp_generic.h:360-371)
+struct HfStream {
+  const uint8_t* p;
+  size_t left, calls;
+};
+static void hf_take(HfStream& st, uint8_t* b, size_t n) {
+  if (n > st.left) n = st.left;  // the tests size the stream generously; running dry would show as a mismatch
+  memcpy(b, st.p, n);
+  st.p += n;
+  st.left -= n;
+  ++st.calls;
+}
+extern "C" size_t hf_p256_sample_both(const uint8_t* stream, size_t len, size_t n, elt32_t* bulk, elt32_t* single, size_t* used) {
+  HfStream a{stream, len, 0}, b{stream, len, 0};
+  h256_sample_many(bulk, n, [&](uint8_t* o, size_t k) { hf_take(a, o, k); });
+  for (size_t i = 0; i < n; ++i) single[i] = h256_sample([&](uint8_t* o, size_t k) { hf_take(b, o, k); });
+  used[0] = len - a.left;
+  used[1] = len - b.left;
+  return a.calls;
+}

@@ -205,3 +205,29 @@ def test_p256_limb_accumulators_and_host_helpers():
         assert L.hf_p256_of_bytes(b.ctypes.data_as(C.c_void_p), P(out)) == fits
         if fits:
             assert to_int(out) == v * R % p
+
+
+def test_p256_bulk_sampling_is_the_reference_stream():
+    """h256_sample_many (one RandomEngine call for many elements; csrc/zk256.hip draws its pads and blinding rows with it)
+    returns the same elements and consumes the same bytes as one 32-byte attempt at a time, INCLUDING rejected attempts
+    (values >= p: probability 2^-32 per draw in practice, forced here)."""
+    import ctypes as C
+    L = _lib()
+    L.hf_p256_sample_both.restype = C.c_size_t
+    p = ol.P256_P
+    rng = np.random.default_rng(11)
+    chunks = [rng.bytes(32) for _ in range(40)]
+    for pos in (0, 3, 4, 17, 18, 19):  # rejected attempts: all ones, p itself, p + 5 -- also two in a row and at the start
+        chunks[pos] = [(2**256 - 1).to_bytes(32, "little"), p.to_bytes(32, "little"), (p + 5).to_bytes(32, "little")][pos % 3]
+    stream = np.frombuffer(b"".join(chunks), dtype=np.uint8).copy()
+    for n in (1, 2, 5, 16, 30):
+        bulk, single = np.zeros((n, 4), dtype=np.uint64), np.zeros((n, 4), dtype=np.uint64)
+        used = (C.c_size_t * 2)()
+        calls = L.hf_p256_sample_both(stream.ctypes.data_as(C.c_void_p), C.c_size_t(stream.size), C.c_size_t(n), P(bulk), P(single), used)
+        assert (bulk == single).all(), n
+        assert used[0] == used[1], (n, list(used))
+        assert calls < n + 6  # a handful of calls, not one per element
+        ok = [c for c in chunks if int.from_bytes(c, "little") < p][:n]
+        want = [int.from_bytes(c, "little") * (1 << 256) % p for c in ok]
+        got = [sum(int(bulk[i, k]) << (64 * k) for k in range(4)) for i in range(n)]
+        assert got == want
