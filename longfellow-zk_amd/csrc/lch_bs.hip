@@ -34,9 +34,10 @@
 // writes of the four dwords of a column land on distinct banks.
 #define BS_PL(p, lc) ((p) * BS_COLS + ((lc) ^ ((((u32)(p)) >> 5) << 3)))
 
+// n = columns per combo of the unit buffer `dst` (its stride); valid = columns of `src` that hold data (the rest reads as 0)
 template <int K, int WPC>
 __global__ __launch_bounds__(256, WPC) void bs_cin_kernel(const elt_t* __restrict__ src, size_t ld, u32 rows, u32 n,
-                                                          u32* __restrict__ dst) {
+                                                          u32* __restrict__ dst, u32 valid) {
   constexpr int M = Tower<K>::M, D = Tower<K>::D;
   extern __shared__ u32 lds[];  // 32 rows x BS_COLS x 4 words, then 128 planes x BS_COLS words
   const u32 t = threadIdx.x, rg = blockIdx.y, c0 = blockIdx.x * BS_COLS;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256, WPC) void bs_cin_kernel(const elt_t* __restric
     for (int i = 0; i < 8; ++i) {
       const u32 row = rg * 32 + rq * 8 + i;
       v[i] = make_uint4(0, 0, 0, 0);
-      if (row < rows) v[i] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c0 + lc);
+      if (row < rows && c0 + lc < valid) v[i] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c0 + lc);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(&lds[((rq * 8 + i) * BS_COLS + lc) * 4]) = v[i];
@@ -134,9 +135,10 @@ __global__ __launch_bounds__(256, WPC) void bs_cin_kernel(const elt_t* __restric
   }
 }
 
+// n = columns per combo of the unit buffer `src`; only the columns [out_lo, out_hi) of the tile range are written to dst
 template <int K, int WPC>
 __global__ __launch_bounds__(256, WPC) void bs_cout_kernel(const u32* __restrict__ src, size_t ld, u32 rows, u32 n,
-                                                         elt_t* __restrict__ dst) {
+                                                         elt_t* __restrict__ dst, u32 out_lo, u32 out_hi) {
   constexpr int M = Tower<K>::M, D = Tower<K>::D;
   extern __shared__ u32 lds[];
   const u32 t = threadIdx.x, rg = blockIdx.y, c0 = blockIdx.x * BS_COLS;
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(256, WPC) void bs_cout_kernel(const u32* __restrict
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const u32 r = rq * 8 + i, row = rg * 32 + r;
-      if (row < rows) *reinterpret_cast<uint4*>(dst + (size_t)row * ld + c0 + lc) = *reinterpret_cast<const uint4*>(&lds[(r * BS_COLS + lc) * 4]);
+      if (row < rows && c0 + lc >= out_lo && c0 + lc < out_hi)
+        *reinterpret_cast<uint4*>(dst + (size_t)row * ld + c0 + lc) = *reinterpret_cast<const uint4*>(&lds[(r * BS_COLS + lc) * 4]);
     }
   }
 }
@@ -231,6 +234,7 @@ struct BflyArgs {
   const u32* tw;      // stage tables, coset folded in: tw[off[b] + u_glob]
   u32 off[BS_NB_MAX];
   u32 n;              // columns per combo (2^l)
+  u32 stride;         // columns per combo in the unit buffer (== n for a whole transform; larger when `data` points at a sub-block)
   u32 lo_bit, nb;     // this pass covers index bits [lo_bit, lo_bit + nb)
   u32 r_log;          // log2(lanes per column pair) = log2(combos per tile) + cu
   u32 cu;             // low column bits kept inside the tile (2^cu consecutive columns: 2^cu * 4m-byte segments)
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void bs_bfly_kernel(BflyArgs a) {
       const u32 j = s >> RL, cl = s & (R - 1);
       v[it] = make_uint4(0, 0, 0, 0);
       if (e < total)
-        v[it] = *reinterpret_cast<const uint4*>(a.data + ((size_t)(cb0 + (cl >> CU)) * a.n + cbase + ((size_t)j << a.lo_bit) + (cl & cumask)) * M + 4 * p4);
+        v[it] = *reinterpret_cast<const uint4*>(a.data + ((size_t)(cb0 + (cl >> CU)) * a.stride + cbase + ((size_t)j << a.lo_bit) + (cl & cumask)) * M + 4 * p4);
     }
 #pragma unroll
     for (u32 it = 0; it < MAXIT; ++it) {
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void bs_bfly_kernel(BflyArgs a) {
     v.y = lds[(4 * p4 + 1) * PS + s];
     v.z = lds[(4 * p4 + 2) * PS + s];
     v.w = lds[(4 * p4 + 3) * PS + s];
-    *reinterpret_cast<uint4*>(a.data + ((size_t)(cb0 + (cl >> CU)) * a.n + cbase + ((size_t)j << a.lo_bit) + (cl & cumask)) * M + 4 * p4) = v;
+    *reinterpret_cast<uint4*>(a.data + ((size_t)(cb0 + (cl >> CU)) * a.stride + cbase + ((size_t)j << a.lo_bit) + (cl & cumask)) * M + 4 * p4) = v;
   }
 }
 
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(64 * NW, 4) void bs_bfly2_kernel(BflyArgs a) {
   constexpr u32 PIECES = M / 4, UPI = 64 / PIECES, NIT = 64 / UPI, XS = 66;
   u32* const stage = xch + (size_t)w * M * XS;
   const u32 piece = lane % PIECES, sub = lane / PIECES;
-  auto slot_base = [&](u32 slot) { return a.data + ((size_t)(cb0 + (slot >> CU)) * a.n + cbase + (slot & cumask)) * M; };
+  auto slot_base = [&](u32 slot) { return a.data + ((size_t)(cb0 + (slot >> CU)) * a.stride + cbase + (slot & cumask)) * M; };
   auto unit_in = [&](u32 j, u32 (&dst)[M]) {
     uint4 v[NIT];
     if (active) {
@@ -519,104 +523,146 @@ static int bs_tables(lfgpu_ctx* c, const GfHostCtx* g, unsigned l, u64 coset, co
   return LFGPU_OK;
 }
 
-template <int K>
-static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows, unsigned l, u64 coset, void* d_B, size_t ld) {
-  constexpr int M = Tower<K>::M, D = Tower<K>::D;
-  if (!(c->attr_done & 4u)) {
-    if (const char* e = getenv("LFGPU_BS_RLOG")) {
-      int v = atoi(e);
-      if (v >= 5 && v <= 7) c->bs_rlog = (u32)v;
-    }
+// shared launch configuration of the bit-sliced kernels (once per context)
+static int bs_setup(lfgpu_ctx* c) {
+  if (c->attr_done & 4u) return LFGPU_OK;
+  if (const char* e = getenv("LFGPU_BS_RLOG")) {
+    int v = atoi(e);
+    if (v >= 5 && v <= 7) c->bs_rlog = (u32)v;
   }
-  const u32 g_bs_rlog = c->bs_rlog;
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+  c->attr_done |= 4u;
+  return LFGPU_OK;
+}
+
+// geometry of the unit buffer for `rows` batch rows: row groups, and combos padded to whole butterfly tiles
+template <int K>
+struct BsGeom {
+  bool v2;
+  u32 R, nbmax, nrg, combos, rlog;
+};
+template <int K>
+static BsGeom<K> bs_geom(lfgpu_ctx* c, size_t rows) {
+  constexpr int D = Tower<K>::D;
   static const int v2_env = getenv("LFGPU_BS_V2") ? atoi(getenv("LFGPU_BS_V2")) : 1;
-  const bool v2 = v2_env && (u32)((rows + 31) / 32) * D >= 64;  // register-resident butterflies: lanes = 64 (combo, inner column) slots
   // 4 index bits per pass (two 512-thread workgroups per CU overlap their HBM and XOR phases): 61.0 ms per 2^20 x 1024 batch;
   // 5 bits (LFGPU_BS_V2_NB=5: one 1024-thread workgroup per CU, 4 passes instead of 5) measured 64.1 ms
   static const u32 v2_nb = getenv("LFGPU_BS_V2_NB") && atoi(getenv("LFGPU_BS_V2_NB")) == 5 ? 5u : 4u;
-  const u32 R = v2 ? 64u : 1u << g_bs_rlog, nbmax = v2 ? v2_nb : 9 - g_bs_rlog;
+  BsGeom<K> gm;
+  gm.nrg = (u32)((rows + 31) / 32);
+  gm.v2 = v2_env && gm.nrg * D >= 64;  // register-resident butterflies: lanes = 64 (combo, inner column) slots
+  gm.rlog = gm.v2 ? 6u : c->bs_rlog;
+  gm.R = 1u << gm.rlog;
+  gm.nbmax = gm.v2 ? v2_nb : 9 - c->bs_rlog;
+  gm.combos = ((gm.nrg * D + gm.R - 1) / gm.R) * gm.R;
+  return gm;
+}
+
+// the butterfly passes of one transform of 2^l columns on the unit buffer `units` (pointing at the transform's first
+// column; `stride` columns per combo): bit groups of <= nbmax index bits; FFT walks stages l-1..0, IFFT 0..l-1
+template <int K>
+static int bs_passes(lfgpu_ctx* c, const GfHostCtx* g, const BsGeom<K>& gm, int inverse, unsigned l, u64 coset, u32* units, u32 stride) {
+  constexpr int M = Tower<K>::M;
   static const u32 cu_env = [] {
     const char* e = getenv("LFGPU_BS_CU");
     return e && (u32)atoi(e) <= 5 ? (u32)atoi(e) : 3u;
   }();
   const u32 n = 1u << l;
-  const u32 nrg = (u32)((rows + 31) / 32);
-  const u32 combos = ((nrg * D + R - 1) / R) * R;  // padded to whole butterfly tiles
-  void* internal = nullptr;
-  LF_TRY(lf_scratch(c, (size_t)combos * n * M * 4, &internal));
   const u32* d_tw = nullptr;
   std::vector<u32> offs;
   LF_TRY(bs_tables<K>(c, g, l, coset, &d_tw, &offs));
-  if (!(c->attr_done & 4u)) {
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly_kernel<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-    c->attr_done |= 4u;
-  }
-  if (combos > nrg * D)  // padded combos: define the bits (values are never read back)
-    LF_HIP(c, hipMemsetAsync((u32*)internal + (size_t)nrg * D * n * M, 0, (size_t)(combos - nrg * D) * n * M * 4, c->stream));
-  // GF2_128<5>: 8-output basis-change programs at 4 waves per SIMD (12.6 -> 10.4 ms per 2^30 elements); <4>: 16-plane programs, 2
-  static const int cin_wpc = getenv("LFGPU_BS_CIN_WPC") ? atoi(getenv("LFGPU_BS_CIN_WPC")) : (K == 5 ? 4 : 2);
-  if (cin_wpc == 3)
-    hipLaunchKernelGGL((bs_cin_kernel<K, 3>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
-                       (u32*)internal);
-  else if (cin_wpc == 4)
-    hipLaunchKernelGGL((bs_cin_kernel<K, 4>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
-                       (u32*)internal);
-  else
-    hipLaunchKernelGGL((bs_cin_kernel<K, 2>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const elt_t*)d_B, ld, (u32)rows, n,
-                       (u32*)internal);
-  // bit groups of <= BS_NB_MAX index bits; FFT walks stages l-1..0, IFFT 0..l-1
   std::vector<std::pair<u32, u32>> groups;  // (lo_bit, nb), ascending
-  for (u32 lo = 0; lo < l; lo += nbmax) groups.push_back({lo, std::min<u32>(nbmax, l - lo)});
+  for (u32 lo = 0; lo < l; lo += gm.nbmax) groups.push_back({lo, std::min<u32>(gm.nbmax, l - lo)});
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const auto& gr = inverse ? groups[gi] : groups[groups.size() - 1 - gi];
     BflyArgs a{};
-    a.data = (u32*)internal;
+    a.data = units;
     a.tw = d_tw;
     for (u32 b = 0; b < gr.second; ++b) a.off[b] = offs[gr.first + b];
     a.n = n;
+    a.stride = stride;
     a.lo_bit = gr.first;
     a.nb = gr.second;
-    a.r_log = v2 ? 6u : g_bs_rlog;
+    a.r_log = gm.rlog;
     a.cu = std::min(std::min(cu_env, gr.first), a.r_log);  // inner bits must lie below the stage bits
     a.inverse = inverse;
     static const u32 probe_env = getenv("LFGPU_BS_PROBE") ? (u32)atoi(getenv("LFGPU_BS_PROBE")) : 0u;
     a.probe = probe_env;
-    const u32 units = R << gr.second;
-    const dim3 grid(n >> (gr.second + a.cu), combos >> (a.r_log - a.cu));
-    if (v2 && gr.second == 5) {  // 16 waves x M planes x (64 + 2) words of exchange / staging buffer
+    const u32 units_per_tile = gm.R << gr.second;
+    const dim3 grid(n >> (gr.second + a.cu), gm.combos >> (a.r_log - a.cu));
+    if (gm.v2 && gr.second == 5) {  // 16 waves x M planes x (64 + 2) words of exchange / staging buffer
       if (inverse)
         hipLaunchKernelGGL((bs_bfly2_kernel<K, true, 16>), grid, dim3(1024), (size_t)16 * M * 66 * 4, c->stream, a);
       else
         hipLaunchKernelGGL((bs_bfly2_kernel<K, false, 16>), grid, dim3(1024), (size_t)16 * M * 66 * 4, c->stream, a);
-    } else if (v2) {
+    } else if (gm.v2) {
       if (inverse)
         hipLaunchKernelGGL((bs_bfly2_kernel<K, true, 8>), grid, dim3(512), (size_t)8 * M * 66 * 4, c->stream, a);
       else
         hipLaunchKernelGGL((bs_bfly2_kernel<K, false, 8>), grid, dim3(512), (size_t)8 * M * 66 * 4, c->stream, a);
     } else if (inverse)
-      hipLaunchKernelGGL((bs_bfly_kernel<K, true>), grid, dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
+      hipLaunchKernelGGL((bs_bfly_kernel<K, true>), grid, dim3(256), (size_t)M * BS_PS(units_per_tile) * 4, c->stream, a);
     else
-      hipLaunchKernelGGL((bs_bfly_kernel<K, false>), grid, dim3(256), (size_t)M * BS_PS(units) * 4, c->stream, a);
+      hipLaunchKernelGGL((bs_bfly_kernel<K, false>), grid, dim3(256), (size_t)M * BS_PS(units_per_tile) * 4, c->stream, a);
   }
-  static const int cout_wpc = getenv("LFGPU_BS_COUT_WPC") ? atoi(getenv("LFGPU_BS_COUT_WPC")) : (K == 5 ? 4 : 2);
-  if (cout_wpc == 4)
-    hipLaunchKernelGGL((bs_cout_kernel<K, 4>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const u32*)internal, ld, (u32)rows, n, (elt_t*)d_B);
-  else if (cout_wpc == 3)
-    hipLaunchKernelGGL((bs_cout_kernel<K, 3>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const u32*)internal, ld, (u32)rows, n, (elt_t*)d_B);
-  else
-    hipLaunchKernelGGL((bs_cout_kernel<K, 2>), dim3(n / BS_COLS, nrg), dim3(256), 32768, c->stream, (const u32*)internal, ld, (u32)rows, n, (elt_t*)d_B);
   LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
+// rows (reference layout; columns >= valid read as 0) -> units, `ncols` columns (a multiple of 64) from the buffer's first column
+template <int K>
+static int bs_convert_in(lfgpu_ctx* c, const BsGeom<K>& gm, size_t rows, u32 ncols, u32 valid, const elt_t* src, size_t ld, u32* units, u32 stride) {
+  // GF2_128<5>: 8-output basis-change programs at 4 waves per SIMD (12.6 -> 10.4 ms per 2^30 elements); <4>: 16-plane programs, 2
+  static const int cin_wpc = getenv("LFGPU_BS_CIN_WPC") ? atoi(getenv("LFGPU_BS_CIN_WPC")) : (K == 5 ? 4 : 2);
+  const dim3 grid(ncols / BS_COLS, gm.nrg);
+  if (cin_wpc == 3)
+    hipLaunchKernelGGL((bs_cin_kernel<K, 3>), grid, dim3(256), 32768, c->stream, src, ld, (u32)rows, stride, units, valid);
+  else if (cin_wpc == 4)
+    hipLaunchKernelGGL((bs_cin_kernel<K, 4>), grid, dim3(256), 32768, c->stream, src, ld, (u32)rows, stride, units, valid);
+  else
+    hipLaunchKernelGGL((bs_cin_kernel<K, 2>), grid, dim3(256), 32768, c->stream, src, ld, (u32)rows, stride, units, valid);
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+// units -> rows: the columns [out_lo, out_hi) of the buffer's first `ncols` columns
+template <int K>
+static int bs_convert_out(lfgpu_ctx* c, const BsGeom<K>& gm, size_t rows, u32 ncols, const u32* units, u32 stride, elt_t* dst, size_t ld, u32 out_lo, u32 out_hi) {
+  static const int cout_wpc = getenv("LFGPU_BS_COUT_WPC") ? atoi(getenv("LFGPU_BS_COUT_WPC")) : (K == 5 ? 4 : 2);
+  const dim3 grid(ncols / BS_COLS, gm.nrg);
+  if (cout_wpc == 4)
+    hipLaunchKernelGGL((bs_cout_kernel<K, 4>), grid, dim3(256), 32768, c->stream, units, ld, (u32)rows, stride, dst, out_lo, out_hi);
+  else if (cout_wpc == 3)
+    hipLaunchKernelGGL((bs_cout_kernel<K, 3>), grid, dim3(256), 32768, c->stream, units, ld, (u32)rows, stride, dst, out_lo, out_hi);
+  else
+    hipLaunchKernelGGL((bs_cout_kernel<K, 2>), grid, dim3(256), 32768, c->stream, units, ld, (u32)rows, stride, dst, out_lo, out_hi);
+  LF_HIP(c, hipGetLastError());
+  return LFGPU_OK;
+}
+
+template <int K>
+static int lch_bs_run(lfgpu_ctx* c, const GfHostCtx* g, int inverse, size_t rows, unsigned l, u64 coset, void* d_B, size_t ld) {
+  constexpr int M = Tower<K>::M, D = Tower<K>::D;
+  LF_TRY(bs_setup(c));
+  const BsGeom<K> gm = bs_geom<K>(c, rows);
+  const u32 n = 1u << l;
+  void* internal = nullptr;
+  LF_TRY(lf_scratch(c, (size_t)gm.combos * n * M * 4, &internal));
+  if (gm.combos > gm.nrg * D)  // padded combos: define the bits (values are never read back)
+    LF_HIP(c, hipMemsetAsync((u32*)internal + (size_t)gm.nrg * D * n * M, 0, (size_t)(gm.combos - gm.nrg * D) * n * M * 4, c->stream));
+  LF_TRY(bs_convert_in<K>(c, gm, rows, n, n, (const elt_t*)d_B, ld, (u32*)internal, n));
+  LF_TRY(bs_passes<K>(c, g, gm, inverse, l, coset, (u32*)internal, n));
+  LF_TRY(bs_convert_out<K>(c, gm, rows, n, (const u32*)internal, n, (elt_t*)d_B, ld, 0u, n));
   return LFGPU_OK;
 }
 
@@ -625,4 +671,101 @@ int lf_lch14_fft_bitsliced(lfgpu_ctx* c, int k, int inverse, size_t rows, unsign
   const GfHostCtx* g = lf_gf_ctx(c, k);
   if (!g) return LFGPU_ERR_ARG;
   return k == 4 ? lch_bs_run<4>(c, g, inverse, rows, l, coset, d_B, ld) : lch_bs_run<5>(c, g, inverse, rows, l, coset, d_B, ld);
+}
+
+// ------------------------------------------------------------------ tower-domain building blocks for rs.hip
+// The Reed-Solomon encoder of rows larger than LDS runs a truncated transform (whole FFT / IFFT blocks of shrinking size
+// and partial butterfly ranges between them) and then one FFT per further coset -- about a dozen transforms on the same
+// coefficients.  Converted once, they stay in the bit-sliced tower representation throughout: one bs_cin, butterfly passes
+// and range kernels on sub-blocks of the unit buffer, one bs_cout per coset of evaluations.
+template <int K>
+__global__ __launch_bounds__(256) void bs_range_kernel(u32 kind, u32 s, u32 lo, u32 cnt, u32 t, u32 stride, u32 ncombo, u32* __restrict__ U) {
+  // butterflies (uv, uv + s), uv in [lo, lo + cnt), of every combo; t = tower bits of the level's one twiddle
+  // kind 0: b0 ^= t b1; b1 ^= b0 (lch14.h:219-223)   1: b1 ^= b0; b0 ^= t b1 (:225-229)   2: x = b1; b1 ^= b0; b0 ^= t x (:231-237)
+  constexpr int M = Tower<K>::M;
+  constexpr u32 MU = Tower<K>::MU_LOW;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)cnt * ncombo) return;
+  const u32 uv = lo + (u32)(idx % cnt), combo = (u32)(idx / cnt);
+  uint4* p0 = reinterpret_cast<uint4*>(U + ((size_t)combo * stride + uv) * M);
+  uint4* p1 = reinterpret_cast<uint4*>(U + ((size_t)combo * stride + uv + s) * M);
+  u32 b0[M], b1[M], acc[M];
+#pragma unroll
+  for (int j = 0; j < M / 4; ++j) {
+    const uint4 x = p0[j], y = p1[j];
+    b0[4 * j] = x.x; b0[4 * j + 1] = x.y; b0[4 * j + 2] = x.z; b0[4 * j + 3] = x.w;
+    b1[4 * j] = y.x; b1[4 * j + 1] = y.y; b1[4 * j + 2] = y.z; b1[4 * j + 3] = y.w;
+  }
+  const u32 tt = __builtin_amdgcn_readfirstlane(t);
+  if (kind == 1) {
+#pragma unroll
+    for (int p = 0; p < M; ++p) b1[p] ^= b0[p];
+  }
+  bs_mul_horner<M, MU>(tt, b1, acc);
+  if (kind == 2) {
+#pragma unroll
+    for (int p = 0; p < M; ++p) b1[p] ^= b0[p];
+  }
+#pragma unroll
+  for (int p = 0; p < M; ++p) b0[p] ^= acc[p];
+  if (kind == 0) {
+#pragma unroll
+    for (int p = 0; p < M; ++p) b1[p] ^= b0[p];
+  }
+#pragma unroll
+  for (int j = 0; j < M / 4; ++j) {
+    p0[j] = make_uint4(b0[4 * j], b0[4 * j + 1], b0[4 * j + 2], b0[4 * j + 3]);
+    p1[j] = make_uint4(b1[4 * j], b1[4 * j + 1], b1[4 * j + 2], b1[4 * j + 3]);
+  }
+}
+// dst = src for the columns below zero_from, 0 from there on (16-byte pieces; the coefficient vector of a further coset)
+__global__ __launch_bounds__(256) void bs_copy_units_kernel(size_t pieces_per_combo, size_t keep_pieces, size_t total, const uint4* __restrict__ src,
+                                                            uint4* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  dst[i] = (i % pieces_per_combo) < keep_pieces ? src[i] : make_uint4(0, 0, 0, 0);
+}
+
+template <int K>
+static int bs_tower_ops(lfgpu_ctx* c, const GfHostCtx* g, int op, size_t rows, u32 a0, u32 a1, u32 a2, u32 a3, u64 coset, elt_t tw, void* U, u32 stride,
+                        const void* src, void* dst, size_t ld) {
+  constexpr int M = Tower<K>::M, D = Tower<K>::D;
+  LF_TRY(bs_setup(c));
+  const BsGeom<K> gm = bs_geom<K>(c, rows);
+  u32* units = (u32*)U;
+  switch (op) {
+    case 0:  // cin: a0 = ncols, a1 = valid
+      if (gm.combos > gm.nrg * D)
+        LF_HIP(c, hipMemsetAsync(units + (size_t)gm.nrg * D * stride * M, 0, (size_t)(gm.combos - gm.nrg * D) * stride * M * 4, c->stream));
+      return bs_convert_in<K>(c, gm, rows, a0, a1, (const elt_t*)src, ld, units, stride);
+    case 1:  // cout: a0 = ncols, a1 = out_lo, a2 = out_hi
+      return bs_convert_out<K>(c, gm, rows, a0, units, stride, (elt_t*)dst, ld, a1, a2);
+    case 2:  // FFT / IFFT passes: a0 = l, a1 = inverse, a2 = first column
+      return bs_passes<K>(c, g, gm, (int)a1, a0, coset, units + (size_t)a2 * M, stride);
+    case 3: {  // range: a0 = kind, a1 = s, a2 = first column of the lower half + lo, a3 = count
+      if (a3 == 0) return LFGPU_OK;
+      const u32 t = tower_twiddle_bits<K>(tw.lo, tw.hi);
+      const size_t total = (size_t)a3 * gm.nrg * D;
+      hipLaunchKernelGGL(bs_range_kernel<K>, dim3((u32)((total + 255) / 256)), dim3(256), 0, c->stream, a0, a1, a2, a3, t, stride, gm.nrg * D, units);
+      LF_HIP(c, hipGetLastError());
+      return LFGPU_OK;
+    }
+    default: {  // copy with zero tail: a0 = zero_from; dst = the other unit buffer
+      const size_t ppc = (size_t)stride * M / 4, total = ppc * gm.combos;
+      hipLaunchKernelGGL(bs_copy_units_kernel, dim3((u32)((total + 255) / 256)), dim3(256), 0, c->stream, ppc, (size_t)a0 * M / 4, total, (const uint4*)U, (uint4*)dst);
+      LF_HIP(c, hipGetLastError());
+      return LFGPU_OK;
+    }
+  }
+}
+// bytes of a unit buffer for `rows` batch rows x `stride` columns
+size_t lf_bs_units_bytes(lfgpu_ctx* c, int k, size_t rows, u32 stride) {
+  return k == 4 ? (size_t)bs_geom<4>(c, rows).combos * stride * Tower<4>::M * 4 : (size_t)bs_geom<5>(c, rows).combos * stride * Tower<5>::M * 4;
+}
+int lf_bs_tower_op(lfgpu_ctx* c, int k, int op, size_t rows, u32 a0, u32 a1, u32 a2, u32 a3, u64 coset, elt_t tw, void* U, u32 stride, const void* src,
+                   void* dst, size_t ld) {
+  const GfHostCtx* g = lf_gf_ctx(c, k);
+  if (!g) return LFGPU_ERR_ARG;
+  return k == 4 ? bs_tower_ops<4>(c, g, op, rows, a0, a1, a2, a3, coset, tw, U, stride, src, dst, ld)
+                : bs_tower_ops<5>(c, g, op, rows, a0, a1, a2, a3, coset, tw, U, stride, src, dst, ld);
 }

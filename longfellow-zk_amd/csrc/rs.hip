@@ -270,6 +270,43 @@ static void big_bidir(const GfHostCtx* g, std::vector<BigOp>& ops, unsigned i, u
   }
 }
 
+// lch_bs.hip: the bit-sliced tower representation as a work format (unit buffers of combos x stride columns)
+size_t lf_bs_units_bytes(lfgpu_ctx* c, int k, size_t rows, u32 stride);
+int lf_bs_tower_op(lfgpu_ctx* c, int k, int op, size_t rows, u32 a0, u32 a1, u32 a2, u32 a3, u64 coset, elt_t tw, void* U, u32 stride, const void* src,
+                   void* dst, size_t ld);
+enum { BS_OP_CIN = 0, BS_OP_COUT = 1, BS_OP_FFT = 2, BS_OP_RANGE = 3, BS_OP_COPY = 4 };
+
+// >= 32 rows: the whole encoder in the tower representation -- ONE conversion in, every FFT / IFFT block of the truncated
+// transform as butterfly passes on a sub-block of the unit buffer, the partial ranges as bit-sliced elementwise launches (a
+// product by the level's one twiddle is ~20 XORs per element there, ~510 VALU operations in gf_mul), one conversion out per
+// coset of evaluations.  Round 2 before this: every block and coset converted in and out on its own (S-lig 70.4 ms).
+static int gf_rs_rows_big_tower(lfgpu_ctx* c, int k, size_t nrow, size_t n, size_t m, elt_t* T, size_t ld, unsigned l, const std::vector<BigOp>& ops) {
+  const u32 fftn = 1u << l;
+  const size_t ub = lf_bs_units_bytes(c, k, nrow, fftn);
+  void *U = nullptr, *U2 = nullptr;
+  LF_TRY(lf_scratch2(c, ub, &U));
+  const elt_t z{0, 0};
+  LF_TRY(lf_bs_tower_op(c, k, BS_OP_CIN, nrow, fftn, (u32)n, 0, 0, 0, z, U, fftn, T, nullptr, ld));
+  for (const BigOp& op : ops) {
+    if (op.kind == BIG_FFT || op.kind == BIG_IFFT) {
+      LF_TRY(lf_bs_tower_op(c, k, BS_OP_FFT, nrow, op.i, op.kind == BIG_IFFT ? 1u : 0u, op.base, 0, op.coset, z, U, fftn, nullptr, nullptr, 0));
+    } else if (op.hi > op.lo) {
+      const u32 kind = op.kind == OP_FWD ? 0u : op.kind == OP_BWD ? 1u : 2u;
+      LF_TRY(lf_bs_tower_op(c, k, BS_OP_RANGE, nrow, kind, 1u << op.i, op.base + op.lo, op.hi - op.lo, 0, op.tw, U, fftn, nullptr, nullptr, 0));
+    }
+  }
+  const u32 top = m < fftn ? (u32)m : fftn;
+  if (n < fftn) LF_TRY(lf_bs_tower_op(c, k, BS_OP_COUT, nrow, fftn, (u32)n, top, 0, 0, z, U, fftn, nullptr, T, ld));  // evaluations n..top of the first coset
+  if (m > fftn) LF_TRY(lf_scratch(c, ub, &U2));
+  for (size_t base = fftn; base < m; base += fftn) {  // further cosets: FFT of the coefficients [c_0 .. c_{n-1}, 0 ...] with coset offset `base`
+    LF_TRY(lf_bs_tower_op(c, k, BS_OP_COPY, nrow, (u32)n, 0, 0, 0, 0, z, U, fftn, nullptr, U2, 0));
+    LF_TRY(lf_bs_tower_op(c, k, BS_OP_FFT, nrow, l, 0, 0, 0, (u64)base, z, U2, fftn, nullptr, nullptr, 0));
+    const u32 w = (u32)std::min<size_t>(fftn, m - base);
+    LF_TRY(lf_bs_tower_op(c, k, BS_OP_COUT, nrow, fftn, 0, w, 0, 0, z, U2, fftn, nullptr, T + base, ld));
+  }
+  return LFGPU_OK;
+}
+
 static int gf_rs_rows_big(lfgpu_ctx* c, const GfHostCtx* g, int k, size_t nrow, size_t n, size_t m, elt_t* T, size_t ld, unsigned l) {
   if ((size_t)1 << g->sub_bits < ((size_t)1 << l)) return lf_fail(c, LFGPU_ERR_ARG, "gf2128_rs_encode_rows: 2^l exceeds the subfield of GF2_128<%d>", k);
   const u32 fftn = 1u << l;
@@ -286,6 +323,10 @@ static int gf_rs_rows_big(lfgpu_ctx* c, const GfHostCtx* g, int k, size_t nrow, 
   const size_t nops = it->second.size() / sizeof(BigOp);
   std::vector<BigOp> ops(nops);  // copy out: the FFT calls below may insert into c->blobs
   memcpy(ops.data(), it->second.data(), nops * sizeof(BigOp));
+  {
+    static const int tower = getenv("LFGPU_RS_TOWER") ? atoi(getenv("LFGPU_RS_TOWER")) : 1;  // 0: per-block conversions (A/B)
+    if (tower && nrow >= 32 && l >= 7) return gf_rs_rows_big_tower(c, k, nrow, n, m, T, ld, l, ops);
+  }
   void* sc = nullptr;
   LF_TRY(lf_scratch2(c, nrow * fftn * 16, &sc));  // scratch2: the batched FFT takes `scratch`
   elt_t* Cc = (elt_t*)sc;

@@ -254,7 +254,10 @@ def test_lch14_fft_roundtrip_full_size(G):
                                         # the S-lig shape (LigeroParam(nw, 0, 4, 132, 2^20) over GF2_128<5>) scaled by 1/4: block 43690, all cosets fit
                                         (5, 43690, 262144, 36),
                                         # block transforms of 2^17 points and short last butterfly groups inside the truncated transform
-                                        (5, 174762, 1 << 20, 32)])
+                                        (5, 174762, 1 << 20, 32),
+                                        # >= 32 rows: the whole encoder in the tower representation (one conversion in, one out per coset);
+                                        # a partial last coset, rows that are not a multiple of 32, both subfields, n = 2^l
+                                        (4, 5000, 20000, 33), (5, 5000, 20000, 70), (4, 8192, 3 * 8192 + 100, 64), (5, 4100, 8192, 129)])
 def test_gf2128_rs_encode_rows(G, k, n, m, nrow):
     o = ol.oracle()
     rng = np.random.default_rng(n * 3 + m)
