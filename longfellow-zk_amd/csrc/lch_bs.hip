@@ -231,6 +231,8 @@ __global__ __launch_bounds__(256, WPC) void bs_cout_kernel(const u32* __restrict
 // ------------------------------------------------------------------ butterflies
 struct BflyArgs {
   u32* data;
+  const u32* src;     // where the pass READS its units (== data: in place; another buffer with the same geometry: out of place)
+  u32 valid;          // columns >= valid of `src` read as zero (the zero-padded coefficient vector of a further coset)
   const u32* tw;      // stage tables, coset folded in: tw[off[b] + u_glob]
   u32 off[BS_NB_MAX];
   u32 n;              // columns per combo (2^l)
@@ -267,8 +269,8 @@ __global__ __launch_bounds__(256, 2) void bs_bfly_kernel(BflyArgs a) {
       const u32 s = e / PIECES, p4 = e % PIECES;
       const u32 j = s >> RL, cl = s & (R - 1);
       v[it] = make_uint4(0, 0, 0, 0);
-      if (e < total)
-        v[it] = *reinterpret_cast<const uint4*>(a.data + ((size_t)(cb0 + (cl >> CU)) * a.stride + cbase + ((size_t)j << a.lo_bit) + (cl & cumask)) * M + 4 * p4);
+      if (e < total && cbase + (j << a.lo_bit) + (cl & cumask) < a.valid)
+        v[it] = *reinterpret_cast<const uint4*>(a.src + ((size_t)(cb0 + (cl >> CU)) * a.stride + cbase + ((size_t)j << a.lo_bit) + (cl & cumask)) * M + 4 * p4);
     }
 #pragma unroll
     for (u32 it = 0; it < MAXIT; ++it) {
@@ -396,11 +398,16 @@ __global__ __launch_bounds__(64 * NW, 4) void bs_bfly2_kernel(BflyArgs a) {
   u32* const stage = xch + (size_t)w * M * XS;
   const u32 piece = lane % PIECES, sub = lane / PIECES;
   auto slot_base = [&](u32 slot) { return a.data + ((size_t)(cb0 + (slot >> CU)) * a.stride + cbase + (slot & cumask)) * M; };
+  auto slot_base_in = [&](u32 slot) { return a.src + ((size_t)(cb0 + (slot >> CU)) * a.stride + cbase + (slot & cumask)) * M; };
   auto unit_in = [&](u32 j, u32 (&dst)[M]) {
     uint4 v[NIT];
     if (active) {
 #pragma unroll
-      for (u32 it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const uint4*>(slot_base(it * UPI + sub) + ((size_t)j << a.lo_bit) * M + 4 * piece);
+      for (u32 it = 0; it < NIT; ++it) {
+        const u32 slot = it * UPI + sub;
+        v[it] = make_uint4(0, 0, 0, 0);
+        if (cbase + (j << a.lo_bit) + (slot & cumask) < a.valid) v[it] = *reinterpret_cast<const uint4*>(slot_base_in(slot) + ((size_t)j << a.lo_bit) * M + 4 * piece);
+      }
 #pragma unroll
       for (u32 it = 0; it < NIT; ++it) {
         u32* q = stage + (4 * piece) * XS + it * UPI + sub;
@@ -572,7 +579,9 @@ static BsGeom<K> bs_geom(lfgpu_ctx* c, size_t rows) {
 // the butterfly passes of one transform of 2^l columns on the unit buffer `units` (pointing at the transform's first
 // column; `stride` columns per combo): bit groups of <= nbmax index bits; FFT walks stages l-1..0, IFFT 0..l-1
 template <int K>
-static int bs_passes(lfgpu_ctx* c, const GfHostCtx* g, const BsGeom<K>& gm, int inverse, unsigned l, u64 coset, u32* units, u32 stride) {
+// src != nullptr: the FIRST pass reads its units from `src` (same geometry, columns >= valid as zero) and writes `units`
+static int bs_passes(lfgpu_ctx* c, const GfHostCtx* g, const BsGeom<K>& gm, int inverse, unsigned l, u64 coset, u32* units, u32 stride,
+                     const u32* src = nullptr, u32 valid = 0xffffffffu) {
   constexpr int M = Tower<K>::M;
   static const u32 cu_env = [] {
     const char* e = getenv("LFGPU_BS_CU");
@@ -588,6 +597,8 @@ static int bs_passes(lfgpu_ctx* c, const GfHostCtx* g, const BsGeom<K>& gm, int 
     const auto& gr = inverse ? groups[gi] : groups[groups.size() - 1 - gi];
     BflyArgs a{};
     a.data = units;
+    a.src = gi == 0 && src ? src : units;
+    a.valid = gi == 0 && src ? valid : 0xffffffffu;
     a.tw = d_tw;
     for (u32 b = 0; b < gr.second; ++b) a.off[b] = offs[gr.first + b];
     a.n = n;
@@ -639,7 +650,15 @@ static int bs_convert_in(lfgpu_ctx* c, const BsGeom<K>& gm, size_t rows, u32 nco
 template <int K>
 static int bs_convert_out(lfgpu_ctx* c, const BsGeom<K>& gm, size_t rows, u32 ncols, const u32* units, u32 stride, elt_t* dst, size_t ld, u32 out_lo, u32 out_hi) {
   static const int cout_wpc = getenv("LFGPU_BS_COUT_WPC") ? atoi(getenv("LFGPU_BS_COUT_WPC")) : (K == 5 ? 4 : 2);
-  const dim3 grid(ncols / BS_COLS, gm.nrg);
+  if (out_hi > ncols) out_hi = ncols;
+  if (out_lo >= out_hi) return LFGPU_OK;
+  constexpr int M = Tower<K>::M;
+  const u32 t0 = out_lo / BS_COLS, t1 = (out_hi + BS_COLS - 1) / BS_COLS;  // only the tiles that hold columns of the window
+  const dim3 grid(t1 - t0, gm.nrg);
+  units += (size_t)t0 * BS_COLS * M;
+  dst += (size_t)t0 * BS_COLS;
+  out_lo -= t0 * BS_COLS;
+  out_hi -= t0 * BS_COLS;
   if (cout_wpc == 4)
     hipLaunchKernelGGL((bs_cout_kernel<K, 4>), grid, dim3(256), 32768, c->stream, units, ld, (u32)rows, stride, dst, out_lo, out_hi);
   else if (cout_wpc == 3)
@@ -740,8 +759,10 @@ static int bs_tower_ops(lfgpu_ctx* c, const GfHostCtx* g, int op, size_t rows, u
       return bs_convert_in<K>(c, gm, rows, a0, a1, (const elt_t*)src, ld, units, stride);
     case 1:  // cout: a0 = ncols, a1 = out_lo, a2 = out_hi
       return bs_convert_out<K>(c, gm, rows, a0, units, stride, (elt_t*)dst, ld, a1, a2);
-    case 2:  // FFT / IFFT passes: a0 = l, a1 = inverse, a2 = first column
-      return bs_passes<K>(c, g, gm, (int)a1, a0, coset, units + (size_t)a2 * M, stride);
+    case 2:  // FFT / IFFT passes: a0 = l, a1 = inverse, a2 = first column; src != nullptr: the first pass reads that unit buffer (a3 = valid columns)
+      if (src && gm.combos > gm.nrg * D)
+        LF_HIP(c, hipMemsetAsync(units + (size_t)gm.nrg * D * stride * M, 0, (size_t)(gm.combos - gm.nrg * D) * stride * M * 4, c->stream));
+      return bs_passes<K>(c, g, gm, (int)a1, a0, coset, units + (size_t)a2 * M, stride, src ? (const u32*)src + (size_t)a2 * M : nullptr, src ? a3 : 0xffffffffu);
     case 3: {  // range: a0 = kind, a1 = s, a2 = first column of the lower half + lo, a3 = count
       if (a3 == 0) return LFGPU_OK;
       const u32 t = tower_twiddle_bits<K>(tw.lo, tw.hi);

@@ -299,8 +299,8 @@ static int gf_rs_rows_big_tower(lfgpu_ctx* c, int k, size_t nrow, size_t n, size
   if (n < fftn) LF_TRY(lf_bs_tower_op(c, k, BS_OP_COUT, nrow, fftn, (u32)n, top, 0, 0, z, U, fftn, nullptr, T, ld));  // evaluations n..top of the first coset
   if (m > fftn) LF_TRY(lf_scratch(c, ub, &U2));
   for (size_t base = fftn; base < m; base += fftn) {  // further cosets: FFT of the coefficients [c_0 .. c_{n-1}, 0 ...] with coset offset `base`
-    LF_TRY(lf_bs_tower_op(c, k, BS_OP_COPY, nrow, (u32)n, 0, 0, 0, 0, z, U, fftn, nullptr, U2, 0));
-    LF_TRY(lf_bs_tower_op(c, k, BS_OP_FFT, nrow, l, 0, 0, 0, (u64)base, z, U2, fftn, nullptr, nullptr, 0));
+    // out of place: the first butterfly pass reads the coefficients from U (columns >= n as zero) and writes U2
+    LF_TRY(lf_bs_tower_op(c, k, BS_OP_FFT, nrow, l, 0, 0, (u32)n, (u64)base, z, U2, fftn, U, nullptr, 0));
     const u32 w = (u32)std::min<size_t>(fftn, m - base);
     LF_TRY(lf_bs_tower_op(c, k, BS_OP_COUT, nrow, fftn, 0, w, 0, 0, z, U2, fftn, nullptr, T + base, ld));
   }
