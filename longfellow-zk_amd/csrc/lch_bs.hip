@@ -545,6 +545,7 @@ static int bs_setup(lfgpu_ctx* c) {
   LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
   LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
   LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 68 * 1024));
+  // NW = 1, 2, 4 (groups of 1, 2, 3 index bits: as many waves as column pairs) need <= 34 KiB: under the default limit
   LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
   LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<5, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
   LF_HIP(c, hipFuncSetAttribute((const void*)bs_bfly2_kernel<4, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
@@ -618,10 +619,22 @@ static int bs_passes(lfgpu_ctx* c, const GfHostCtx* g, const BsGeom<K>& gm, int 
       else
         hipLaunchKernelGGL((bs_bfly2_kernel<K, false, 16>), grid, dim3(1024), (size_t)16 * M * 66 * 4, c->stream, a);
     } else if (gm.v2) {
-      if (inverse)
-        hipLaunchKernelGGL((bs_bfly2_kernel<K, true, 8>), grid, dim3(512), (size_t)8 * M * 66 * 4, c->stream, a);
-      else
-        hipLaunchKernelGGL((bs_bfly2_kernel<K, false, 8>), grid, dim3(512), (size_t)8 * M * 66 * 4, c->stream, a);
+      // one wave per column pair of the tile: a short group (the tail of l mod 4 bits, the small blocks of the truncated
+      // Reed-Solomon transform) launched with 8 waves left 7 / 6 / 4 of them idle and cost 1.9x / 1.4x a full pass
+      static const int match_nw = getenv("LFGPU_BS_NW_MATCH") ? atoi(getenv("LFGPU_BS_NW_MATCH")) : 1;
+      const u32 nw = match_nw ? 1u << (gr.second - 1) : 8u;
+#define BS_LAUNCH2(NWV)                                                                                                              \
+  do {                                                                                                                               \
+    if (inverse)                                                                                                                     \
+      hipLaunchKernelGGL((bs_bfly2_kernel<K, true, NWV>), grid, dim3(64 * NWV), (size_t)NWV * M * 66 * 4, c->stream, a);            \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((bs_bfly2_kernel<K, false, NWV>), grid, dim3(64 * NWV), (size_t)NWV * M * 66 * 4, c->stream, a);           \
+  } while (0)
+      if (nw == 1) BS_LAUNCH2(1);
+      else if (nw == 2) BS_LAUNCH2(2);
+      else if (nw == 4) BS_LAUNCH2(4);
+      else BS_LAUNCH2(8);
+#undef BS_LAUNCH2
     } else if (inverse)
       hipLaunchKernelGGL((bs_bfly_kernel<K, true>), grid, dim3(256), (size_t)M * BS_PS(units_per_tile) * 4, c->stream, a);
     else
