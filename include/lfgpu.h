@@ -44,8 +44,11 @@ extern "C" {
 #define LFGPU_FIELD_GF2_128 4 /* FieldID, lib/proto/circuit_io.h:24-36 */
 #define LFGPU_FIELD_FP128 6
 #define LFGPU_FIELD_P256 1 /* Fp256Base, the P-256 base field: 32-byte elements (lib/algebra/fp_p256.h); accepted by
-                              lfgpu_fp256_rs_encode_rows, lfgpu_column_commit / lfgpu_column_leaves and lfgpu_field_binop,
-                              where ld / n then count 32-byte elements */
+                              lfgpu_fp256_rs_encode_rows[_host], lfgpu_column_commit[_host] / lfgpu_column_leaves,
+                              lfgpu_field_binop, lfgpu_quad_upload (kvec: 32-byte elements) and the whole prover-level ABI of
+                              lfgpu_zk.h (circuits with field id 1); ld / n then count 32-byte elements.  The per-step
+                              sumcheck entry points below (partials, scatter, binds, bind_g, sumcheck_layer) take the
+                              16-byte fields only: for Fp256Base those steps run inside lfgpu_zk_prove / lfgpu_zk_verify */
 
 typedef struct lfgpu_ctx lfgpu_ctx;
 

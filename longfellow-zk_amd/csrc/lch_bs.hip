@@ -7,13 +7,15 @@
 // twiddle product is ~m/2 conditional plane XORs: ~45 (k=4) / ~85 (k=5) ops per butterfly.
 //
 // Pipeline (all device-resident, "internal" = bit-sliced tower units of m words):
-//   bs_cin   : rows (reference Elt layout) -> transpose 32x32 bits -> poly->tower basis -> units
-//   bs_bfly  : one launch per group of <= 4 index bits; tile = 32 (row-group, coordinate) combos x
-//              16 columns in LDS, lanes run over combos so a wave shares its twiddle (scalar branches);
-//              measured HBM-bound (32 GiB moved per pass at 3.7 TB/s)
-//   bs_cout  : units -> tower->poly basis -> transpose -> rows
-// Internal buffer: unit index ((rg*D + q)*n + c), m words each; 128-byte (k=5) / 64-byte (k=4)
-// contiguous chunks in every pass.
+//   bs_cin    : rows (reference Elt layout) -> transpose 32x32 bits -> poly->tower basis -> units
+//   bs_bfly2  : one launch per group of <= 4 index bits, a lane keeps its butterfly pair in registers through the group's
+//               stages, one wave per column pair (1 / 2 / 4 / 8 waves for groups of 1 / 2 / 3 / 4 bits); 87 % of the pass's
+//               memory-only time.  bs_bfly is the round-1 LDS-tile kernel, kept for < 64 combos.
+//   bs_cout   : units -> tower->poly basis -> transpose -> rows
+// Internal buffer: unit index ((rg*D + q)*stride + c), m words each; 128-byte (k=5) / 64-byte (k=4)
+// contiguous chunks in every pass.  The tower representation is also a WORK FORMAT: the Reed-Solomon encoder of large rows
+// (rs.hip) converts once, runs its dozen transforms on sub-blocks of a unit buffer (lf_bs_tower_op, end of this file) and
+// converts each coset of evaluations out once.
 #include <string>
 
 #include "bitslice.h"
