@@ -136,6 +136,12 @@ elt_t h_lch14_twiddle(const GfHostCtx* g, unsigned i, u64 u) {
   return t;
 }
 
+// first launch of any kernel of this library loads its code object onto the device (~150 ms for the 2 MiB of gfx950 code):
+// lfgpu_init pays that, so that the first FFT / circuit upload / proof of a process is not the one that does
+__global__ void lf_warm_kernel(u32* p) {
+  if (threadIdx.x == 0 && p) p[0] = 0;
+}
+
 // ------------------------------------------------------------------ C ABI: context
 extern "C" {
 
@@ -168,6 +174,11 @@ int lfgpu_init(int device, lfgpu_ctx** out) {
   if (hipHostMalloc(&c->stage_h, 4 * LF_STAGE_SLOT) != hipSuccess) c->stage_h = nullptr;  // optional: uploads then synchronise
   for (int i = 0; i < 4 && c->stage_h; ++i)
     if (hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess) c->stage_ev[i] = nullptr;
+  hipLaunchKernelGGL(lf_warm_kernel, dim3(1), dim3(64), 0, c->stream, (u32*)c->mailbox_d);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+    lfgpu_shutdown(c);
+    return LFGPU_ERR_HIP;
+  }
   *out = c;
   return LFGPU_OK;
 }

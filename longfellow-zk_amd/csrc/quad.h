@@ -32,3 +32,7 @@ struct lfgpu_quad {
   };
   std::vector<BindShape> bind_shape;  // indexed by round-hand
 };
+
+// lfgpu_quad_upload for corners that are already packed and range-checked (g < nv, vi < nk; hmax = largest hand index): the
+// canonical order goes up once, the by-gate order and its offsets are built on the device (quad.hip)
+int lf_quad_upload_corners(lfgpu_ctx* c, int field, size_t n, const corner4* corners, size_t hmax, size_t nk, const void* h_kvec, size_t nv, lfgpu_quad** out);

@@ -237,29 +237,61 @@ extern "C" int lfgpu_quad_free(lfgpu_quad* q) {
   return LFGPU_OK;
 }
 
-extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32_t* g, const uint32_t* h0,
-                                 const uint32_t* h1, const uint32_t* vi, size_t nk, const void* h_kvec, size_t nv,
-                                 lfgpu_quad** out) {
-  if (!c || !out || n == 0 || !g || !h0 || !h1 || !vi || !h_kvec || nk == 0 || nv == 0)
-    return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: bad argument (Quad n > 0, quad.h:86)");
-  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128 && field != LFGPU_FIELD_P256) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: field");
-  const size_t esz = field == LFGPU_FIELD_P256 ? 32 : 16;  // h_kvec: nk elements of the field's in-memory size
+// ---- the by-gate order on the device: histogram of g, exclusive scan, scatter.  eval_quad adds a gate's terms exactly
+// (field arithmetic), so their order inside a gate does not matter and the scatter may take its slots with atomics.
+__global__ __launch_bounds__(256) void quad_gate_hist_kernel(size_t n, const corner4* __restrict__ t, u32* __restrict__ cnt) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) atomicAdd(&cnt[t[i].g], 1u);
+}
+// exclusive scan of cnt[0..m) by ONE workgroup, 16 consecutive entries per thread and step (m <= a few million: well under a
+// millisecond); writes off[0..m], and a second copy the scatter consumes
+__global__ __launch_bounds__(1024) void quad_gate_scan_kernel(u32 m, const u32* __restrict__ cnt, u32* __restrict__ off, u32* __restrict__ cursor) {
+  __shared__ u32 sh[1024];
+  __shared__ u32 carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (u32 base = 0; base < m; base += 16 * 1024) {
+    const u32 i0 = base + threadIdx.x * 16;
+    u32 v[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      v[k] = i0 + k < m ? cnt[i0 + k] : 0;
+      sum += v[k];
+    }
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (u32 o = 1; o < 1024; o <<= 1) {
+      const u32 x = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += x;
+      __syncthreads();
+    }
+    u32 run = carry + sh[threadIdx.x] - sum;  // exclusive prefix of this thread's first entry
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (i0 + k < m) {
+        off[i0 + k] = run;
+        cursor[i0 + k] = run;
+      }
+      run += v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) off[m] = carry;
+}
+__global__ __launch_bounds__(256) void quad_gate_scatter_kernel(size_t n, const corner4* __restrict__ t, u32* __restrict__ cursor, corner4* __restrict__ byg) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const corner4 cr = t[i];
+  byg[atomicAdd(&cursor[cr.g], 1u)] = cr;
+}
+
+int lf_quad_upload_corners(lfgpu_ctx* c, int field, size_t n, const corner4* corners, size_t hmax, size_t nk, const void* h_kvec, size_t nv, lfgpu_quad** out) {
   if (n > 0xfffffff0u || nv > 0xfffffff0u) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: too large");
+  const size_t esz = field == LFGPU_FIELD_P256 ? 32 : 16;  // h_kvec: nk elements of the field's in-memory size
   LF_HIP(c, hipSetDevice(c->device));
-  std::vector<corner4> mort(n), byg(n);
-  std::vector<u32> goff(nv + 1, 0);
-  size_t hmax = 0;
-  for (size_t i = 0; i < n; ++i) {
-    if (g[i] >= nv || vi[i] >= nk) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: corner %zu out of range", i);
-    hmax = std::max<size_t>(hmax, std::max(h0[i], h1[i]));
-    mort[i] = corner4{g[i], h0[i], h1[i], vi[i]};
-    goff[g[i] + 1]++;
-  }
-  for (size_t v = 0; v < nv; ++v) goff[v + 1] += goff[v];
-  {
-    std::vector<u32> pos(goff.begin(), goff.end() - 1);
-    for (size_t i = 0; i < n; ++i) byg[pos[g[i]]++] = mort[i];  // counting sort: stable
-  }
   lfgpu_quad* q = new lfgpu_quad();
   q->c = c;
   q->field = field;
@@ -272,34 +304,58 @@ extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32
   q->d_kvec = nullptr;
   q->d_runoff = q->d_nh = nullptr;
   q->nh0 = 0;
+  static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
+  auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tq0 = clk();
+  u32* d_tmp = nullptr;  // gate counts, then the scatter's cursors
   bool ok = hipMalloc((void**)&q->d_morton, n * 16) == hipSuccess && hipMalloc((void**)&q->d_bygate, n * 16) == hipSuccess &&
-            hipMalloc((void**)&q->d_goff, (nv + 1) * 4) == hipSuccess && hipMalloc((void**)&q->d_kvec, nk * esz) == hipSuccess;
-  ok = ok && hipMemcpy(q->d_morton, mort.data(), n * 16, hipMemcpyHostToDevice) == hipSuccess &&
-       hipMemcpy(q->d_bygate, byg.data(), n * 16, hipMemcpyHostToDevice) == hipSuccess &&
-       hipMemcpy(q->d_goff, goff.data(), (nv + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
-       hipMemcpy(q->d_kvec, h_kvec, nk * esz, hipMemcpyHostToDevice) == hipSuccess;
+            hipMalloc((void**)&q->d_goff, (nv + 1) * 4) == hipSuccess && hipMalloc((void**)&q->d_kvec, nk * esz) == hipSuccess &&
+            hipMalloc((void**)&d_tmp, 2 * (nv + 1) * 4) == hipSuccess;
+  const double tq1 = clk();
+  ok = ok && hipMemcpyAsync(q->d_morton, corners, n * 16, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+       hipMemcpyAsync(q->d_kvec, h_kvec, nk * esz, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+       hipMemsetAsync(d_tmp, 0, (nv + 1) * 4, c->stream) == hipSuccess;
+  const u32 nb = (u32)((n + BG_THREADS - 1) / BG_THREADS);
+  u32 total = 0;
+  ok = ok && hipMalloc((void**)&q->d_runoff, (size_t)nb * 4) == hipSuccess && hipMalloc((void**)&q->d_nh, 4) == hipSuccess;
+  if (ok) {
+    const u32 nb256 = (u32)((n + 255) / 256);
+    hipLaunchKernelGGL(quad_gate_hist_kernel, dim3(nb256), dim3(256), 0, c->stream, n, (const corner4*)q->d_morton, d_tmp);
+    hipLaunchKernelGGL(quad_gate_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (u32)nv, (const u32*)d_tmp, q->d_goff, d_tmp + nv + 1);
+    hipLaunchKernelGGL(quad_gate_scatter_kernel, dim3(nb256), dim3(256), 0, c->stream, n, (const corner4*)q->d_morton, d_tmp + nv + 1, q->d_bygate);
+    // run heads of the canonical order: counts per block -> exclusive offsets + total
+    hipLaunchKernelGGL(bindg_count_kernel, dim3(nb), dim3(BG_THREADS), 0, c->stream, n, (const corner4*)q->d_morton, q->d_runoff);
+    hipLaunchKernelGGL(bindg_scan_kernel, dim3(1), dim3(1024), 0, c->stream, nb, q->d_runoff, q->d_nh);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&total, q->d_nh, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+         hipStreamSynchronize(c->stream) == hipSuccess;  // also: `corners` and `h_kvec` are the caller's
+  }
+  const double tq2 = clk();
+  if (d_tmp) (void)hipFree(d_tmp);
+  if (verbose) fprintf(stderr, "lfgpu quad_upload: %zu terms, %zu gates: alloc %.2f ms, copy + kernels %.2f ms, free %.2f ms\n", n, nv, tq1 - tq0, tq2 - tq1, clk() - tq2);
   if (!ok) {
     lfgpu_quad_free(q);
-    return lf_fail(c, LFGPU_ERR_NOMEM, "quad_upload: device allocation / copy failed");
+    return lf_fail(c, LFGPU_ERR_NOMEM, "quad_upload: device allocation / copy / run structure failed");
   }
-  {  // run heads: counts per block -> exclusive offsets + total
-    const u32 nb = (u32)((n + BG_THREADS - 1) / BG_THREADS);
-    u32 total = 0;
-    ok = hipMalloc((void**)&q->d_runoff, (size_t)nb * 4) == hipSuccess && hipMalloc((void**)&q->d_nh, 4) == hipSuccess;
-    if (ok) {
-      hipLaunchKernelGGL(bindg_count_kernel, dim3(nb), dim3(BG_THREADS), 0, c->stream, n, (const corner4*)q->d_morton, q->d_runoff);
-      hipLaunchKernelGGL(bindg_scan_kernel, dim3(1), dim3(1024), 0, c->stream, nb, q->d_runoff, q->d_nh);
-      ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&total, q->d_nh, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-           hipStreamSynchronize(c->stream) == hipSuccess;
-    }
-    if (!ok) {
-      lfgpu_quad_free(q);
-      return lf_fail(c, LFGPU_ERR_NOMEM, "quad_upload: run structure");
-    }
-    q->nh0 = total;
-  }
+  q->nh0 = total;
   *out = q;
   return LFGPU_OK;
+}
+
+extern "C" int lfgpu_quad_upload(lfgpu_ctx* c, int field, size_t n, const uint32_t* g, const uint32_t* h0,
+                                 const uint32_t* h1, const uint32_t* vi, size_t nk, const void* h_kvec, size_t nv,
+                                 lfgpu_quad** out) {
+  if (!c || !out || n == 0 || !g || !h0 || !h1 || !vi || !h_kvec || nk == 0 || nv == 0)
+    return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: bad argument (Quad n > 0, quad.h:86)");
+  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128 && field != LFGPU_FIELD_P256) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: field");
+  if (n > 0xfffffff0u || nv > 0xfffffff0u) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: too large");
+  std::vector<corner4> mort(n);
+  size_t hmax = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (g[i] >= nv || vi[i] >= nk) return lf_fail(c, LFGPU_ERR_ARG, "quad_upload: corner %zu out of range", i);
+    hmax = std::max<size_t>(hmax, std::max(h0[i], h1[i]));
+    mort[i] = corner4{g[i], h0[i], h1[i], vi[i]};
+  }
+  return lf_quad_upload_corners(c, field, n, mort.data(), hmax, nk, h_kvec, nv, out);
 }
 
 // one layer, asynchronously: assert-zero failures are OR-ed into *d_fail (device); the caller clears and reads it

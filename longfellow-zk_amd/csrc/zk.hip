@@ -253,34 +253,45 @@ extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t le
   std::unique_ptr<lfgpu_circuit> C(new lfgpu_circuit());
   C->c = c;
   size_t nterms = 0, nout = nv;
-  std::vector<u32> g, h0, h1, vi;
+  std::vector<corner4> corners;
+  const double t_begin = now_ms();
+  double t_upload = 0;
   for (size_t ly = 0; ly < nl; ++ly) {
     size_t logw, nw, nq;
     if (!num(&logw) || !num(&nw) || !num(&nq)) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: truncated layer header");
     // read_layers (circuit_reader.h:161-168): lw in (0, kMaxBindings], 0 < nw, lw <= nw <= 2^lw, nq > 0
     if (logw > kMaxBindings || logw == 0 || nw == 0 || nw < logw || nw > ((size_t)1 << logw) || nq == 0 || !need(12 * nq))
       return lf_fail(c, LFGPU_ERR_ARG, "LFC1: bad layer %zu", ly);
-    g.resize(nq); h0.resize(nq); h1.resize(nq); vi.resize(nq);
+    corners.resize(nq);
     int64_t acc[3] = {0, 0, 0};
-    for (size_t t = 0; t < nq; ++t) {
-      size_t v[4];
-      for (int j = 0; j < 4; ++j) num(&v[j]);
+    const uint8_t* q = b + pos;  // 12 * nq bytes are there (checked above): four 3-byte little-endian numbers per term
+    size_t hmax = 0;
+    for (size_t t = 0; t < nq; ++t, q += 12) {
+      u32 v[4];
+      for (int j = 0; j < 4; ++j) v[j] = (u32)q[3 * j] | (u32)q[3 * j + 1] << 8 | (u32)q[3 * j + 2] << 16;
       for (int j = 0; j < 3; ++j) {  // delta with the sign in the LSB (circuit_writer.h:103-114)
         const int64_t d = (int64_t)(v[j] >> 1);
         acc[j] += (v[j] & 1) ? -d : d;
       }
       if (acc[0] < 0 || (size_t)acc[0] >= nout || acc[1] < 0 || (size_t)acc[1] >= nw || acc[2] < 0 || (size_t)acc[2] >= nw || v[3] >= nk)
         return lf_fail(c, LFGPU_ERR_ARG, "LFC1: layer %zu term %zu out of range", ly, t);
-      g[t] = (u32)acc[0]; h0[t] = (u32)acc[1]; h1[t] = (u32)acc[2]; vi[t] = (u32)v[3];
+      corners[t] = corner4{(u32)acc[0], (u32)acc[1], (u32)acc[2], v[3]};
+      hmax = std::max<size_t>(hmax, (size_t)std::max(acc[1], acc[2]));
     }
+    pos += 12 * nq;
     lfgpu_circuit::Layer L{logw, nw, nq, nullptr};
-    LF_TRY(lfgpu_quad_upload(c, field, nq, g.data(), h0.data(), h1.data(), vi.data(), nk, kvec.data(), nout, &L.q));
+    const double tu0 = now_ms();
+    LF_TRY(lf_quad_upload_corners(c, field, nq, corners.data(), hmax, nk, kvec.data(), nout, &L.q));  // indices range-checked above
+    t_upload += now_ms() - tu0;
     C->layers.push_back(L);
     nterms += nq;
     nout = nw;
   }
   if (!need(32) || pos + 32 != len) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: bad trailer");
   if (nout != nin) return lf_fail(c, LFGPU_ERR_ARG, "LFC1: input layer width %zu != ninputs %zu", nout, nin);
+  if (getenv("LFGPU_VERBOSE"))
+    fprintf(stderr, "lfgpu circuit_from_lfc1: %zu terms in %zu layers: %.1f ms (decode %.1f, lfgpu_quad_upload %.1f)\n", nterms, nl, now_ms() - t_begin,
+            now_ms() - t_begin - t_upload, t_upload);
   lfgpu_circuit_info& I = C->info;
   I.field = field;
   I.nv = nv; I.nc = nc; I.npub_in = npub; I.subfield_boundary = sfb; I.ninputs = nin; I.nl = nl; I.nterms = nterms;
