@@ -347,6 +347,20 @@ def zk_prove_mdoc(pkg, gpu, np, reps=3):
         zk.close()
         circ.close()
     rng_t.close()
+    # the whole run_mdoc_prover / run_mdoc_verifier bodies with the library's provers / verifiers in the reference's place, next
+    # to the reference's own on this host (oracle/_ref/mdoc_gpu: built in the build container, travels with the snapshot)
+    exe = os.path.join(ROOT, "oracle", "_ref", "mdoc_gpu")
+    if os.path.exists(exe):
+        import subprocess
+        try:
+            r = subprocess.run([exe, "3"], capture_output=True, timeout=240)
+            e2e = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            res["end_to_end"] = {"proof_bytes_identical_to_reference": e2e["identical"], "reference_verifier_accepts": e2e["reference_verifier_accepts_gpu_proof"],
+                                 "prove_ms": e2e["gpu_ms"], "cpu_reference_prove_ms": dict(e2e["ref_ms"], cores=1, kind="reference"),
+                                 "verify_ms": e2e["verify"]["gpu_ms"], "cpu_reference_verify_ms": e2e["verify"]["ref_ms"],
+                                 "circuit_parse_upload_ms": e2e["host_ms"]["gpu_parse_upload"], "cpu_reference_parse_ms": e2e["host_ms"]["reference_parse"]}
+        except Exception as e:  # noqa: BLE001
+            res["end_to_end"] = {"error": repr(e)[:200]}
     res["total_ms"] = res["hash"]["total_ms"] + res["sig"]["total_ms"]
     res["cpu_reference_total_ms"] = res["hash"]["cpu_reference"]["total_ms"] + res["sig"]["cpu_reference"]["total_ms"]
     return res

@@ -45,12 +45,13 @@ __global__ __launch_bounds__(256, WPC) void bs_cin_kernel(const elt_t* __restric
   const u32 t = threadIdx.x, rg = blockIdx.y, c0 = blockIdx.x * BS_COLS;
   {  // phase 1: coalesced row reads (16 B per lane, 1 KiB contiguous per row), all issued before the LDS writes
     const u32 lc = t & (BS_COLS - 1), rq = t / BS_COLS;
+    const u32 rows_eff = c0 + lc < valid ? rows : 0u;  // columns past the data read as zero: same loop as without the bound
     uint4 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const u32 row = rg * 32 + rq * 8 + i;
       v[i] = make_uint4(0, 0, 0, 0);
-      if (row < rows && c0 + lc < valid) v[i] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c0 + lc);
+      if (row < rows_eff) v[i] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c0 + lc);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(&lds[((rq * 8 + i) * BS_COLS + lc) * 4]) = v[i];
@@ -221,11 +222,11 @@ __global__ __launch_bounds__(256, WPC) void bs_cout_kernel(const u32* __restrict
   __syncthreads();
   {
     const u32 lc = t & (BS_COLS - 1), rq = t / BS_COLS;
+    const u32 rows_eff = (c0 + lc >= out_lo && c0 + lc < out_hi) ? rows : 0u;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const u32 r = rq * 8 + i, row = rg * 32 + r;
-      if (row < rows && c0 + lc >= out_lo && c0 + lc < out_hi)
-        *reinterpret_cast<uint4*>(dst + (size_t)row * ld + c0 + lc) = *reinterpret_cast<const uint4*>(&lds[(r * BS_COLS + lc) * 4]);
+      if (row < rows_eff) *reinterpret_cast<uint4*>(dst + (size_t)row * ld + c0 + lc) = *reinterpret_cast<const uint4*>(&lds[(r * BS_COLS + lc) * 4]);
     }
   }
 }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256, WPC) void bs_cout_kernel(const u32* __restrict
 // ------------------------------------------------------------------ butterflies
 struct BflyArgs {
   u32* data;
-  const u32* src;     // where the pass READS its units (== data: in place; another buffer with the same geometry: out of place)
+  long long src_off;  // words from `data` to where the pass READS its units (0: in place; else another buffer with the same geometry)
   u32 valid;          // columns >= valid of `src` read as zero (the zero-padded coefficient vector of a further coset)
   const u32* tw;      // stage tables, coset folded in: tw[off[b] + u_glob]
   u32 off[BS_NB_MAX];
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void bs_bfly_kernel(BflyArgs a) {
       const u32 j = s >> RL, cl = s & (R - 1);
       v[it] = make_uint4(0, 0, 0, 0);
       if (e < total && cbase + (j << a.lo_bit) + (cl & cumask) < a.valid)
-        v[it] = *reinterpret_cast<const uint4*>(a.src + ((size_t)(cb0 + (cl >> CU)) * a.stride + cbase + ((size_t)j << a.lo_bit) + (cl & cumask)) * M + 4 * p4);
+        v[it] = *reinterpret_cast<const uint4*>(a.data + a.src_off + ((size_t)(cb0 + (cl >> CU)) * a.stride + cbase + ((size_t)j << a.lo_bit) + (cl & cumask)) * M + 4 * p4);
     }
 #pragma unroll
     for (u32 it = 0; it < MAXIT; ++it) {
@@ -400,16 +401,17 @@ __global__ __launch_bounds__(64 * NW, 4) void bs_bfly2_kernel(BflyArgs a) {
   u32* const stage = xch + (size_t)w * M * XS;
   const u32 piece = lane % PIECES, sub = lane / PIECES;
   auto slot_base = [&](u32 slot) { return a.data + ((size_t)(cb0 + (slot >> CU)) * a.stride + cbase + (slot & cumask)) * M; };
-  auto slot_base_in = [&](u32 slot) { return a.src + ((size_t)(cb0 + (slot >> CU)) * a.stride + cbase + (slot & cumask)) * M; };
   auto unit_in = [&](u32 j, u32 (&dst)[M]) {
     uint4 v[NIT];
     if (active) {
 #pragma unroll
       for (u32 it = 0; it < NIT; ++it) {
         const u32 slot = it * UPI + sub;
-        v[it] = make_uint4(0, 0, 0, 0);
-        if (cbase + (j << a.lo_bit) + (slot & cumask) < a.valid) v[it] = *reinterpret_cast<const uint4*>(slot_base_in(slot) + ((size_t)j << a.lo_bit) * M + 4 * piece);
+        v[it] = *reinterpret_cast<const uint4*>(slot_base(slot) + a.src_off + ((size_t)j << a.lo_bit) * M + 4 * piece);  // always in bounds: same geometry
       }
+#pragma unroll
+      for (u32 it = 0; it < NIT; ++it)  // selects after the loads: the loads of a unit stay one batch
+        if (cbase + (j << a.lo_bit) + ((it * UPI + sub) & cumask) >= a.valid) v[it] = make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (u32 it = 0; it < NIT; ++it) {
         u32* q = stage + (4 * piece) * XS + it * UPI + sub;
@@ -600,7 +602,7 @@ static int bs_passes(lfgpu_ctx* c, const GfHostCtx* g, const BsGeom<K>& gm, int 
     const auto& gr = inverse ? groups[gi] : groups[groups.size() - 1 - gi];
     BflyArgs a{};
     a.data = units;
-    a.src = gi == 0 && src ? src : units;
+    a.src_off = gi == 0 && src ? (long long)(src - units) : 0;
     a.valid = gi == 0 && src ? valid : 0xffffffffu;
     a.tw = d_tw;
     for (u32 b = 0; b < gr.second; ++b) a.off[b] = offs[gr.first + b];
