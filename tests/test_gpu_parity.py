@@ -257,7 +257,10 @@ def test_lch14_fft_roundtrip_full_size(G):
                                         (5, 174762, 1 << 20, 32),
                                         # >= 32 rows: the whole encoder in the tower representation (one conversion in, one out per coset);
                                         # a partial last coset, rows that are not a multiple of 32, both subfields, n = 2^l
-                                        (4, 5000, 20000, 33), (5, 5000, 20000, 70), (4, 8192, 3 * 8192 + 100, 64), (5, 4100, 8192, 129)])
+                                        (4, 5000, 20000, 33), (5, 5000, 20000, 70), (4, 8192, 3 * 8192 + 100, 64), (5, 4100, 8192, 129),
+                                        # >= 64 (row group, coordinate) combos: the register-resident butterfly kernel on sub-blocks, out of
+                                        # place for the further cosets, workgroups of 1 / 2 / 4 / 8 waves for the short groups
+                                        (5, 5000, 20000, 512), (4, 4100, 8192 + 100, 256), (5, 2731, 16384, 544)])
 def test_gf2128_rs_encode_rows(G, k, n, m, nrow):
     o = ol.oracle()
     rng = np.random.default_rng(n * 3 + m)
