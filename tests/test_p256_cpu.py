@@ -124,3 +124,20 @@ def test_oracle_vs_compiled_reference():
     r.ref_p256_column_commit(7, 40, 9, 31, P(T), P(nz), P(r1))
     o.lfo_column_commit32(7, 40, 9, 31, P(T), P(nz), P(r2), None)
     assert (r1 == r2).all()
+
+
+def test_small_p256_fixture_is_consistent():
+    """tests/golden/small_p256.json (the reference's zk_test example circuit over Fp256Base, proved by the reference): the stored
+    SHA-256 is that of the stored wire bytes, the LFC1 header names field id 1, and the witness satisfies the circuit's
+    relation 2 n = (s - 2) m^2 - (s - 4) m over the P-256 base field (values out of Montgomery form)."""
+    import hashlib
+    import json
+    import os
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_p256.json")))
+    wire, lfc1, w = bytes.fromhex(fx["zk_wire"]), bytes.fromhex(fx["lfc1"]), bytes.fromhex(fx["witness"])
+    assert hashlib.sha256(wire).hexdigest() == fx["zk_wire_sha256"] and fx["reference_verifier_accepts"] is True
+    assert lfc1[0] == 1 and int.from_bytes(lfc1[1:4], "little") == 1  # version, FieldID P256_ID
+    p = ol.P256_P
+    Rinv = pow(1 << 256, -1, p)
+    one, n, m, s_ = (int.from_bytes(w[32 * i:32 * i + 32], "little") * Rinv % p for i in range(4))
+    assert one == 1 and (2 * n - ((s_ - 2) * m * m - (s_ - 4) * m)) % p == 0

@@ -551,3 +551,51 @@ def test_zk_mdoc_signature_circuit_matches_reference():
     assert verify(wire[:-5], pub) == (False, "proof does not parse")
     zk.close()
     circ.close()
+
+
+@pytest.mark.gpu
+def test_zk_small_p256_circuit_matches_reference():
+    """The Fp256Base prover and verifier on TINY layers: the reference's own zk_test example circuit (lib/zk/zk_test.cc:250-271,
+    2 n = (s - 2) m^2 - (s - 4) m; 2 layers, 4 inputs of which 2 public) compiled over the P-256 base field and proved by the
+    reference's ZkProver<Fp256Base, .> with rate 4, 6 queries, block_enc chosen by LigeroParam's search (oracle/ref_small_p256.cc
+    -> tests/golden/small_p256.json, `./oracle/_ref/gen_small_p256 > tests/golden/small_p256.json`): the library's wire bytes
+    must be identical, its verifier must accept them and reject tampered copies; a witness with m changed does not prove."""
+    import gpu_util as G
+    import ligero_fixture as lf
+    fx = json.load(open(os.path.join(GOLD, "small_p256.json")))
+    assert fx["reference_verifier_accepts"] is True
+    raw, want = bytes.fromhex(fx["lfc1"]), bytes.fromhex(fx["zk_wire"])
+    W = np.frombuffer(bytes.fromhex(fx["witness"]), dtype=np.uint64).reshape(-1, 4).copy()
+    gpu = G.gpu()
+    circ = G.pkg.Circuit(gpu, raw)
+    ci = circ.info
+    assert (ci.field, ci.nl, ci.ninputs, ci.npub_in, ci.nv) == (G.pkg.FIELD_P256, fx["nl"], fx["ninputs"], fx["npub_in"], fx["nv"])
+    zk = G.pkg.ZkProver(gpu, circ, fx["rate"], fx["nreq"], 0)
+    assert (zk.param.block_enc, zk.param.nrow, zk.param.block) == (fx["block_enc"], fx["nrow"], fx["block"])
+    ts = G.pkg.FsTranscript(b"test")
+    zk.commit(W, lf.LcgRng(100).bytes, ts)
+    assert zk.prove(W, ts)
+    wire = zk.wire()
+    ts.close()
+    assert wire == want and hashlib.sha256(wire).hexdigest() == fx["zk_wire_sha256"]
+
+    def verify(w, pub):
+        tv = G.pkg.FsTranscript(b"test")
+        try:
+            return G.pkg.zk_verify(gpu, circ, w, pub, tv, fx["rate"], fx["nreq"], 0)
+        finally:
+            tv.close()
+    pub = W[:ci.npub_in]
+    assert verify(wire, pub) == (True, "ok")
+    for off in (3, 40, 200, len(wire) // 2, len(wire) - 40):
+        bad = bytearray(wire)
+        bad[off] ^= 1
+        assert verify(bytes(bad), pub)[0] is False, off
+    Wbad = W.copy()
+    Wbad[2, 0] ^= np.uint64(8)  # m: the constraint no longer holds
+    ts = G.pkg.FsTranscript(b"test")
+    zk.commit(Wbad, lf.LcgRng(100).bytes, ts)
+    assert zk.prove(Wbad, ts) is False
+    ts.close()
+    zk.close()
+    circ.close()
