@@ -293,6 +293,411 @@ __global__ __launch_bounds__(Z_THREADS) void bind256_kernel(u32 nbd, size_t n0, 
   st32(&vc_out[off], v);
 }
 
+// ---- the rest of a layer in ONE launch of co-resident workgroups (what sc_grid_layer_kernel is for the 16-byte fields,
+// sumcheck.hip: same phases, same bounded waits, without its LDS tail and wave-split variants).  Per round-hand:
+//   barrier | sums a0, a2 -> per-workgroup slots -> the workgroup that arrives last folds them and posts to the host |
+//   layout of HQuad::bind_h (which entries merge, where each result goes: nothing of it needs the challenge, so it hides behind
+//   the host's turn) | challenge (eight tagged words) | Dense::bind + HQUAD values + the NEXT evaluation's accumulators from
+//   those values (double-buffered) | workgroups beyond ceil(largest array / per_wg) leave.
+// Launched as an ordinary kernel of <= G256_WGS <= #CU workgroups (the host checks co-residency); every wait is bounded by an
+// abort flag and a wall-clock timeout, so all waves always leave.
+#define G256_THREADS 512
+#define G256_WGS 128
+#define G256_MAX (128u * 1024u)  // largest HQUAD / hand array the grid takes
+struct Grid256Sync {  // device memory, zeroed before every launch
+  u32 count, gen, abort, arrive;
+  u64 chal[8];  // the challenge as the host's eight tagged words
+  u64 pad_[6];
+  u32 l1_bar[8 * 16];  // first-level arrival counters of the barrier, one cache line each
+  u32 l1_arr[8 * 16];  // ... of the sums' arrival ticket
+  u64 slots[8 * G256_WGS];  // per workgroup {a0, a2}
+};
+struct Grid256 {
+  uint2* hcA;  // current HQUAD
+  E* vcA;
+  uint2* hcB;  // the other half of the ping-pong
+  E* vcB;
+  u32 nh;
+  const E* W[2];  // hand arrays at entry
+  u32 nW[2];
+  E* Wb[2][2];  // bind destinations per hand (ping-pong)
+  u64* QW;      // limb accumulators of the evaluation being summed, 8 words per target
+  u64* QW2;     // of the next one
+  u32 rh0, rh1;  // round-hands [rh0, rh1), rh1 = 2 logw
+  u64 seq0, timeout_ticks;
+  volatile u64* post;
+  const volatile u64* cmd;
+  Grid256Sync* gs;
+  u32* counts;  // one word per workgroup
+  u32* src;     // one word per HQUAD entry: where each bound entry comes from (+ its merge kind in the top bits)
+  u32 per_wg;
+  E rsq;
+};
+// two-level arrival ticket (see sc_arrive in sumcheck.hip): true for the one workgroup that arrives last
+__device__ __forceinline__ bool g256_arrive(u32* lvl1, u32* lvl2, u32 G, u32 g) {
+  const u32 grp = g & 7, ngrp = G < 8 ? G : 8, members = (G - grp + 7) >> 3;
+  u32* c1 = lvl1 + grp * 16;
+  if (__hip_atomic_fetch_add(c1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != members - 1) return false;
+  __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__hip_atomic_fetch_add(lvl2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) != ngrp - 1) return false;
+  __hip_atomic_store(lvl2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+// barrier among the first G workgroups; false = aborted (every caller then returns)
+__device__ __forceinline__ bool g256_barrier(Grid256Sync* gs, u32 G, u32& gen, u64 timeout_ticks) {
+  __shared__ u32 s_abort;
+  if (G == 1) {
+    __threadfence_block();
+    __syncthreads();
+    return true;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 ab = 0;
+    const u64 t0 = wall_clock64();
+    if (g256_arrive(gs->l1_bar, &gs->count, G, blockIdx.x)) {
+      __hip_atomic_fetch_add(&gs->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (__hip_atomic_load(&gs->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          ab = 1;
+          break;
+        }
+        if (wall_clock64() - t0 > 2 * timeout_ticks) {  // never reached in a healthy run: no wait is unbounded
+          __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          ab = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    s_abort = ab;
+  }
+  ++gen;
+  __syncthreads();
+  return s_abort == 0;
+}
+
+__global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) {
+  __shared__ E s_red[2][G256_THREADS / 64];
+  __shared__ u32 s_wave[G256_THREADS / 64];
+  __shared__ u32 s_carry, s_off, s_tot, s_last;
+  __shared__ u64 s_cmd[5];
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32 g = blockIdx.x;
+  u32 G = gridDim.x;  // active workgroups: shrinks with the data
+  Grid256Sync* gs = a.gs;
+  const uint2* hc = a.hcA;
+  const E* vc = a.vcA;
+  uint2* hc_o = a.hcB;
+  E* vc_o = a.vcB;
+  u32 nh = a.nh;
+  const E* W[2] = {a.W[0], a.W[1]};
+  u32 nW[2] = {a.nW[0], a.nW[1]};
+  u32 wsel[2] = {a.W[0] == a.Wb[0][0] ? 1u : 0u, a.W[1] == a.Wb[1][0] ? 1u : 0u};
+  u64* QW = a.QW;
+  u64* QWn = a.QW2;
+  u32 gen = 0;
+  u64 seq = a.seq0;
+  const E rsq = a.rsq;
+  {
+    const u32 GT = G * G256_THREADS, gtid = (wave * G + g) * 64 + lane;  // 64-entry chunks dealt round-robin over the workgroups
+    const u32 h0 = a.rh0 & 1;
+    for (u32 i = gtid; i < 8 * nW[h0]; i += GT) QW[i] = 0;
+    for (u32 i = gtid; i < 8 * nW[1 - h0]; i += GT) QWn[i] = 0;
+  }
+  if (!g256_barrier(gs, G, gen, a.timeout_ticks)) return;
+  {  // first evaluation of the hand-off: QW[h[hand]] += v * Wother[h[1-hand]] over the whole HQUAD
+    const int hand = (int)(a.rh0 & 1);
+    const u32 GT = G * G256_THREADS;
+    const E* Wo = W[1 - hand];
+    for (u32 base = (wave * G + g) * 64; base < (nh + 63) / 64 * 64; base += GT) {  // whole waves: the fold shuffles
+      const u32 i = base + lane;
+      u32 key = 0xffffffffu;
+      E t = e32_zero();
+      if (i < nh) {
+        const uint2 h = hc[i];
+        key = hand ? h.y : h.x;
+        t = fp256_mul(ld32(&vc[i]), ld32(&Wo[hand ? h.x : h.y]));
+      }
+      run_fold_commit256(key, t, QW);
+    }
+  }
+  for (u32 rh = a.rh0; rh < a.rh1; ++rh, ++seq) {
+    const int hand = (int)(rh & 1);
+    if (!g256_barrier(gs, G, gen, a.timeout_ticks)) return;  // the accumulators of this evaluation are complete
+    {  // shrink: one workgroup per per_wg entries of the largest array; the others are done
+      u32 big = nh > nW[0] ? nh : nW[0];
+      big = big > nW[1] ? big : nW[1];
+      u32 want = (big + a.per_wg - 1) / a.per_wg;
+      want = want ? want : 1;
+      if (want < G) G = want;
+      if (g >= G) return;
+    }
+    const u32 GT = G * G256_THREADS, gtid = (wave * G + g) * 64 + lane;
+    // ---- ProverLayers::evaluations: a0, a2 from the accumulators
+    {
+      const u32 nq = nW[hand], nodd = nq / 2;
+      const E* Wh = W[hand];
+      auto qw_at = [&](u32 j) -> E {
+        u64 q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = QW[8 * (size_t)j + k];
+        return fp256_reduce_limbs(q, rsq);
+      };
+      E a0 = e32_zero(), a2 = e32_zero();
+      for (u32 i = gtid; i < nodd; i += GT) {
+        const E q0 = qw_at(2 * i), q1 = qw_at(2 * i + 1), w0 = ld32(&Wh[2 * i]), w1 = ld32(&Wh[2 * i + 1]);
+        a0 = fp256_add(a0, fp256_mul(q0, w0));
+        a2 = fp256_add(a2, fp256_mul(fp256_sub(q1, q0), fp256_sub(w1, w0)));
+      }
+      if (gtid == 0 && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388)
+        const E t = fp256_mul(qw_at(2 * nodd), ld32(&Wh[2 * nodd]));
+        a0 = fp256_add(a0, t);
+        a2 = fp256_add(a2, t);
+      }
+      auto wg_sum = [&](E& x0, E& x2) {  // wave shuffles, then the wave sums through LDS; result in thread 0
+        for (int off = 32; off > 0; off >>= 1) {
+          E o0, o2;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            o0.l[k] = __shfl_down(x0.l[k], off, 64);
+            o2.l[k] = __shfl_down(x2.l[k], off, 64);
+          }
+          x0 = fp256_add(x0, o0);
+          x2 = fp256_add(x2, o2);
+        }
+        if (lane == 0) {
+          s_red[0][wave] = x0;
+          s_red[1][wave] = x2;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          x0 = s_red[0][0];
+          x2 = s_red[1][0];
+          for (u32 w = 1; w < G256_THREADS / 64; ++w) {
+            x0 = fp256_add(x0, s_red[0][w]);
+            x2 = fp256_add(x2, s_red[1][w]);
+          }
+        }
+        __syncthreads();
+      };
+      wg_sum(a0, a2);
+      bool poster = tid == 0;
+      if (G > 1) {  // slots + arrival ticket: the last workgroup to arrive folds all slots
+        if (tid == 0) {
+          u64* sl = &gs->slots[8 * g];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            sl[k] = a0.l[k];
+            sl[4 + k] = a2.l[k];
+          }
+          s_last = g256_arrive(gs->l1_arr, &gs->arrive, G, g) ? 1u : 0u;  // releases the slot
+        }
+        __syncthreads();
+        poster = false;
+        if (s_last) {  // uniform per workgroup
+          a0 = e32_zero();
+          a2 = e32_zero();
+          if (tid < G) {
+            const u64* sl = &gs->slots[8 * tid];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              a0.l[k] = __hip_atomic_load(&sl[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              a2.l[k] = __hip_atomic_load(&sl[4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          wg_sum(a0, a2);
+          poster = tid == 0;
+        }
+      }
+      if (poster) {  // system-scope stores into the pinned words, then the sequence number
+        u64* po = (u64*)a.post;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __hip_atomic_store(&po[k], a0.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&po[4 + k], a2.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __hip_atomic_store(&po[8], (u64)nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[9], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&po[16], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    // ---- while the host works on the challenge: the layout of HQuad::bind_h
+    u32 my_off, my_end, new_nh;
+    {
+      const u32 R = ((nh + G - 1) / G + 63) / 64 * 64;  // range per workgroup, whole waves
+      const u32 lo = (u64)g * R < nh ? g * R : nh, hi = (u64)lo + R < nh ? lo + R : nh;
+      if (tid == 0) {
+        s_carry = 0;
+        s_off = 0;
+        s_tot = 0;
+      }
+      __syncthreads();
+      if (G > 1) {
+        u32 mine = 0;
+        for (u32 base = lo; base < hi; base += G256_THREADS) {
+          const u32 i = base + tid;
+          const bool head = i < hi && !is_second256(hc, i, hand);
+          mine += (u32)__popcll(__ballot(head));
+        }
+        if (lane == 0 && mine) atomicAdd(&s_carry, mine);
+        __syncthreads();
+        if (tid == 0) a.counts[g] = s_carry;
+        if (!g256_barrier(gs, G, gen, a.timeout_ticks)) return;
+        if (tid < G) {
+          const u32 cnt = a.counts[tid];
+          if (cnt) {
+            atomicAdd(&s_tot, cnt);
+            if (tid < g) atomicAdd(&s_off, cnt);
+          }
+        }
+        __syncthreads();
+      }
+      my_off = s_off;
+      __syncthreads();
+      if (tid == 0) s_carry = my_off;
+      __syncthreads();
+      for (u32 base = lo; base < hi; base += G256_THREADS) {
+        const u32 i = base + tid;
+        const bool head = i < hi && !is_second256(hc, i, hand);
+        const u64 mask = __ballot(head);
+        if (lane == 0) s_wave[wave] = (u32)__popcll(mask);
+        __syncthreads();
+        u32 off = s_carry;
+        for (u32 w = 0; w < wave; ++w) off += s_wave[w];
+        off += (u32)__popcll(mask & ((1ull << lane) - 1));
+        if (head) {
+          uint2 h = hc[i];
+          const u32 hh = hand ? h.y : h.x;
+          const u32 kind = (i + 1 < nh && is_second256(hc, i + 1, hand)) ? 0u : ((hh & 1) == 0 ? 1u : 2u);
+          if (hand) h.y = hh >> 1;
+          else h.x = hh >> 1;
+          hc_o[off] = h;
+          a.src[off] = i | (kind << 30);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          u32 tot = 0;
+          for (u32 w = 0; w < G256_THREADS / 64; ++w) tot += s_wave[w];
+          s_carry += tot;
+        }
+        __syncthreads();
+      }
+      my_end = s_carry;
+      new_nh = G > 1 ? s_tot : my_end;
+    }
+    // ---- the challenge: eight 64-bit words {tag = low half of the sequence number, 32 bits of the challenge}; a read that
+    // finds the tag in all eight has the whole challenge.  Workgroup 0 polls the host and hands it on through a device slot.
+    if (wave == 0) {
+      const u64 t0 = wall_clock64();
+      const u64 tag = seq & 0xffffffffull;
+      const bool from_host = g == 0;
+      u64 got = 0, w = 0;
+      for (;;) {
+        if (lane < 8) {
+          if (from_host) w = __hip_atomic_load((const u64*)&a.cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          else w = __hip_atomic_load(&gs->chal[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (__all(lane >= 8 || (w >> 32) == tag)) {
+          got = seq;
+          break;
+        }
+        int stop = 0;
+        if (lane == 0) {
+          if (G > 1 && __hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) stop = 1;
+          else if (wall_clock64() - t0 > (from_host ? 1 : 2) * a.timeout_ticks) {  // the host went away: release every workgroup and report
+            __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == 0) {
+              a.post[9] = 1;
+              __threadfence_system();
+              __hip_atomic_store((u64*)&a.post[16], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            stop = 1;
+          }
+        }
+        if (__shfl(stop, 0, 64)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (got == seq && g == 0 && G > 1 && lane < 8) __hip_atomic_store(&gs->chal[lane], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 lo32 = w & 0xffffffffull;
+      const u64 even = __shfl(lo32, (lane & 3) * 2, 64), odd = __shfl(lo32, (lane & 3) * 2 + 1, 64);
+      if (lane < 4) s_cmd[lane] = even | (odd << 32);
+      if (lane == 0) s_cmd[4] = got;
+    }
+    __syncthreads();
+    if (s_cmd[4] != seq) return;  // uniform per workgroup; the barriers of the others see the abort flag
+    E r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.l[k] = s_cmd[k];
+    // ---- Dense::bind of W[hand] (out of place); the HQUAD values for the layout above; and, from those values, the next
+    // evaluation's accumulators -- the bound hand entry is recomputed from the unbound array (one more product) so that no
+    // workgroup waits for another one's Dense::bind
+    const E* Wold = W[hand];
+    const u32 n0 = nW[hand], nout = (n0 + 1) / 2;
+    auto bind_at = [&](u32 j) -> E {
+      const E f0 = ld32(&Wold[2 * j]);
+      if (2 * j + 1 < n0) return fp256_add(f0, fp256_mul(fp256_sub(ld32(&Wold[2 * j + 1]), f0), r));
+      return fp256_sub(f0, fp256_mul(f0, r));
+    };
+    const bool more = rh + 1 < a.rh1;
+    for (u32 i = gtid; i < 8 * nout; i += GT) QW[i] = 0;  // next written two round-hands from now, for this hand again
+    E* const Wout = a.Wb[hand][wsel[hand]];
+    for (u32 i = gtid; i < nout; i += GT) st32(&Wout[i], bind_at(i));
+    for (u32 base = my_off; base < my_end; base += G256_THREADS) {
+      const u32 o = base + tid;
+      u32 key = 0xffffffffu;
+      E t = e32_zero();
+      if (o < my_end) {
+        const u32 sidx = a.src[o], i = sidx & 0x3fffffffu, kind = sidx >> 30;
+        const E v0 = ld32(&vc[i]);
+        E v;
+        if (kind == 0) v = fp256_add(v0, fp256_mul(fp256_sub(ld32(&vc[i + 1]), v0), r));  // HQuad::bind_h (hquad.h:94-118)
+        else if (kind == 1) v = fp256_sub(v0, fp256_mul(v0, r));
+        else v = fp256_mul(v0, r);
+        st32(&vc_o[o], v);
+        if (more) {
+          const uint2 h = hc_o[o];
+          key = hand ? h.x : h.y;  // the next evaluation is for the other hand
+          t = fp256_mul(v, bind_at(hand ? h.y : h.x));
+        }
+      }
+      if (more) run_fold_commit256(key, t, QWn);
+    }
+    W[hand] = Wout;
+    nW[hand] = nout;
+    wsel[hand] ^= 1;
+    {
+      nh = new_nh;
+      uint2* th = const_cast<uint2*>(hc);
+      E* tv = const_cast<E*>(vc);
+      hc = hc_o;
+      vc = vc_o;
+      hc_o = th;
+      vc_o = tv;
+      u64* tq = QW;
+      QW = QWn;
+      QWn = tq;
+    }
+  }
+  if (g == 0 && tid == 0) {  // end of the layer: W[R,C], W[L,C] and HQUAD->scalar() (the last binds of this workgroup: G == 1 by now)
+    __threadfence();
+    const E w0 = nW[0] ? ld32(&W[0][0]) : e32_zero(), w1 = nW[1] ? ld32(&W[1][0]) : e32_zero(), sc = nh ? ld32(&vc[0]) : e32_zero();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a.post[k] = w0.l[k];
+      a.post[4 + k] = w1.l[k];
+      a.post[12 + k] = sc.l[k];
+    }
+    a.post[8] = nh;
+    a.post[9] = 0;
+    __threadfence_system();
+    __hip_atomic_store((u64*)&a.post[16], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---- Ligero row combinations (ligero.hip / sumcheck.hip, over 32-byte elements)
 // y[j] += sum_i u[i] T[i][j]: 64 columns x 4 row slices per workgroup
 __global__ __launch_bounds__(256) void rows_axpy256_kernel(u32 nrows, size_t n, E* __restrict__ y, const E* __restrict__ u, const E* __restrict__ T, size_t ld) {
@@ -454,7 +859,8 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   // scratch: eq | limb accumulators (bind_g runs, then the QW of every round-hand; self-cleaning) | hc[2] | vc[2] |
   // 4 half hand buffers | the round's two sums as limbs
   const size_t acc_n = std::max(nh0, nw);
-  const size_t bytes = q->nv * 32 + acc_n * 64 + 2 * nh0 * 8 + 2 * nh0 * 32 + 4 * half * 32 + 256 + 1024;
+  const size_t grid_bytes = acc_n * 64 + sizeof(Grid256Sync) + G256_WGS * 4 + nh0 * 4 + 256;  // second accumulator array, barrier state, counts, src
+  const size_t bytes = q->nv * 32 + acc_n * 64 + 2 * nh0 * 8 + 2 * nh0 * 32 + 4 * half * 32 + 256 + 1024 + grid_bytes;
   void* sc = nullptr;
   LF_TRY(lf_scratch(c, bytes, &sc));
   uint8_t* b = (uint8_t*)sc;
@@ -466,7 +872,13 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   E* wb[2][2] = {{(E*)b, (E*)b + half}, {(E*)b + 2 * half, (E*)b + 3 * half}};  b += 4 * half * 32;
   u64* d_sums = (u64*)b;
   u32* d_done = (u32*)(d_sums + 16);
+  b += 256;
+  u64* acc2 = (u64*)b;                 b += acc_n * 64;
+  Grid256Sync* gsync = (Grid256Sync*)b; b += sizeof(Grid256Sync);
+  u32* g_counts = (u32*)b;             b += G256_WGS * 4;
+  u32* g_src = (u32*)b;
   volatile u64* post = c->poll_h + 256;  // coherent pinned words a running kernel writes and the host polls (ctx.h)
+  volatile u64* cmd = c->poll_h + 320;   // ... and the host's answers (the challenge as tagged words)
   // Quad::bind_g
   LF_TRY(raw_eq2_256(c, F, logv, q->nv, G0, G1, alpha, d_eq));
   LF_HIP(c, hipMemsetAsync(acc, 0, acc_n * 64, c->stream));
@@ -484,8 +896,103 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   if (q->bind_shape.size() < 2 * logw) q->bind_shape.resize(2 * logw, lfgpu_quad::BindShape{nullptr, 0, 0});
   u64 h_sums[16];
   E* h_out = (E*)c->mailbox_h;
+  auto wait_post = [&](u64 seq) -> int {  // bounded: a kernel that is over without posting is an error
+    u64 spins = 0;
+    while (__atomic_load_n((const u64*)&post[16], __ATOMIC_ACQUIRE) != seq) {
+      if ((++spins & 0xfff) == 0) {
+        const hipError_t qe = hipStreamQuery(c->stream);
+        if (qe == hipSuccess) {
+          if (__atomic_load_n((const u64*)&post[16], __ATOMIC_ACQUIRE) == seq) break;
+          return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: kernel finished without posting");
+        }
+        if (qe != hipErrorNotReady) return lf_fail(c, LFGPU_ERR_HIP, "sumcheck_layer256: %s", hipGetErrorString(qe));
+      }
+    }
+    return LFGPU_OK;
+  };
+  // LFGPU_P256_GRID [1]: once the HQUAD and both hand arrays have <= G256_MAX entries the rest of the layer is ONE launch of
+  // co-resident workgroups that take every challenge through pinned memory (grid256_layer_kernel); 0 = three launches per
+  // round-hand throughout (A/B, and the fallback where a running kernel cannot see host writes)
+  static const int grid_env = getenv("LFGPU_P256_GRID") ? atoi(getenv("LFGPU_P256_GRID")) : 1;
+  const bool grid_ok = grid_env && lf_sc_resident_ok(c);
   for (size_t rnd = 0; rnd < logw; ++rnd)
     for (int hand = 0; hand < 2; ++hand) {
+      // hand-off point: above it a round-hand is three launches spread over the whole chip.  Measured on the mdoc signature
+      // circuit (sumcheck ms): no grid 19.8; grid from 1024 / 2048 / 8192 / 32768 / 131072 entries on: 19.1 / 19.1 / 19.8 / 20.0 /
+      // 20.1 -- the round-hand is bound by its chain of ~8 dependent 256-bit Montgomery products (~1.7 us each on one wave), not
+      // by launches or barriers, so the resident grid only saves the launch gaps of the small rounds
+      static const size_t grid_max = [] {
+        const char* e = getenv("LFGPU_P256_GRID_MAX");
+        return std::min<size_t>(e ? (size_t)atol(e) : (size_t)2048, G256_MAX);
+      }();
+      if (grid_ok && nh <= grid_max && nW[0] <= grid_max && nW[1] <= grid_max) {
+        static const u32 per_wg = getenv("LFGPU_P256_PER_WG") ? (u32)std::max(64, atoi(getenv("LFGPU_P256_PER_WG"))) : 512u;
+        const size_t big = std::max(nh, std::max(nW[0], nW[1]));
+        u32 G = (u32)((big + per_wg - 1) / per_wg);
+        G = std::min<u32>(std::max<u32>(G, 1), G256_WGS);
+        if ((int)G > c->num_cu) G = (u32)c->num_cu;
+        int pc = 0;  // all G workgroups must be resident together (they synchronise through device memory)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, (const void*)grid256_layer_kernel, G256_THREADS, 0) != hipSuccess) pc = 0;
+        if (pc < 1) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "sumcheck_layer256: the grid kernel does not fit a CU");
+        Grid256 a{};
+        a.hcA = hc[cur];
+        a.vcA = vc[cur];
+        a.hcB = hc[1 - cur];
+        a.vcB = vc[1 - cur];
+        a.nh = (u32)nh;
+        for (int h = 0; h < 2; ++h) {
+          a.W[h] = WH[h];
+          a.nW[h] = (u32)nW[h];
+          a.Wb[h][0] = wb[h][0];
+          a.Wb[h][1] = wb[h][1];
+        }
+        a.QW = acc;
+        a.QW2 = acc2;
+        a.rh0 = (u32)(2 * rnd + hand);
+        a.rh1 = (u32)(2 * logw);
+        a.seq0 = c->poll_seq + 1;
+        c->poll_seq += (a.rh1 - a.rh0) + 1;
+        a.timeout_ticks = 5000ull * c->wall_khz;
+        a.post = post;
+        a.cmd = cmd;
+        a.gs = gsync;
+        a.counts = g_counts;
+        a.src = g_src;
+        a.per_wg = per_wg;
+        a.rsq = F.rsq;
+        LF_HIP(c, hipMemsetAsync(gsync, 0, sizeof(Grid256Sync), c->stream));
+        hipLaunchKernelGGL(grid256_layer_kernel, dim3(G), dim3(G256_THREADS), 0, c->stream, a);
+        LF_HIP(c, hipGetLastError());
+        u64 seq = a.seq0;
+        size_t r2 = rnd;
+        for (u32 rh = a.rh0; rh < a.rh1; ++rh, ++seq) {
+          const int hd = (int)(rh & 1);
+          r2 = rh >> 1;
+          LF_TRY(wait_post(seq));
+          if (post[9] != 0) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: the grid kernel timed out waiting for a challenge");
+          E coef[3], ev[3], r;
+          for (int k = 0; k < 4; ++k) {
+            coef[0].l[k] = post[k];
+            coef[2].l[k] = post[4 + k];
+          }
+          coef[1] = F.sub(F.sub(F.sub(sum, coef[0]), coef[0]), coef[2]);
+          for (int k = 0; k < 3; ++k) ev[k] = F.eval_monomial(coef, F.pts[k]);
+          round(user, (size_t)hd, r2, ev, &r);
+          g_out[hd * logw + r2] = r;
+          sum = F.eval_lagrange(ev, r);
+          const u64 tag = (seq & 0xffffffffull) << 32;  // eight tagged words: valid as soon as all eight carry the tag
+          for (int k = 0; k < 8; ++k) __atomic_store_n((u64*)&cmd[k], tag | ((r.l[k >> 1] >> (32 * (k & 1))) & 0xffffffffull), __ATOMIC_RELAXED);
+          __atomic_thread_fence(__ATOMIC_RELEASE);
+        }
+        LF_TRY(wait_post(seq));  // the layer's last post: W[0][0], W[1][0], the HQUAD scalar
+        if (post[9] != 0 || post[8] != 1) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: HQUAD did not fold to one entry (%llu)", (unsigned long long)post[8]);
+        for (int k = 0; k < 4; ++k) {
+          wc_out[0].l[k] = post[k];
+          wc_out[1].l[k] = post[4 + k];
+          if (bound_quad) bound_quad->l[k] = post[12 + k];
+        }
+        return LFGPU_OK;
+      }
       // QW scatter (prover_layers.h:239-243) + evaluations: two launches, one read-back
       if (nh) hipLaunchKernelGGL(qw_scatter256_kernel, dim3(nblk(nh)), dim3(Z_THREADS), 0, c->stream, nh, (const uint2*)hc[cur], (const E*)vc[cur], hand,
                                  WH[1 - hand], acc);
@@ -493,20 +1000,8 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
       hipLaunchKernelGGL(partials256_kernel, dim3(std::min<u32>(nblk(nW[hand] / 2), 256)), dim3(Z_THREADS), 0, c->stream, nW[hand], acc, F.rsq, WH[hand], d_sums,
                          d_done, post, seq);
       LF_HIP(c, hipGetLastError());
-      {  // wait for the post (bounded: if the kernel is over without posting, something is wrong)
-        u64 spins = 0;
-        while (__atomic_load_n((const u64*)&post[16], __ATOMIC_ACQUIRE) != seq) {
-          if ((++spins & 0xfff) == 0) {
-            const hipError_t qe = hipStreamQuery(c->stream);
-            if (qe == hipSuccess) {
-              if (__atomic_load_n((const u64*)&post[16], __ATOMIC_ACQUIRE) == seq) break;
-              return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: kernel finished without posting");
-            }
-            if (qe != hipErrorNotReady) return lf_fail(c, LFGPU_ERR_HIP, "sumcheck_layer256: %s", hipGetErrorString(qe));
-          }
-        }
-        for (int k = 0; k < 16; ++k) h_sums[k] = post[k];
-      }
+      LF_TRY(wait_post(seq));
+      for (int k = 0; k < 16; ++k) h_sums[k] = post[k];
       // coef[0] = a0, coef[2] = a2, coef[1] from the running sum (prover_layers.h:390-396, logc = 0)
       E coef[3], ev[3], r;
       coef[0] = fp256_reduce_limbs(h_sums, F.rsq);
