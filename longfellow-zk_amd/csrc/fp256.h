@@ -186,9 +186,28 @@ __device__ inline void st32(elt32_t* p, const elt32_t& v) {
 LF_HD bool e32_is_zero(const elt32_t& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
 
 // sum_k acc[k] 2^(32k) mod p for eight 64-bit limb accumulators (sums of 32-bit limbs of canonical residues; images add, so
-// the result of summing Montgomery images is the image of the sum).  S = lo + 2^256 hi with hi < 2^40:
-// S = (lo mod p) + hi * R, and hi * R mod p is the Montgomery image of hi = fp256_mul(hi, R^2).
+// the result of summing Montgomery images is the image of the sum).  S = lo + 2^256 hi with hi < 2^40, and
+// 2^256 = D = 2^224 - 2^192 - 2^96 + 1 (mod p): two folds of the overflow word with shifts and signed carries
+// (lo + hi D < 2^265, then < 2^256 + 2^233 < 2p) and one conditional subtraction -- no product.  (`rsq` is unused; the
+// first version computed hi R as the Montgomery image of hi with a full product, and the sumcheck rounds are chains of
+// dependent 256-bit products.)
+namespace fp256_detail {
+LF_HD void fold_overflow(u32 (&t)[8], u32 h0, u32 h1, u32& top) {  // t + (h1 2^32 + h0) D -> t, top (9th limb)
+  long long s;
+  s = (long long)t[0] + h0;               t[0] = (u32)s; s >>= 32;
+  s += (long long)t[1] + h1;              t[1] = (u32)s; s >>= 32;
+  s += (long long)t[2];                   t[2] = (u32)s; s >>= 32;
+  s += (long long)t[3] - h0;              t[3] = (u32)s; s >>= 32;
+  s += (long long)t[4] - h1;              t[4] = (u32)s; s >>= 32;
+  s += (long long)t[5];                   t[5] = (u32)s; s >>= 32;
+  s += (long long)t[6] - h0;              t[6] = (u32)s; s >>= 32;
+  s += (long long)t[7] - h1 + h0;         t[7] = (u32)s; s >>= 32;
+  s += (long long)h1;
+  top = (u32)s;  // the sum is non-negative and below 2^265
+}
+}  // namespace fp256_detail
 LF_HD elt32_t fp256_reduce_limbs(const u64 acc[8], const elt32_t& rsq) {
+  (void)rsq;
   u32 w[8];
   u64 c = 0;
 #pragma unroll
@@ -198,10 +217,12 @@ LF_HD elt32_t fp256_reduce_limbs(const u64 acc[8], const elt32_t& rsq) {
     w[k] = (u32)c;
     c >>= 32;
   }
-  c += acc[7] >> 32;  // the part above 2^256
-  fp256_detail::cond_sub_p(w, 0);  // lo < 2^256 < 2p
-  const elt32_t lo = fp256_detail::from_w(w);
-  return fp256_add(lo, fp256_mul(elt32_t{{c, 0, 0, 0}}, rsq));
+  c += acc[7] >> 32;  // the part above 2^256: < 2^40
+  u32 top;
+  fp256_detail::fold_overflow(w, (u32)c, (u32)(c >> 32), top);  // < 2^265: top < 2^9
+  fp256_detail::fold_overflow(w, top, 0u, top);                  // < 2^256 + 2^233 < 2p: top is 0 or 1
+  fp256_detail::cond_sub_p(w, top);
+  return fp256_detail::from_w(w);
 }
 
 // ---- host-side helpers (FpGeneric: to_montgomery, of_scalar, invertf, of_bytes_field, sample)

@@ -184,6 +184,13 @@ def test_p256_limb_accumulators_and_host_helpers():
     # sums of real residues: n copies of limbs of (p - 1)
     w = [((p - 1) >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
     cases += [[n * x for x in w] for n in (1, 2, 1000, 2**32 - 1)]
+    # integers around the fold boundaries (S = lo + 2^256 hi: hi up to 2^40 - 1, results next to 0, p and 2p), written as limbs
+    D = (1 << 224) - (1 << 192) - (1 << 96) + 1
+    for S in (p - 1, p, p + 1, 2 * p - 1, 2 * p, (1 << 256) - 1, 1 << 256, (1 << 256) + D, ((1 << 32) - 1) << 256, (((1 << 32) - 1) << 256) + (1 << 256) - 1,
+              (511 << 256) + p - 1, (1 << 264) - 1, 3 * p + 7, (1 << 256) + (1 << 233) - 1, (1 << 288) - 1):  # S < 2^288: what eight 64-bit limbs can hold
+        limbs = [(S >> (32 * k)) & 0xFFFFFFFF for k in range(7)] + [S >> 224]  # the top accumulator takes everything above 2^224
+        assert limbs[7] < (1 << 64)
+        cases.append(limbs)
     for acc in cases:
         a = np.array(acc, dtype=np.uint64)
         out = np.zeros(4, dtype=np.uint64)
