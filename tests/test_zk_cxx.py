@@ -599,3 +599,40 @@ def test_zk_small_p256_circuit_matches_reference():
     ts.close()
     zk.close()
     circ.close()
+
+
+@pytest.mark.gpu
+def test_zk_verify_with_commitment_received_separately():
+    """ZkVerifier::recv_commitment and ::verify are two calls in the reference (lib/zk/zk_verifier.h:68-94) and the mdoc verifier
+    does other transcript work between them (mdoc_zk.cc:676-681): lfgpu_zk_verify_committed is verify for a transcript that has
+    already received the commitment.  Same verdict as the combined call when the caller wrote the root (write_bytes of the first
+    32 proof bytes, as LigeroTranscript::write_commitment does); rejection when it did not, or wrote a different one."""
+    import gpu_util as G
+    import ligero_fixture as lf
+    raw, W, info = _load(1)
+    gpu = G.gpu()
+    circ = G.pkg.Circuit(gpu, raw)
+    zk = G.pkg.ZkProver(gpu, circ, 7, 132)
+    ts = G.pkg.FsTranscript(b"test")
+    zk.commit(W, lf.LcgRng(100).bytes, ts)
+    assert zk.prove(W, ts)
+    wire = zk.wire()
+    ts.close()
+    zk.close()
+    assert hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"]
+    pub = W[:circ.info.npub_in]
+
+    def run(prefix, committed):
+        tv = G.pkg.FsTranscript(b"test")
+        try:
+            if prefix is not None:
+                tv.write_bytes(prefix)
+            return G.pkg.zk_verify(gpu, circ, wire, pub, tv, committed=committed)
+        finally:
+            tv.close()
+    assert run(None, False) == (True, "ok")
+    assert run(wire[:32], True) == (True, "ok")
+    assert run(None, True)[0] is False
+    assert run(bytes(32), True)[0] is False
+    assert run(wire[:32], False)[0] is False  # the root twice
+    circ.close()
