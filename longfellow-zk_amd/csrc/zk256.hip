@@ -919,8 +919,11 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
     for (int hand = 0; hand < 2; ++hand) {
       // hand-off point: above it a round-hand is three launches spread over the whole chip.  Measured on the mdoc signature
       // circuit (sumcheck ms): no grid 19.8; grid from 1024 / 2048 / 8192 / 32768 / 131072 entries on: 19.1 / 19.1 / 19.8 / 20.0 /
-      // 20.1 -- the round-hand is bound by its chain of ~8 dependent 256-bit Montgomery products (~1.7 us each on one wave), not
-      // by launches or barriers, so the resident grid only saves the launch gaps of the small rounds
+      // 20.1.  With LFGPU_VERBOSE the host's turn shows as 1.2 us per round-hand and the wait for the device as 23 us for a
+      // layer that starts at 409 entries (one workgroup) up to 41 us from 69150: ~5000 instructions on the critical path of a
+      // round-hand (0.82 us per product, tools/ubench_p256; the 8-wave sum with its serial tail; the recomputed bound hand
+      // entry) at the one-instruction-per-5.6-cycles issue rate of a lone wave -- not launches, barriers or memory round trips
+      // (an LDS-resident tail for <= 512 entries was built and measured: no change)
       static const size_t grid_max = [] {
         const char* e = getenv("LFGPU_P256_GRID_MAX");
         return std::min<size_t>(e ? (size_t)atol(e) : (size_t)2048, G256_MAX);
@@ -965,10 +968,17 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
         LF_HIP(c, hipGetLastError());
         u64 seq = a.seq0;
         size_t r2 = rnd;
+        static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
+        double t_wait = 0, t_host = 0, tp0 = verbose ? now_ms() : 0;
         for (u32 rh = a.rh0; rh < a.rh1; ++rh, ++seq) {
           const int hd = (int)(rh & 1);
           r2 = rh >> 1;
           LF_TRY(wait_post(seq));
+          if (verbose) {
+            const double t = now_ms();
+            t_wait += t - tp0;
+            tp0 = t;
+          }
           if (post[9] != 0) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: the grid kernel timed out waiting for a challenge");
           E coef[3], ev[3], r;
           for (int k = 0; k < 4; ++k) {
@@ -983,7 +993,15 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
           const u64 tag = (seq & 0xffffffffull) << 32;  // eight tagged words: valid as soon as all eight carry the tag
           for (int k = 0; k < 8; ++k) __atomic_store_n((u64*)&cmd[k], tag | ((r.l[k >> 1] >> (32 * (k & 1))) & 0xffffffffull), __ATOMIC_RELAXED);
           __atomic_thread_fence(__ATOMIC_RELEASE);
+          if (verbose) {
+            const double t = now_ms();
+            t_host += t - tp0;
+            tp0 = t;
+          }
         }
+        if (verbose)
+          fprintf(stderr, "lfgpu sumcheck_layer256 grid: %u round-hands from %zu entries: waiting for the device %.1f us, host's turn %.1f us per round-hand\n",
+                  a.rh1 - a.rh0, big, 1e3 * t_wait / (a.rh1 - a.rh0), 1e3 * t_host / (a.rh1 - a.rh0));
         LF_TRY(wait_post(seq));  // the layer's last post: W[0][0], W[1][0], the HQUAD scalar
         if (post[9] != 0 || post[8] != 1) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: HQUAD did not fold to one entry (%llu)", (unsigned long long)post[8]);
         for (int k = 0; k < 4; ++k) {
