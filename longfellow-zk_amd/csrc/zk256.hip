@@ -447,15 +447,30 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
         return fp256_reduce_limbs(q, rsq);
       };
       E a0 = e32_zero(), a2 = e32_zero();
-      for (u32 i = gtid; i < nodd; i += GT) {
-        const E q0 = qw_at(2 * i), q1 = qw_at(2 * i + 1), w0 = ld32(&Wh[2 * i]), w1 = ld32(&Wh[2 * i + 1]);
-        a0 = fp256_add(a0, fp256_mul(q0, w0));
-        a2 = fp256_add(a2, fp256_mul(fp256_sub(q1, q0), fp256_sub(w1, w0)));
-      }
-      if (gtid == 0 && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388)
-        const E t = fp256_mul(qw_at(2 * nodd), ld32(&Wh[2 * nodd]));
-        a0 = fp256_add(a0, t);
-        a2 = fp256_add(a2, t);
+      if (G == 1) {  // one workgroup left: the two products of a pair on different waves (even waves sum a0, odd waves a2)
+        const u32 half = G256_THREADS / 2, ht = (wave >> 1) * 64 + lane;
+        const bool second = (wave & 1) != 0;
+        for (u32 i = ht; i < nodd; i += half) {
+          const E q0 = qw_at(2 * i), w0 = ld32(&Wh[2 * i]);
+          if (!second) a0 = fp256_add(a0, fp256_mul(q0, w0));
+          else a2 = fp256_add(a2, fp256_mul(fp256_sub(qw_at(2 * i + 1), q0), fp256_sub(ld32(&Wh[2 * i + 1]), w0)));
+        }
+        if (ht == 0 && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388): in both sums
+          const E t = fp256_mul(qw_at(2 * nodd), ld32(&Wh[2 * nodd]));
+          if (!second) a0 = fp256_add(a0, t);
+          else a2 = fp256_add(a2, t);
+        }
+      } else {
+        for (u32 i = gtid; i < nodd; i += GT) {
+          const E q0 = qw_at(2 * i), q1 = qw_at(2 * i + 1), w0 = ld32(&Wh[2 * i]), w1 = ld32(&Wh[2 * i + 1]);
+          a0 = fp256_add(a0, fp256_mul(q0, w0));
+          a2 = fp256_add(a2, fp256_mul(fp256_sub(q1, q0), fp256_sub(w1, w0)));
+        }
+        if (gtid == 0 && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388)
+          const E t = fp256_mul(qw_at(2 * nodd), ld32(&Wh[2 * nodd]));
+          a0 = fp256_add(a0, t);
+          a2 = fp256_add(a2, t);
+        }
       }
       auto wg_sum = [&](E& x0, E& x2) {  // wave shuffles, then the wave sums through LDS; result in thread 0
         for (int off = 32; off > 0; off >>= 1) {
@@ -473,12 +488,19 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
           s_red[1][wave] = x2;
         }
         __syncthreads();
-        if (tid == 0) {
-          x0 = s_red[0][0];
-          x2 = s_red[1][0];
-          for (u32 w = 1; w < G256_THREADS / 64; ++w) {
-            x0 = fp256_add(x0, s_red[0][w]);
-            x2 = fp256_add(x2, s_red[1][w]);
+        if (wave == 0) {  // the 8 wave sums of a0 on lanes 0-7, of a2 on lanes 8-15: three shuffle steps instead of 14 additions in a row
+          E v = lane < 16 ? s_red[lane >> 3][lane & 7] : e32_zero();
+#pragma unroll
+          for (int off = 4; off > 0; off >>= 1) {
+            E o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.l[k] = __shfl_down(v.l[k], off, 64);
+            v = fp256_add(v, o);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            x0.l[k] = __shfl(v.l[k], 0, 64);
+            x2.l[k] = __shfl(v.l[k], 8, 64);
           }
         }
         __syncthreads();
@@ -645,6 +667,39 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
     const bool more = rh + 1 < a.rh1;
     for (u32 i = gtid; i < 8 * nout; i += GT) QW[i] = 0;  // next written two round-hands from now, for this hand again
     E* const Wout = a.Wb[hand][wsel[hand]];
+    auto bind_value = [&](u32 o) -> E {  // HQuad::bind_h value of output o (hquad.h:94-118)
+      const u32 sidx = a.src[o], i = sidx & 0x3fffffffu, kind = sidx >> 30;
+      const E v0 = ld32(&vc[i]);
+      if (kind == 0) return fp256_add(v0, fp256_mul(fp256_sub(ld32(&vc[i + 1]), v0), r));
+      if (kind == 1) return fp256_sub(v0, fp256_mul(v0, r));
+      return fp256_mul(v0, r);
+    };
+    if (G == 1) {
+      // One workgroup left: what counts is the longest chain of instructions a single wave issues, so the independent products go
+      // to different waves -- the even waves bind the HQUAD values while the odd waves bind the hand array -- and, a workgroup
+      // barrier being cheap, the next evaluation's products take the bound hand entries from memory instead of recomputing them
+      const u32 half = G256_THREADS / 2, ht = (wave >> 1) * 64 + lane;
+      if ((wave & 1) == 0) {
+        for (u32 o = ht; o < my_end; o += half) st32(&vc_o[o], bind_value(o));
+      } else {
+        for (u32 i = ht; i < nout; i += half) st32(&Wout[i], bind_at(i));
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (more) {
+        for (u32 base = 0; base < my_end; base += G256_THREADS) {
+          const u32 o = base + tid;
+          u32 key = 0xffffffffu;
+          E t = e32_zero();
+          if (o < my_end) {
+            const uint2 h = hc_o[o];
+            key = hand ? h.x : h.y;  // the next evaluation is for the other hand
+            t = fp256_mul(ld32(&vc_o[o]), ld32(&Wout[hand ? h.y : h.x]));
+          }
+          run_fold_commit256(key, t, QWn);
+        }
+      }
+    } else {
     for (u32 i = gtid; i < nout; i += GT) st32(&Wout[i], bind_at(i));
     for (u32 base = my_off; base < my_end; base += G256_THREADS) {
       const u32 o = base + tid;
@@ -665,6 +720,7 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
         }
       }
       if (more) run_fold_commit256(key, t, QWn);
+    }
     }
     W[hand] = Wout;
     nW[hand] = nout;
