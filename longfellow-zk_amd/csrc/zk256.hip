@@ -42,7 +42,7 @@ __device__ __forceinline__ void limbs_atomic_add(u64* a, const E& v) {
 __device__ __forceinline__ void run_fold_commit256(u32 key, E t, u64* __restrict__ acc) {
   const u32 lane = threadIdx.x & 63;
   const u32 pkey = __shfl_up(key, 1, 64);
-  const bool head = lane == 0 || pkey != key;
+  const bool head = lane == 0 || pkey != key || key == 0xffffffffu;  // idle lanes never form a run: a partly filled wave skips the fold
   const u64 hmask = __ballot(head);
   if (hmask != ~0ull) {  // wave-uniform: some neighbours share a key
     const u32 rid = (u32)__popcll(hmask & ((2ull << lane) - 1));  // monotone, so equal ids = one contiguous run
@@ -472,16 +472,29 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
           a2 = fp256_add(a2, t);
         }
       }
-      auto wg_sum = [&](E& x0, E& x2) {  // wave shuffles, then the wave sums through LDS; result in thread 0
-        for (int off = 32; off > 0; off >>= 1) {
-          E o0, o2;
+      auto wg_sum = [&](E& x0, E& x2, bool split) {  // wave shuffles, then the wave sums through LDS; result in thread 0
+        if (split) {  // even waves carry only a0, odd waves only a2: one value to fold per wave
+          const bool second = (wave & 1) != 0;
+          E v = second ? x2 : x0;
+          for (int off = 32; off > 0; off >>= 1) {
+            E o;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            o0.l[k] = __shfl_down(x0.l[k], off, 64);
-            o2.l[k] = __shfl_down(x2.l[k], off, 64);
+            for (int k = 0; k < 4; ++k) o.l[k] = __shfl_down(v.l[k], off, 64);
+            v = fp256_add(v, o);
           }
-          x0 = fp256_add(x0, o0);
-          x2 = fp256_add(x2, o2);
+          x0 = second ? e32_zero() : v;
+          x2 = second ? v : e32_zero();
+        } else {
+          for (int off = 32; off > 0; off >>= 1) {
+            E o0, o2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              o0.l[k] = __shfl_down(x0.l[k], off, 64);
+              o2.l[k] = __shfl_down(x2.l[k], off, 64);
+            }
+            x0 = fp256_add(x0, o0);
+            x2 = fp256_add(x2, o2);
+          }
         }
         if (lane == 0) {
           s_red[0][wave] = x0;
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
         }
         __syncthreads();
       };
-      wg_sum(a0, a2);
+      wg_sum(a0, a2, G == 1);
       bool poster = tid == 0;
       if (G > 1) {  // slots + arrival ticket: the last workgroup to arrive folds all slots
         if (tid == 0) {
@@ -530,7 +543,7 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
               a2.l[k] = __hip_atomic_load(&sl[4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
-          wg_sum(a0, a2);
+          wg_sum(a0, a2, false);
           poster = tid == 0;
         }
       }
