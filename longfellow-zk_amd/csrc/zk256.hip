@@ -107,6 +107,33 @@ __global__ __launch_bounds__(Z_THREADS) void raw_eq2_256_kernel(u32 logn, u32 n,
   st32(&eq[i], fp256_add(e0, e1));
 }
 
+// The same vector with 2 products per entry instead of 2 logn: EQ(G, i) = LO[i mod 2^lb] * HI[i >> lb].  eq_tables256_kernel
+// builds the four factor tables LO0 | HI0 | LO1 | HI1 (alpha folded into HI1), one thread per entry (<= 2^ceil(logn / 2)
+// entries each), raw_eq2_split256_kernel combines them.  Exact field arithmetic: the association does not matter.
+__global__ __launch_bounds__(Z_THREADS) void eq_tables256_kernel(u32 logn, u32 lb, const E* __restrict__ G, E alpha, E one, E* __restrict__ tab) {
+  const u32 hb = logn - lb, nlo = 1u << lb, nhi = 1u << hb;
+  const u32 t = blockIdx.x * Z_THREADS + threadIdx.x;
+  if (t >= 2 * (nlo + nhi)) return;
+  const u32 which = t < nlo ? 0 : t < nlo + nhi ? 1 : t < 2 * nlo + nhi ? 2 : 3;  // LO0, HI0, LO1, HI1
+  const u32 j = which == 0 ? t : which == 1 ? t - nlo : which == 2 ? t - nlo - nhi : t - 2 * nlo - nhi;
+  const u32 bits = (which & 1) ? hb : lb, shift = (which & 1) ? lb : 0, g = which >> 1;  // g: 0 -> G0, 1 -> G1
+  E e = which == 3 ? alpha : one;
+  for (u32 l = 0; l < bits; ++l) {
+    const u32 bit = (j >> l) & 1;
+    e = fp256_mul(e, ld32(&G[(bit ? g * logn : (2 + g) * logn) + shift + l]));
+  }
+  st32(&tab[t], e);
+}
+__global__ __launch_bounds__(Z_THREADS) void raw_eq2_split256_kernel(u32 logn, u32 lb, u32 n, const E* __restrict__ tab, E* __restrict__ eq) {
+  const u32 i = blockIdx.x * Z_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const u32 nlo = 1u << lb, nhi = 1u << (logn - lb);
+  const u32 lo = i & (nlo - 1), hi = i >> lb;
+  const E e0 = fp256_mul(ld32(&tab[lo]), ld32(&tab[nlo + hi]));
+  const E e1 = fp256_mul(ld32(&tab[nlo + nhi + lo]), ld32(&tab[2 * nlo + nhi + hi]));
+  st32(&eq[i], fp256_add(e0, e1));
+}
+
 // Quad::bind_g: every term computes prep_v(v, beta) * eq[g]; the terms of a run (equal hand pair, contiguous in canonical
 // order) add into the run's limb accumulators
 __device__ __forceinline__ bool is_head256(const corner4* t, size_t i) { return i == 0 || t[i].h0 != t[i - 1].h0 || t[i].h1 != t[i - 1].h1; }
@@ -901,15 +928,23 @@ int raw_eq2_256(lfgpu_ctx* c, const F256& F, size_t logn, size_t n, const E* G0,
     Gt[2 * logn + l] = F.sub(F.one, G0[l]);
     Gt[3 * logn + l] = F.sub(F.one, G1[l]);
   }
+  const u32 lb = (u32)(logn / 2), hb = (u32)logn - lb;
+  const size_t ntab = 2 * (((size_t)1 << lb) + ((size_t)1 << hb));
   void* d_G = nullptr;
-  LF_TRY(lf_scratch2(c, Gt.size() * 32 + 64, &d_G));
+  LF_TRY(lf_scratch2(c, (Gt.size() + ntab) * 32 + 64, &d_G));
+  E* d_tab = (E*)d_G + Gt.size();
   if (Gt.size() * 32 <= LF_STAGE_SLOT) {  // 4 logn + 1 <= 128 elements: through the pinned ring, no synchronisation
     LF_TRY(lf_stage_upload(c, d_G, Gt.data(), Gt.size() * 32));
   } else {
     LF_HIP(c, hipMemcpyAsync(d_G, Gt.data(), Gt.size() * 32, hipMemcpyHostToDevice, c->stream));
     LF_HIP(c, hipStreamSynchronize(c->stream));  // Gt is a local
   }
-  hipLaunchKernelGGL(raw_eq2_256_kernel, dim3(nblk(n)), dim3(Z_THREADS), 0, c->stream, (u32)logn, (u32)n, (const E*)d_G, alpha, F.one, d_eq);
+  if (logn < 6) {  // tiny: the direct product per entry
+    hipLaunchKernelGGL(raw_eq2_256_kernel, dim3(nblk(n)), dim3(Z_THREADS), 0, c->stream, (u32)logn, (u32)n, (const E*)d_G, alpha, F.one, d_eq);
+  } else {
+    hipLaunchKernelGGL(eq_tables256_kernel, dim3(nblk(ntab)), dim3(Z_THREADS), 0, c->stream, (u32)logn, lb, (const E*)d_G, alpha, F.one, d_tab);
+    hipLaunchKernelGGL(raw_eq2_split256_kernel, dim3(nblk(n)), dim3(Z_THREADS), 0, c->stream, (u32)logn, lb, (u32)n, (const E*)d_tab, d_eq);
+  }
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
 }
