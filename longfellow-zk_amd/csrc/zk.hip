@@ -338,6 +338,8 @@ struct lfgpu_zk_prover {
   std::vector<uint8_t> nonces, path;
   size_t npath = 0;
   bool have_proof = false;
+  mutable std::vector<uint8_t> wire;  // ZkProof::write bytes of the held proof (lfgpu_zk_proof_write fills it once)
+  mutable bool wire_valid = false;
   // subfield solver for the wire format (GF2_128::solve, lib/gf2k/gf2_128.h:496-508): echelon rows of beta
   struct Row {
     elt_t v;
@@ -685,6 +687,7 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
     zk->lp = nullptr;
   }
   zk->have_proof = false;
+  zk->wire_valid = false;
   LF_TRY(lfgpu_ligero_commit(c, field, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), rng, rng_user, zk->root, &zk->lp));
   ts->write_bytes(ts->user, zk->root, 32);  // LigeroTranscript::write_commitment
   if (root_out) memcpy(root_out, zk->root, 32);
@@ -706,6 +709,7 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
   const Ts ts{tso, tso->user, I.field};
   *ok = 0;
   zk->have_proof = false;
+  zk->wire_valid = false;
   LF_HIP(c, hipSetDevice(c->device));
 
   // eval_circuit (prover_layers.h:52-104): layer inputs stay resident for the sumcheck
@@ -859,7 +863,16 @@ extern "C" int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, siz
   if (!zk || !nbytes) return LFGPU_ERR_ARG;
   if (zk->z256) return zk256_proof_write(zk->z256, buf, cap, nbytes);
   if (!zk->have_proof) return lf_fail(zk->c, LFGPU_ERR_ARG, "zk_proof_write: no proof");
-  std::vector<uint8_t> o;
+  std::vector<uint8_t>& o = zk->wire;  // serialised once per proof: the size query and the copy share it
+  if (zk->wire_valid) {
+    *nbytes = o.size();
+    if (buf) {
+      if (cap < o.size()) return lf_fail(zk->c, LFGPU_ERR_ARG, "zk_proof_write: buffer too small (%zu < %zu)", cap, o.size());
+      memcpy(buf, o.data(), o.size());
+    }
+    return LFGPU_OK;
+  }
+  o.clear();
   const int field = zk->C->info.field;
   auto pute = [&](elt_t e) {
     uint8_t b[16];
@@ -894,18 +907,33 @@ extern "C" int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, siz
   // opened columns: alternating runs of full-field / subfield elements, run-length prefixed (:156-178)
   constexpr size_t kMaxRunLen = (size_t)1 << 25;
   const size_t nreq_elts = zk->req.size();
+  // GF2_128: solve every opened element against the subfield basis ONCE (residue == 0 iff it lies in the subfield; the
+  // coordinates are its 2-byte image)
+  std::vector<u32> sub_coord;
+  std::vector<uint8_t> sub_flag;
+  if (field == LFGPU_FIELD_GF2_128) {
+    sub_coord.resize(nreq_elts);
+    sub_flag.resize(nreq_elts);
+    for (size_t i = 0; i < nreq_elts; ++i) {
+      const auto r = solve_subfield(zk, zk->req[i]);
+      sub_flag[i] = (r.first.lo | r.first.hi) == 0;
+      sub_coord[i] = r.second;
+    }
+  }
+  auto is_sub = [&](size_t i) { return field != LFGPU_FIELD_GF2_128 ? true : sub_flag[i] != 0; };
+  o.reserve(o.size() + nreq_elts * 16 + 32 * zk->npath + 64);
   size_t ci = 0;
   bool subfield_run = false;
   while (ci < nreq_elts) {
     size_t runlen = 0;
     while (ci + runlen < nreq_elts && runlen < kMaxRunLen) {
-      if (in_subfield(zk->req[ci + runlen]) != subfield_run) break;
+      if (is_sub(ci + runlen) != subfield_run) break;
       ++runlen;
     }
     putsz(runlen);
     for (size_t i = ci; i < ci + runlen; ++i) {
       if (subfield_run && field == LFGPU_FIELD_GF2_128) {
-        const u32 u = solve_subfield(zk, zk->req[i]).second;  // to_bytes_subfield: 2 bytes LE
+        const u32 u = sub_coord[i];  // to_bytes_subfield: 2 bytes LE
         o.push_back((uint8_t)u);
         o.push_back((uint8_t)(u >> 8));
       } else {  // full-field run, or Fp128 where to_bytes_subfield == to_bytes_field
@@ -917,6 +945,7 @@ extern "C" int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, siz
   }
   putsz(zk->npath);
   o.insert(o.end(), zk->path.begin(), zk->path.begin() + 32 * zk->npath);
+  zk->wire_valid = true;
   *nbytes = o.size();
   if (buf) {
     if (cap < o.size()) return lf_fail(zk->c, LFGPU_ERR_ARG, "zk_proof_write: buffer too small (%zu < %zu)", cap, o.size());

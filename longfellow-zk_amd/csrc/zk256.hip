@@ -1389,6 +1389,8 @@ struct Zk256 {
   std::vector<uint8_t> nonces, path;
   size_t npath = 0;
   bool have_proof = false;
+  mutable std::vector<uint8_t> wire;  // ZkProof::write bytes of the held proof (zk256_proof_write fills it once)
+  mutable bool wire_valid = false;
   std::vector<void*> d_in;  // the layers' inputs (eval_circuit), resident for the sumcheck
   void* d_V = nullptr;
   void* h_V = nullptr;  // pinned: outputs then the assert-zero flag
@@ -1698,6 +1700,7 @@ int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, co
   delete z->lp;
   z->lp = nullptr;
   z->have_proof = false;
+  z->wire_valid = false;
   LF_TRY(lig256_commit(c, z->param, Wv.data(), z->lqc.data(), rng, rng_user, z->root, &z->lp));
   ts->write_bytes(ts->user, z->root, 32);  // LigeroTranscript::write_commitment
   if (root_out) memcpy(root_out, z->root, 32);
@@ -1719,6 +1722,7 @@ int zk256_prove(Zk256* z, const void* h_W, const lfgpu_transcript_ops* tso, int*
   const Ts256 ts{tso, tso->user};
   *ok = 0;
   z->have_proof = false;
+  z->wire_valid = false;
   LF_HIP(c, hipSetDevice(c->device));
 
   // eval_circuit (prover_layers.h:52-104): all layers back to back while the host hashes the Fiat-Shamir preamble
@@ -1851,7 +1855,9 @@ int zk256_prove(Zk256* z, const void* h_W, const lfgpu_transcript_ops* tso, int*
 // "subfield" run after an empty full-field run
 int zk256_proof_write(const Zk256* z, uint8_t* buf, size_t cap, size_t* nbytes) {
   if (!z->have_proof) return lf_fail(z->c, LFGPU_ERR_ARG, "zk_proof_write: no proof");
-  std::vector<uint8_t> o;
+  std::vector<uint8_t>& o = z->wire;  // serialised once per proof: the size query and the copy share it
+  if (!z->wire_valid) {
+  o.clear();
   auto pute = [&](const E& e) {
     uint8_t b[32];
     h256_to_bytes(e, b);
@@ -1891,6 +1897,8 @@ int zk256_proof_write(const Zk256* z, uint8_t* buf, size_t cap, size_t* nbytes) 
   }
   putsz(z->npath);
   o.insert(o.end(), z->path.begin(), z->path.begin() + 32 * z->npath);
+  z->wire_valid = true;
+  }
   *nbytes = o.size();
   if (buf) {
     if (cap < o.size()) return lf_fail(z->c, LFGPU_ERR_ARG, "zk_proof_write: buffer too small (%zu < %zu)", cap, o.size());
