@@ -879,11 +879,6 @@ extern "C" int lfgpu_zk_proof_write(const lfgpu_zk_prover* zk, uint8_t* buf, siz
     elt_to_bytes(field, e, b);
     o.insert(o.end(), b, b + 16);
   };
-  auto in_subfield = [&](elt_t e) {  // Fp128: the subfield is the field (fp_generic.h:284)
-    if (field != LFGPU_FIELD_GF2_128) return true;
-    const elt_t res = solve_subfield(zk, e).first;
-    return (res.lo | res.hi) == 0;
-  };
   auto putsz = [&](size_t g) {  // write_size: 4 bytes LE (zk_proof.h:211-216)
     for (int i = 0; i < 4; ++i) o.push_back((uint8_t)(g >> (8 * i)));
   };
