@@ -245,12 +245,6 @@ static void launch_lch(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
     hipLaunchKernelGGL(lch_fft_tile<512>, grid, dim3(512), lds, c->stream, args...);
 }
 
-static u32 floor_pow2_log(size_t x) {
-  u32 l = 0;
-  while (((size_t)2 << l) <= x) ++l;
-  return l;
-}
-
 static elt_t fp_reroot(elt_t w, u64 n, u64 r) {  // twiddle.h:47-55
   while (r < n) {
     w = fp_mul(w, w);
