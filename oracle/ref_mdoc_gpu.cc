@@ -115,17 +115,23 @@ static int verify_both(HashVerifier& hash_v, SigVerifier& sig_v, const Circuit<f
   return ok && ok2 ? 1 : 0;
 }
 
-int mdoc_gpu(int reps, bool with_ref) {
+// which of the reference's own examples (mdoc_zk_test.cc:118-240): 0 = kZkSpecs[0], mdoc_tests[0], age_over_18 (the BASELINE
+// config); 1 = kZkSpecs[0], mdoc_tests[3], familyname_mustermann (another document, a text attribute); 2 = kZkSpecs[1] -- the
+// TWO-attribute circuits, a different pair of circuits -- mdoc_tests[3], age_over_18 + familyname_mustermann
+int mdoc_gpu(int reps, bool with_ref, int which) {
   set_log_level(ERROR);
-  const ZkSpecStruct* zk_spec = &kZkSpecs[0];
+  const ZkSpecStruct* zk_spec = &kZkSpecs[which == 2 ? 1 : 0];
   uint8_t* bcp;
   size_t bcsz;
   const double tg0 = now_ms();
   if (generate_circuit(zk_spec, &bcp, &bcsz) != CIRCUIT_GENERATION_SUCCESS) return 3;
   const double tg1 = now_ms();
-  const MdocTests* test = &mdoc_tests[0];
-  const RequestedAttribute attrs[] = {test::age_over_18};
-  const size_t attrs_len = 1;
+  const MdocTests* test = &mdoc_tests[which == 0 ? 0 : 3];
+  const RequestedAttribute attrs_all[3][2] = {{test::age_over_18, test::age_over_18},
+                                              {test::familyname_mustermann, test::familyname_mustermann},
+                                              {test::age_over_18, test::familyname_mustermann}};
+  const RequestedAttribute* attrs = attrs_all[which];
+  const size_t attrs_len = which == 2 ? 2 : 1;
   Elt pkX, pkY;
   if (!parsePk(test->pkx.as_pointer, test->pky.as_pointer, pkX, pkY)) return 4;
   const f2_p256 p256_2(p256_base);
@@ -216,12 +222,12 @@ int mdoc_gpu(int reps, bool with_ref) {
                         (const char*)test->now, proof_gpu.data(), proof_gpu.size(), test->doc_type, zk_spec);
   const double t_verify = now_ms() - tv0;
   printf(
-      "{\"proof_bytes\": %zu, \"gpu_sha256\": \"%s\", \"ref_sha256\": \"%s\", \"identical\": %s, \"reference_verifier_accepts_gpu_proof\": %s, "
+      "{\"case\": %d, \"attributes\": %zu, \"proof_bytes\": %zu, \"gpu_sha256\": \"%s\", \"ref_sha256\": \"%s\", \"identical\": %s, \"reference_verifier_accepts_gpu_proof\": %s, "
       "\"gpu_ms\": {\"commit\": %.2f, \"prove\": %.2f, \"total\": %.2f}, \"ref_ms\": {\"commit\": %.2f, \"prove\": %.2f, \"total\": %.2f}, "
       "\"host_ms\": {\"generate_circuit\": %.1f, \"reference_parse\": %.1f, \"fill_witness\": %.1f, \"gpu_parse_upload\": %.1f, \"reference_verify\": %.1f}, "
       "\"verify\": {\"gpu_verifiers_accept\": %s, \"gpu_verifiers_reject_flipped_bit\": %s, \"reference_verifiers_accept\": %s, \"gpu_ms\": %.2f, \"ref_ms\": %.2f}, "
       "\"circuit_bytes\": {\"sig\": %zu, \"hash\": %zu}}\n",
-      proof_gpu.size(), sha_hex(proof_gpu).c_str(), with_ref ? sha_hex(proof_ref).c_str() : "", with_ref && proof_ref == proof_gpu ? "true" : "false",
+      which, attrs_len, proof_gpu.size(), sha_hex(proof_gpu).c_str(), with_ref ? sha_hex(proof_ref).c_str() : "", with_ref && proof_ref == proof_gpu ? "true" : "false",
       vr == MDOC_VERIFIER_SUCCESS ? "true" : "false", ms_gpu[0], ms_gpu[1], ms_gpu[0] + ms_gpu[1], ms_ref[0], ms_ref[1], ms_ref[0] + ms_ref[1], tg1 - tg0,
       t_parse_ref, t_witness, t_upload, t_verify, gpu_verdict == 1 ? "true" : "false", gpu_verdict_bad == 0 ? "true" : "false",
       ref_verdict == 1 ? "true" : "false", ms_gpu_verify, ms_ref_verify_body, sig_len, hash_len);
@@ -235,5 +241,7 @@ int mdoc_gpu(int reps, bool with_ref) {
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 2;
   const bool with_ref = !(argc > 2 && std::string(argv[2]) == "--no-ref");
-  return proofs::mdoc_gpu(reps < 1 ? 1 : reps, with_ref);
+  const int which = argc > 3 ? atoi(argv[3]) : 0;
+  if (which < 0 || which > 2) return 2;
+  return proofs::mdoc_gpu(reps < 1 ? 1 : reps, with_ref, which);
 }

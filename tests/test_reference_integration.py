@@ -69,21 +69,27 @@ def test_reference_zkprover_p256_signature_circuit_with_gpu_interpolator():
 
 
 @pytest.mark.gpu
-def test_mdoc_end_to_end_with_gpu_provers_in_run_mdoc_prover():
+@pytest.mark.parametrize("which,reps", [(0, 3), (1, 1), (2, 1)], ids=["age_over_18", "other_document_text_attribute", "two_attribute_circuits"])
+def test_mdoc_end_to_end_with_gpu_provers_in_run_mdoc_prover(which, reps):
     """BASELINE config 5 end to end: the body of the reference's run_mdoc_prover (lib/circuits/mdoc/mdoc_zk.cc:398-546:
     circuit generation and parsing, CBOR witness filling, the shared transcript, MAC key and update_macs between commit and
     prove, ZkProof::write of both proofs) with lfgpu::GpuZkProver (include/lfgpu_zk_adapters.h) in the place of
     ZkProver<f_128, .> AND ZkProver<Fp256Base, .> -- every commit and prove on the device -- against the same body with the
     reference's own provers, same witness, same deterministic RandomEngine (oracle/ref_mdoc_gpu.cc).  The two mdoc proof
     strings must be byte-identical and the reference's run_mdoc_verifier must accept the library's; then the verifier's body
-    with lfgpu::GpuZkVerifier for both circuits must accept that proof and reject it with one bit flipped."""
+    with lfgpu::GpuZkVerifier for both circuits must accept that proof and reject it with one bit flipped.
+
+    Cases are the reference's own examples (lib/circuits/mdoc/mdoc_zk_test.cc:118-240): kZkSpecs[0] on mdoc_tests[0] with
+    age_over_18 (the BASELINE configuration), kZkSpecs[0] on mdoc_tests[3] with the text attribute family_name, and
+    kZkSpecs[1] -- the two-attribute pair of circuits, different circuits from the first two cases -- on mdoc_tests[3]."""
     exe = os.path.join(ROOT, "oracle", "_ref", "mdoc_gpu")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/mdoc_gpu not built (needs the reference sources and zstd.h: make -C oracle ref in the build container)")
-    out = subprocess.run([exe, "3"], capture_output=True, timeout=900)
+    out = subprocess.run([exe, str(reps), "--ref", str(which)], capture_output=True, timeout=900)
     assert out.returncode == 0, (out.returncode, out.stdout.decode()[-1000:], out.stderr.decode()[-2000:])
     res = json.loads(out.stdout.decode().strip().splitlines()[-1])
     print("mdoc end to end:", res)
+    assert res["case"] == which and res["attributes"] == (2 if which == 2 else 1)
     assert res["identical"] is True and res["gpu_sha256"] == res["ref_sha256"]
     assert res["reference_verifier_accepts_gpu_proof"] is True
     # the body of run_mdoc_verifier (mdoc_zk.cc:548-712) with lfgpu::GpuZkVerifier in the place of both ZkVerifiers
