@@ -72,6 +72,12 @@ int lfgpu_memcpy_d2h(lfgpu_ctx* ctx, void* h_dst, const void* d_src, size_t byte
  * of two >= n) in Montgomery form, exactly the (omega_j, j) arguments of fftb. */
 int lfgpu_fp128_fft(lfgpu_ctx* ctx, int dir, size_t rows, size_t n, const uint64_t omega[2],
                     uint64_t omega_order, void* d_A, size_t ld);
+/* Same transform over F64_2 = Fp2<Fp<1>>, p = 2^64 - 2^32 + 1 -- the second field of the reference's FFT tests and
+ * benchmarks (lib/algebra/fft_test.cc:205-229, BM_FFT_F64_2).  Elements are the memory image of Fp2<Fp<1>>::Elt
+ * (lib/algebra/fp2.h:48-52): {re, im}, 8 bytes each, Montgomery form (R = 2^64), reduced.  omega = {re, im} likewise;
+ * a root in the base field (im = 0, as in the reference's test) takes the cheaper twiddle product. */
+int lfgpu_f64_2_fft(lfgpu_ctx* ctx, int dir, size_t rows, size_t n, const uint64_t omega[2],
+                    uint64_t omega_order, void* d_A, size_t ld);
 
 /* ---- K2: additive (LCH14) FFT over GF(2^128) ------------------------------
  * Replaces LCH14<GF2_128<k>>::FFT / IFFT (lib/gf2k/lch14.h:106-144).
@@ -292,6 +298,8 @@ int lfgpu_ligero_free(lfgpu_ligero_prover* pr);
 
 /* ---- host-buffer conveniences (what the header-only adapters call) ---------- */
 int lfgpu_fp128_fft_host(lfgpu_ctx* ctx, int dir, size_t n, const uint64_t omega[2], uint64_t omega_order,
+                         void* h_A);
+int lfgpu_f64_2_fft_host(lfgpu_ctx* ctx, int dir, size_t n, const uint64_t omega[2], uint64_t omega_order,
                          void* h_A);
 int lfgpu_gf2128_lch14_fft_host(lfgpu_ctx* ctx, int subfield_log_bits, int dir, unsigned l, uint64_t coset,
                                 void* h_B);

@@ -21,13 +21,16 @@ FIELD_P256 = 1  # Fp256Base, 32-byte elements
 # 2^32-order root of unity of Fp128 (reference lib/algebra/fp_p128.h:48-56), canonical value
 FP128_OMEGA32 = 164956748514267535023998284330560247862
 FP128_P = 2**128 - 2**108 + 1
+# F64 = Fp<1>, p = 2^64 - 2^32 + 1, and its root of unity of order 2^32 (reference lib/algebra/fft_test.cc:208-213)
+F64_P = 2**64 - 2**32 + 1
+F64_OMEGA32 = 2752994695033296049
 
 ABI_SYMBOLS = [
     "lfgpu_init", "lfgpu_shutdown", "lfgpu_last_error", "lfgpu_set_stream", "lfgpu_sync", "lfgpu_malloc",
-    "lfgpu_free", "lfgpu_memcpy_h2d", "lfgpu_memcpy_d2h", "lfgpu_fp128_fft", "lfgpu_gf2128_lch14_fft",
+    "lfgpu_free", "lfgpu_memcpy_h2d", "lfgpu_memcpy_d2h", "lfgpu_fp128_fft", "lfgpu_f64_2_fft", "lfgpu_gf2128_lch14_fft",
     "lfgpu_gf2128_rs_encode_rows", "lfgpu_gf2128_rs_encode_tableau", "lfgpu_fp128_rs_encode_rows", "lfgpu_fp256_rs_encode_rows", "lfgpu_column_commit", "lfgpu_column_leaves", "lfgpu_merkle_build_tree",
     "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
-    "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_field_binop", "lfgpu_fp128_fft_host", "lfgpu_gf2128_lch14_fft_host",
+    "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_field_binop", "lfgpu_fp128_fft_host", "lfgpu_f64_2_fft_host", "lfgpu_gf2128_lch14_fft_host",
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_fp128_rs_encode_rows_host", "lfgpu_fp256_rs_encode_rows_host", "lfgpu_column_commit_host",
     "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_layout_rows", "lfgpu_ligero_encode_rows", "lfgpu_ligero_prover_from_slab", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
     "lfgpu_ligero_inner_product_rows", "lfgpu_ligero_dot_proof_sparse",
@@ -97,6 +100,7 @@ def load_library():
         "lfgpu_malloc": [vp, sz, C.POINTER(vp)], "lfgpu_free": [vp, vp],
         "lfgpu_memcpy_h2d": [vp, vp, vp, sz], "lfgpu_memcpy_d2h": [vp, vp, vp, sz],
         "lfgpu_fp128_fft": [vp, ci, sz, sz, pu64, u64, vp, sz],
+        "lfgpu_f64_2_fft": [vp, ci, sz, sz, pu64, u64, vp, sz],
         "lfgpu_gf2128_lch14_fft": [vp, ci, ci, sz, C.c_uint, u64, vp, sz],
         "lfgpu_gf2128_rs_encode_rows": [vp, ci, sz, sz, sz, vp, sz],
         "lfgpu_gf2128_rs_encode_tableau": [vp, ci, sz, sz, sz, sz, sz, sz, vp, sz],
@@ -114,6 +118,7 @@ def load_library():
         "lfgpu_field_binop": [vp, ci, ci, sz, vp, vp, vp],
         "lfgpu_gather_columns": [vp, sz, sz, sz, vp, vp, sz, vp],
         "lfgpu_fp128_fft_host": [vp, ci, sz, pu64, u64, vp],
+        "lfgpu_f64_2_fft_host": [vp, ci, sz, pu64, u64, vp],
         "lfgpu_gf2128_lch14_fft_host": [vp, ci, ci, C.c_uint, u64, vp],
         "lfgpu_gf2128_rs_encode_rows_host": [vp, ci, sz, sz, sz, vp, sz],
         "lfgpu_fp128_rs_encode_rows_host": [vp, sz, sz, sz, pu64, u64, vp, sz],
@@ -185,6 +190,21 @@ def fp128_from_montgomery(x):
     return (x * pow(1 << 128, -1, FP128_P)) % FP128_P
 
 
+def f64_to_montgomery(x):
+    return (x * (1 << 64)) % F64_P
+
+
+def f64_from_montgomery(x):
+    return (x * pow(1 << 64, -1, F64_P)) % F64_P
+
+
+def _f64_2_omega(omega):
+    """None = the reference's root of order 2^32 (real); else (re, im) Montgomery images"""
+    if omega is None:
+        omega = (f64_to_montgomery(F64_OMEGA32), 0)
+    return (C.c_uint64 * 2)(int(omega[0]), int(omega[1]))
+
+
 class LfGpu:
     """One context per process / GPU (lfgpu_ctx).  Pointer arguments are raw device
     addresses (e.g. torch.Tensor.data_ptr()); strides are in 16-byte elements."""
@@ -224,6 +244,12 @@ class LfGpu:
     def fp128_fft(self, d_ptr, rows, n, ld=None, forward=False, omega=None, omega_order=1 << 32):
         omega = _u64x2(fp128_to_montgomery(FP128_OMEGA32) if omega is None else omega)
         self._ck(self.L.lfgpu_fp128_fft(self.h, 1 if forward else 0, rows, n, omega, omega_order, C.c_void_p(d_ptr),
+                                        n if ld is None else ld))
+
+    # --- K1 over F64_2 = Fp2<Fp<1>> (reference lib/algebra/fft_test.cc:205-229); omega = (re, im) in Montgomery form
+    def f64_2_fft(self, d_ptr, rows, n, ld=None, forward=False, omega=None, omega_order=1 << 32):
+        omega = _f64_2_omega(omega)
+        self._ck(self.L.lfgpu_f64_2_fft(self.h, 1 if forward else 0, rows, n, omega, omega_order, C.c_void_p(d_ptr),
                                         n if ld is None else ld))
 
     # --- K2 LCH14::FFT / IFFT (reference lib/gf2k/lch14.h:106-144)
@@ -332,6 +358,10 @@ class LfGpu:
     def fp128_fft_host(self, a, forward=False, omega=None, omega_order=1 << 32):
         omega = _u64x2(fp128_to_montgomery(FP128_OMEGA32) if omega is None else omega)
         self._ck(self.L.lfgpu_fp128_fft_host(self.h, 1 if forward else 0, a.shape[0], omega, omega_order,
+                                             C.c_void_p(a.ctypes.data)))
+
+    def f64_2_fft_host(self, a, forward=False, omega=None, omega_order=1 << 32):
+        self._ck(self.L.lfgpu_f64_2_fft_host(self.h, 1 if forward else 0, a.shape[0], _f64_2_omega(omega), omega_order,
                                              C.c_void_p(a.ctypes.data)))
 
     def gf2128_lch14_fft_host(self, a, l, coset=0, inverse=False, subfield_log_bits=4):

@@ -42,10 +42,46 @@ __device__ __forceinline__ u32 lds_slot(u32 k, u32 c, u32 logT, u32 logC) {
   return slot;
 }
 
-// ------------------------------------------------------------------ K1: Fp128
+// ------------------------------------------------------------------ K1: Fp128 (and the F64_2 of the reference's FFT tests)
+// What K1 needs of a field with 16-byte elements: add, sub, the product with a twiddle (a power of the root) and, on the
+// host, the general product, 1 and the inverse.  Fp128 is the field of the prover; F64_2 = Fp2<Fp<1>> over
+// p = 2^64 - 2^32 + 1 is the second field of lib/algebra/fft_test.cc:205-229 (BM_FFT_F64_2) -- same plan, same kernel.
+struct Fp128Ops {
+  static constexpr const char* kKey = "fp";
+  static LF_HD elt_t add(elt_t a, elt_t b) { return fp_add(a, b); }
+  static LF_HD elt_t sub(elt_t a, elt_t b) { return fp_sub(a, b); }
+  static LF_HD elt_t mul_tw(elt_t a, elt_t w) { return fp_mul(a, w); }
+  static elt_t hmul(elt_t a, elt_t b) { return fp_mul(a, b); }
+  static elt_t one() { return h_fp_of_scalar(1); }
+  static elt_t inv(elt_t a) { return h_fp_inv(a); }
+};
+static u64 h_f64_pow(u64 x, u64 e) {
+  u64 r = 0xFFFFFFFFull;  // 2^64 mod p: the Montgomery image of 1
+  for (; e; e >>= 1) {
+    if (e & 1) r = f64_mul(r, x);
+    x = f64_mul(x, x);
+  }
+  return r;
+}
+// REAL: the root lies in the base field (as in the reference's test and benchmark, fft_test.cc:211-217), so every
+// twiddle has a zero imaginary part and its product costs two base-field products instead of three
+template <bool REAL>
+struct F64x2Ops {
+  static constexpr const char* kKey = "f64x2";
+  static LF_HD elt_t add(elt_t a, elt_t b) { return f64x2_add(a, b); }
+  static LF_HD elt_t sub(elt_t a, elt_t b) { return f64x2_sub(a, b); }
+  static LF_HD elt_t mul_tw(elt_t a, elt_t w) { return REAL ? f64x2_mul_real(a, w.lo) : f64x2_mul(a, w); }
+  static elt_t hmul(elt_t a, elt_t b) { return f64x2_mul(a, b); }
+  static elt_t one() { return elt_t{0xFFFFFFFFull, 0ull}; }
+  static elt_t inv(elt_t a) {  // Fp2::invert (fp2.h:112-123): conj(a) / (re^2 + im^2)
+    const u64 d = f64_add(f64_mul(a.lo, a.lo), f64_mul(a.hi, a.hi));
+    return f64x2_mul_real(elt_t{a.lo, f64_sub(0, a.hi)}, h_f64_pow(d, F64_P - 2));
+  }
+};
+
 // W[i << wshift] = w_T^i (i < T/2).  Optional inter-pass twiddle w_n^{j*(col)}
 // = tw_lo[e & 1023] * tw_hi[e >> 10].
-template <int R, int FFT_THREADS>
+template <class O, int R, int FFT_THREADS>
 __device__ __forceinline__ void fp_radix_round(elt_t* s, const elt_t* Wl, u32 wsh, u32 logT, u32 logC, u32 st, u32 tid) {
   constexpr u32 N = 1u << R;
   const u32 T = 1u << logT, C = 1u << logC, m = 1u << st;
@@ -68,11 +104,11 @@ __device__ __forceinline__ void fp_radix_round(elt_t* s, const elt_t* Wl, u32 ws
         if (a & half) continue;
         const u32 jj = j + (a & (half - 1)) * m;
         if (t > 0 || j) {
-          if ((a & (half - 1)) || j) x[a + half] = fp_mul(x[a + half], ld16(&Wl[(size_t)(jj << (logT - 1 - st - t)) << wsh]));
+          if ((a & (half - 1)) || j) x[a + half] = O::mul_tw(x[a + half], ld16(&Wl[(size_t)(jj << (logT - 1 - st - t)) << wsh]));
         }
         const elt_t u = x[a], v = x[a + half];
-        x[a] = fp_add(u, v);
-        x[a + half] = fp_sub(u, v);
+        x[a] = O::add(u, v);
+        x[a + half] = O::sub(u, v);
       }
     }
 #pragma unroll
@@ -83,7 +119,7 @@ __device__ __forceinline__ void fp_radix_round(elt_t* s, const elt_t* Wl, u32 ws
 // tw_hi == nullptr with tw_lo != nullptr: tw_lo is the FULL inter-pass table [j][column] (one product per element
 // instead of two; rows of the grid then vary fastest so that a tile's slice of the table stays in L2 while the
 // batch rows stream past it).
-template <int FFT_THREADS>
+template <class O, int FFT_THREADS>
 __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt_t* __restrict__ W, u32 wshift,
                                                            const elt_t* __restrict__ tw_lo,
                                                            const elt_t* __restrict__ tw_hi, u32 row_fast) {
@@ -119,9 +155,9 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
   while (st < p.logT) {
     const u32 rem = p.logT - st;
     const u32 R = (rem == 3 || rem > 4) ? 3 : (rem >= 2 ? 2 : 1);
-    if (R == 3) fp_radix_round<3, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
-    else if (R == 2) fp_radix_round<2, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
-    else fp_radix_round<1, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
+    if (R == 3) fp_radix_round<O, 3, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
+    else if (R == 2) fp_radix_round<O, 2, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
+    else fp_radix_round<O, 1, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
     __syncthreads();
     st += R;
   }
@@ -135,10 +171,10 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
       if (ex) {
         if (tw_hi) {
           elt_t t = ld16(&tw_lo[ex & 1023]);
-          if (ex >> 10) t = fp_mul(t, ld16(&tw_hi[ex >> 10]));
-          v = fp_mul(v, t);
+          if (ex >> 10) t = O::mul_tw(t, ld16(&tw_hi[ex >> 10]));
+          v = O::mul_tw(v, t);
         } else {
-          v = fp_mul(v, ld16(&tw_lo[(size_t)j * p.nbatch + col]));
+          v = O::mul_tw(v, ld16(&tw_lo[(size_t)j * p.nbatch + col]));
         }
       }
     }
@@ -209,14 +245,21 @@ __global__ __launch_bounds__(FFT_THREADS) void lch_fft_tile(TilePlan p, int inve
 }
 
 // ------------------------------------------------------------------ host side
+template <class O>
+static int set_lds_limit_fp(lfgpu_ctx* c) {
+  LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<O, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<O, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return LFGPU_OK;
+}
 static int set_lds_limit(lfgpu_ctx* c) {
   if (!(c->attr_done & 1u)) {
     if (const char* e = getenv("LFGPU_TILE_LOG")) {  // tuning knob: 12 or 13
       int v = atoi(e);
       if (v == 12 || v == 13) c->tile_log = v;
     }
-    LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    LF_TRY(set_lds_limit_fp<Fp128Ops>(c));
+    LF_TRY(set_lds_limit_fp<F64x2Ops<true>>(c));
+    LF_TRY(set_lds_limit_fp<F64x2Ops<false>>(c));
     LF_HIP(c, hipFuncSetAttribute((const void*)lch_fft_tile<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
     LF_HIP(c, hipFuncSetAttribute((const void*)lch_fft_tile<512>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELTS * 16));
     c->attr_done |= 1u;
@@ -230,12 +273,12 @@ static size_t fp_lds_bytes(TilePlan& p) {
   p.wlds = tile + tw <= 160u * 1024u ? 1u : 0u;
   return p.wlds ? tile + tw : tile;
 }
-template <class... Args>
+template <class O, class... Args>
 static void launch_fp(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
   if (c->tile_log == 13)
-    hipLaunchKernelGGL(fp_fft_tile<1024>, grid, dim3(1024), lds, c->stream, args...);
+    hipLaunchKernelGGL((fp_fft_tile<O, 1024>), grid, dim3(1024), lds, c->stream, args...);
   else
-    hipLaunchKernelGGL(fp_fft_tile<512>, grid, dim3(512), lds, c->stream, args...);
+    hipLaunchKernelGGL((fp_fft_tile<O, 512>), grid, dim3(512), lds, c->stream, args...);
 }
 template <class... Args>
 static void launch_lch(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
@@ -245,9 +288,10 @@ static void launch_lch(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
     hipLaunchKernelGGL(lch_fft_tile<512>, grid, dim3(512), lds, c->stream, args...);
 }
 
+template <class O>
 static elt_t fp_reroot(elt_t w, u64 n, u64 r) {  // twiddle.h:47-55
   while (r < n) {
-    w = fp_mul(w, w);
+    w = O::hmul(w, w);
     r += r;
   }
   return w;
@@ -282,15 +326,16 @@ static TilePlan plan_single(const lfgpu_ctx* c, void* A, size_t rows, u32 logn, 
 }
 
 // root table W[i] = w_Tw^i, i < Tw/2, for a transform of 2^logn points with the root wn of that order
+template <class O>
 static int fp_root_table(lfgpu_ctx* c, const elt_t wn, u32 logn, u32 logTw, std::string* key_out, void** dW) {
   const size_t n = (size_t)1 << logn;
-  std::string key = keyf("fpW:%llx:%llx:%u:%u", (u64)wn.lo, (u64)wn.hi, logn, logTw);
+  std::string key = keyf("%sW:%llx:%llx:%u:%u", O::kKey, (u64)wn.lo, (u64)wn.hi, logn, logTw);
   if (!lf_table_lookup(c, key, dW)) {
     std::vector<elt_t> W((size_t)1 << (logTw ? logTw - 1 : 0));
-    elt_t wt = fp_reroot(wn, n, (u64)1 << logTw), x = h_fp_of_scalar(1);
+    elt_t wt = fp_reroot<O>(wn, n, (u64)1 << logTw), x = O::one();
     for (size_t i = 0; i < W.size(); ++i) {
       W[i] = x;
-      x = fp_mul(x, wt);
+      x = O::hmul(x, wt);
     }
     LF_TRY(lf_table(c, key, W.data(), W.size() * 16, dW));
   }
@@ -298,20 +343,21 @@ static int fp_root_table(lfgpu_ctx* c, const elt_t wn, u32 logn, u32 logTw, std:
   return LFGPU_OK;
 }
 // the two-level inter-pass table lo[e & 1023] = wn^(e & 1023), hi[e >> 10] = wn^(1024 (e >> 10)), e < n
+template <class O>
 static int fp_two_level_tables(lfgpu_ctx* c, const elt_t wn, u32 logn, const std::string& key, void** dlo, void** dhi) {
   std::string klo = key + ":lo", khi = key + ":hi";
   if (!lf_table_lookup(c, klo, dlo) || !lf_table_lookup(c, khi, dhi)) {
     std::vector<elt_t> lo(1024), hi((size_t)1 << (logn > 10 ? logn - 10 : 0));
-    elt_t x = h_fp_of_scalar(1);
+    elt_t x = O::one();
     for (size_t i = 0; i < 1024; ++i) {
       lo[i] = x;
-      x = fp_mul(x, wn);
+      x = O::hmul(x, wn);
     }
     elt_t w1024 = x;  // wn^1024
-    x = h_fp_of_scalar(1);
+    x = O::one();
     for (size_t i = 0; i < hi.size(); ++i) {
       hi[i] = x;
-      x = fp_mul(x, w1024);
+      x = O::hmul(x, w1024);
     }
     LF_TRY(lf_table(c, klo, lo.data(), lo.size() * 16, dlo));
     LF_TRY(lf_table(c, khi, hi.data(), hi.size() * 16, dhi));
@@ -321,6 +367,7 @@ static int fp_two_level_tables(lfgpu_ctx* c, const elt_t wn, u32 logn, const std
 
 // Two tile passes for 2^12 < n <= 2^20: `rows` transforms with the root wn of order n, row r read at src + r*sld and
 // written to X[j] = dst[r*drow + j*dstep] (dstep = 1, drow = ld: a plain row).  Goes through `scratch`.
+template <class O>
 static int fp_fft_two_pass(lfgpu_ctx* c, const elt_t wn, u32 logn, size_t rows, const elt_t* src, size_t sld, elt_t* dst, long long drow,
                            long long dstep) {
   const size_t n = (size_t)1 << logn;
@@ -328,27 +375,27 @@ static int fp_fft_two_pass(lfgpu_ctx* c, const elt_t wn, u32 logn, size_t rows, 
   const u32 logTw = logn1 > logn2 ? logn1 : logn2;  // root table covers the larger tile
   void *dW = nullptr, *dlo = nullptr, *dhi = nullptr;
   std::string key;
-  LF_TRY(fp_root_table(c, wn, logn, logTw, &key, &dW));
+  LF_TRY(fp_root_table<O>(c, wn, logn, logTw, &key, &dW));
   // Inter-pass twiddles w_n^(j1*k2): either the full [j1][k2] table (n elements, default: one product
   // per element, table slices stay in L2 because batch rows vary fastest in the grid) or, with LFGPU_FP_TW=2, the
   // two-level form lo[e & 1023] * hi[e >> 10] (2 KiB + n/64 bytes of tables, two products per element).
   static const bool two_level = getenv("LFGPU_FP_TW") && atoi(getenv("LFGPU_FP_TW")) == 2;
   const size_t n1 = (size_t)1 << logn1, n2 = (size_t)1 << logn2;
   if (two_level) {
-    LF_TRY(fp_two_level_tables(c, wn, logn, key, &dlo, &dhi));
+    LF_TRY(fp_two_level_tables<O>(c, wn, logn, key, &dlo, &dhi));
   } else {
     std::string kfull = key + ":full";
     if (!lf_table_lookup(c, kfull, &dlo)) {
       std::vector<elt_t> full(n1 * n2);
-      elt_t wj = h_fp_of_scalar(1);  // wn^j1
+      elt_t wj = O::one();  // wn^j1
       for (size_t j = 0; j < n1; ++j) {
-        elt_t x = h_fp_of_scalar(1);
+        elt_t x = O::one();
         elt_t* row = &full[j * n2];
         for (size_t k = 0; k < n2; ++k) {
           row[k] = x;
-          x = fp_mul(x, wj);
+          x = O::hmul(x, wj);
         }
-        wj = fp_mul(wj, wn);
+        wj = O::hmul(wj, wn);
       }
       LF_TRY(lf_table(c, kfull, full.data(), full.size() * 16, &dlo));
     }
@@ -373,9 +420,9 @@ static int fp_fft_two_pass(lfgpu_ctx* c, const elt_t wn, u32 logn, size_t rows, 
     size_t lds = fp_lds_bytes(p);
     static const bool row_fast_env = !(getenv("LFGPU_FP_ROWFAST") && atoi(getenv("LFGPU_FP_ROWFAST")) == 0);
     if (!two_level && rows <= 65535 && row_fast_env)  // rows fastest: the tile's table slice is reused by every row while it is hot
-      launch_fp(c, dim3((u32)rows, (u32)(n2 >> p.logC)), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi, 1u);
+      launch_fp<O>(c, dim3((u32)rows, (u32)(n2 >> p.logC)), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi, 1u);
     else
-      launch_fp(c, dim3((u32)(n2 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi, 0u);
+      launch_fp<O>(c, dim3((u32)(n2 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn1, (const elt_t*)dlo, (const elt_t*)dhi, 0u);
     LF_HIP(c, hipGetLastError());
   }
   {  // pass B: n2-point transforms on contiguous rows j1; output X[j1 + n1*j2]
@@ -397,42 +444,44 @@ static int fp_fft_two_pass(lfgpu_ctx* c, const elt_t wn, u32 logn, size_t rows, 
     p.kfast_src = 1;
     p.kfast_dst = 0;
     size_t lds = fp_lds_bytes(p);
-    launch_fp(c, dim3((u32)(n1 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn2, (const elt_t*)nullptr,
+    launch_fp<O>(c, dim3((u32)(n1 >> p.logC), (u32)rows), lds, p, (const elt_t*)dW, logTw - logn2, (const elt_t*)nullptr,
               (const elt_t*)nullptr, 0u);
     LF_HIP(c, hipGetLastError());
   }
   return LFGPU_OK;
 }
 
-extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, const uint64_t omega[2],
-                               uint64_t omega_order, void* d_A, size_t ld) {
-  if (!c || !omega || (!d_A && rows && n)) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: null argument");
+// FFT<Field>::fftb / fftf (fft.h:185-201) for the field O describes
+template <class O>
+static int fft_any(lfgpu_ctx* c, const char* what, int dir, size_t rows, size_t n, const uint64_t omega[2], uint64_t omega_order, void* d_A,
+                   size_t ld) {
+  if (!c || !omega || (!d_A && rows && n)) return lf_fail(c, LFGPU_ERR_ARG, "%s: null argument", what);
   if (rows == 0 || n <= 1) return LFGPU_OK;
-  if (n & (n - 1)) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: n=%zu is not a power of two", n);
+  if (n & (n - 1)) return lf_fail(c, LFGPU_ERR_ARG, "%s: n=%zu is not a power of two", what, n);
   if (omega_order < n || (omega_order & (omega_order - 1)))
-    return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: omega_order must be a power of two >= n");
-  if (ld < n) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: ld < n");
-  if (rows > 0x7fffffffu) return lf_fail(c, LFGPU_ERR_ARG, "fp128_fft: too many rows");
+    return lf_fail(c, LFGPU_ERR_ARG, "%s: omega_order must be a power of two >= n", what);
+  if (ld < n) return lf_fail(c, LFGPU_ERR_ARG, "%s: ld < n", what);
+  if (rows > 0x7fffffffu) return lf_fail(c, LFGPU_ERR_ARG, "%s: too many rows", what);
   const u32 logn = lf_log2(n);
-  if (logn > 30) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "fp128_fft: n > 2^30");
+  if (logn > 30) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "%s: n > 2^30", what);
   LF_HIP(c, hipSetDevice(c->device));
   LF_TRY(set_lds_limit(c));
 
   elt_t w{omega[0], omega[1]};
-  if (dir == 1) w = h_fp_inv(w);  // fftf = fftb with omega^-1 (fft.h:198-201)
-  elt_t wn = fp_reroot(w, omega_order, n);
+  if (dir == 1) w = O::inv(w);  // fftf = fftb with omega^-1 (fft.h:198-201)
+  elt_t wn = fp_reroot<O>(w, omega_order, n);
   if (logn <= (u32)c->tile_log) {  // one pass
     void* dW = nullptr;
     std::string key;
-    LF_TRY(fp_root_table(c, wn, logn, logn, &key, &dW));
+    LF_TRY(fp_root_table<O>(c, wn, logn, logn, &key, &dW));
     TilePlan p = plan_single(c, d_A, rows, logn, ld);
     u32 ntiles = (u32)((rows + (1u << p.logC) - 1) >> p.logC);
     size_t lds = fp_lds_bytes(p);
-    launch_fp(c, dim3(ntiles, 1), lds, p, (const elt_t*)dW, 0u, (const elt_t*)nullptr, (const elt_t*)nullptr, 0u);
+    launch_fp<O>(c, dim3(ntiles, 1), lds, p, (const elt_t*)dW, 0u, (const elt_t*)nullptr, (const elt_t*)nullptr, 0u);
     LF_HIP(c, hipGetLastError());
     return LFGPU_OK;
   }
-  if (logn <= 20) return fp_fft_two_pass(c, wn, logn, rows, (const elt_t*)d_A, ld, (elt_t*)d_A, (long long)ld, 1);
+  if (logn <= 20) return fp_fft_two_pass<O>(c, wn, logn, rows, (const elt_t*)d_A, ld, (elt_t*)d_A, (long long)ld, 1);
   // n > 2^20: n = n1 * 2^20.  Per row: one tile pass of n1-point transforms down the stride-2^20 dimension, multiplied by
   // the twiddles w_n^(j1 * column) (two-level table), written as n1 contiguous sequences of 2^20 points; those are
   // transformed by the two-pass plan with the root w_n^n1 and written to X[j1 + n1 * J].
@@ -440,11 +489,11 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
   const size_t n1 = (size_t)1 << logn1, n2 = (size_t)1 << 20;
   void *dW = nullptr, *dlo = nullptr, *dhi = nullptr, *mid = nullptr;
   std::string key;
-  LF_TRY(fp_root_table(c, wn, logn, logn1, &key, &dW));
-  LF_TRY(fp_two_level_tables(c, wn, logn, key, &dlo, &dhi));
+  LF_TRY(fp_root_table<O>(c, wn, logn, logn1, &key, &dW));
+  LF_TRY(fp_two_level_tables<O>(c, wn, logn, key, &dlo, &dhi));
   LF_TRY(lf_scratch2(c, n * 16, &mid));
   elt_t wi = wn;  // w_n^n1: the root of order 2^20 of the inner transforms
-  for (u32 i = 0; i < logn1; ++i) wi = fp_mul(wi, wi);
+  for (u32 i = 0; i < logn1; ++i) wi = O::hmul(wi, wi);
   for (size_t r = 0; r < rows; ++r) {
     elt_t* row = (elt_t*)d_A + r * ld;
     TilePlan p{};
@@ -459,11 +508,23 @@ extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, con
     p.nbatch = (u32)n2;
     p.kfast_src = p.kfast_dst = 0;
     size_t lds = fp_lds_bytes(p);
-    launch_fp(c, dim3((u32)(n2 >> p.logC), 1), lds, p, (const elt_t*)dW, 0u, (const elt_t*)dlo, (const elt_t*)dhi, 0u);
+    launch_fp<O>(c, dim3((u32)(n2 >> p.logC), 1), lds, p, (const elt_t*)dW, 0u, (const elt_t*)dlo, (const elt_t*)dhi, 0u);
     LF_HIP(c, hipGetLastError());
-    LF_TRY(fp_fft_two_pass(c, wi, 20, n1, (const elt_t*)mid, n2, row, 1, (long long)n1));
+    LF_TRY(fp_fft_two_pass<O>(c, wi, 20, n1, (const elt_t*)mid, n2, row, 1, (long long)n1));
   }
   return LFGPU_OK;
+}
+
+extern "C" int lfgpu_fp128_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, const uint64_t omega[2], uint64_t omega_order, void* d_A,
+                               size_t ld) {
+  return fft_any<Fp128Ops>(c, "fp128_fft", dir, rows, n, omega, omega_order, d_A, ld);
+}
+// FFT<Fp2<Fp<1>>>::fftb / fftf over p = 2^64 - 2^32 + 1 (fft_test.cc:205-229).  omega = {re, im}; the usual root is real.
+extern "C" int lfgpu_f64_2_fft(lfgpu_ctx* c, int dir, size_t rows, size_t n, const uint64_t omega[2], uint64_t omega_order, void* d_A,
+                               size_t ld) {
+  if (omega && (omega[0] >= F64_P || omega[1] >= F64_P)) return lf_fail(c, LFGPU_ERR_ARG, "f64_2_fft: omega is not reduced");
+  if (omega && omega[1] == 0) return fft_any<F64x2Ops<true>>(c, "f64_2_fft", dir, rows, n, omega, omega_order, d_A, ld);
+  return fft_any<F64x2Ops<false>>(c, "f64_2_fft", dir, rows, n, omega, omega_order, d_A, ld);
 }
 
 // Build (and cache) LCH14 twiddle tables for one tile pass.
@@ -591,6 +652,17 @@ extern "C" int lfgpu_fp128_fft_host(lfgpu_ctx* c, int dir, size_t n, const uint6
   LF_TRY(lf_scratch2(c, n * 16, &d));
   LF_HIP(c, hipMemcpyAsync(d, h_A, n * 16, hipMemcpyHostToDevice, c->stream));
   LF_TRY(lfgpu_fp128_fft(c, dir, 1, n, omega, omega_order, d, n));
+  LF_HIP(c, hipMemcpyAsync(h_A, d, n * 16, hipMemcpyDeviceToHost, c->stream));
+  LF_HIP(c, hipStreamSynchronize(c->stream));
+  return LFGPU_OK;
+}
+
+extern "C" int lfgpu_f64_2_fft_host(lfgpu_ctx* c, int dir, size_t n, const uint64_t omega[2], uint64_t omega_order, void* h_A) {
+  if (!c || !h_A) return LFGPU_ERR_ARG;
+  void* d = nullptr;
+  LF_TRY(lf_scratch2(c, n * 16, &d));
+  LF_HIP(c, hipMemcpyAsync(d, h_A, n * 16, hipMemcpyHostToDevice, c->stream));
+  LF_TRY(lfgpu_f64_2_fft(c, dir, 1, n, omega, omega_order, d, n));
   LF_HIP(c, hipMemcpyAsync(h_A, d, n * 16, hipMemcpyDeviceToHost, c->stream));
   LF_HIP(c, hipStreamSynchronize(c->stream));
   return LFGPU_OK;

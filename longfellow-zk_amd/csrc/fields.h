@@ -467,6 +467,42 @@ LF_HD elt_t fp_reduce_limbs(u64 a0, u64 a1, u64 a2, u64 a3) {
   return fp_add(fp_add(x, y), z);
 }
 
+// ===================================================================== F64 and F64_2
+// F64 = Fp<1> with p = 2^64 - 2^32 + 1 (lib/algebra/fp_generic.h; the prime of lib/algebra/fft_test.cc:205-229), values
+// in Montgomery form with R = 2^64, canonical in [0, p).  F64_2 = Fp2<F64> with i^2 = -1 (lib/algebra/fp2.h:36-52):
+// elt_t{lo = re, hi = im}, the memory image of Fp2<Fp<1>>::Elt.
+#define F64_P 0xFFFFFFFF00000001ull
+LF_HD u64 f64_add(u64 a, u64 b) {
+  u64 s = a + b;
+  if (s < a || s >= F64_P) s -= F64_P;
+  return s;
+}
+LF_HD u64 f64_sub(u64 a, u64 b) {
+  u64 d = a - b;
+  if (a < b) d += F64_P;
+  return d;
+}
+// Montgomery product a b 2^-64 mod p.  p^-1 = 2^32 + 1 (mod 2^64), so m = lo (2^32 + 1) has m p = lo (mod 2^64) and
+// (a b - m p) / 2^64 = hi - floor(m p / 2^64) exactly; with m p = m 2^64 - m (2^32 - 1) the floor needs shifts only.
+LF_HD u64 f64_mul(u64 a, u64 b) {
+  u64 lo, hi;
+  mul64(a, b, lo, hi);
+  const u64 m = lo + (lo << 32);
+  const u64 s = m << 32;                                         // m (2^32 - 1) = ((m >> 32) - (s < m)) 2^64 + (s - m)
+  const u64 mh = m - (m >> 32) + (u64)(s < m) - (u64)(lo != 0);  // floor(m p / 2^64); s - m = -lo (mod 2^64)
+  u64 t = hi - mh;
+  if (hi < mh) t += F64_P;
+  return t;
+}
+LF_HD elt_t f64x2_add(elt_t a, elt_t b) { return elt_t{f64_add(a.lo, b.lo), f64_add(a.hi, b.hi)}; }
+LF_HD elt_t f64x2_sub(elt_t a, elt_t b) { return elt_t{f64_sub(a.lo, b.lo), f64_sub(a.hi, b.hi)}; }
+LF_HD elt_t f64x2_mul(elt_t a, elt_t b) {  // Fp2::mul (fp2.h:87-101): three base-field products
+  const u64 p0 = f64_mul(a.lo, b.lo), p1 = f64_mul(a.hi, b.hi);
+  const u64 x = f64_mul(f64_add(a.lo, a.hi), f64_add(b.lo, b.hi));
+  return elt_t{f64_sub(p0, p1), f64_sub(f64_sub(x, p0), p1)};
+}
+LF_HD elt_t f64x2_mul_real(elt_t a, u64 y) { return elt_t{f64_mul(a.lo, y), f64_mul(a.hi, y)}; }  // Fp2::mul(Elt, Scalar) (:102-105)
+
 // ===================================================================== GF(2^128)
 LF_HD elt_t gf_add(elt_t a, elt_t b) { return elt_t{a.lo ^ b.lo, a.hi ^ b.hi}; }
 

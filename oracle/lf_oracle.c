@@ -441,6 +441,94 @@ void lfo_fp_fftf(lfo_elt* A, size_t n, lfo_elt omega_j, uint64_t j) { /* fft.h:1
   lfo_fp_fftb(A, n, lfo_fp_inv(omega_j), j);
 }
 
+/* ------------------------------------------------------------------ F64, F64_2 */
+/* Fp<1> over p = 2^64 - 2^32 + 1: one-limb Montgomery arithmetic, R = 2^64 (lib/algebra/fp_generic.h:161-184 add / sub,
+ * :484-513 mul0 / mulstep with one reduction_step: a += (a[0] * mprime mod 2^64) * m, drop the low limb, subtract m once). */
+#define F64_P 0xFFFFFFFF00000001ull
+uint64_t lfo_f64_add(uint64_t a, uint64_t b) {
+  u128 s = (u128)a + b;
+  return (uint64_t)(s >= F64_P ? s - F64_P : s);
+}
+uint64_t lfo_f64_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (F64_P - b); }
+uint64_t lfo_f64_mul(uint64_t a, uint64_t b) {
+  static uint64_t mprime = 0; /* -p^-1 mod 2^64 by Newton iteration */
+  if (!mprime) {
+    uint64_t inv = 1;
+    for (int i = 0; i < 6; ++i) inv *= 2 - F64_P * inv;
+    mprime = 0 - inv;
+  }
+  u128 x = (u128)a * b;
+  uint64_t q = (uint64_t)x * mprime;
+  u128 qm = (u128)q * F64_P;
+  /* (x + q m) / 2^64 without losing the carry out of 128 bits */
+  u128 lo = (u128)(uint64_t)x + (uint64_t)qm; /* low limbs: sum is 0 mod 2^64 */
+  u128 t = (x >> 64) + (qm >> 64) + (lo >> 64);
+  return (uint64_t)(t >= F64_P ? t - F64_P : t);
+}
+uint64_t lfo_f64_of_scalar(uint64_t u) { /* to_montgomery (fp_generic.h:278-287): u * R^2 * R^-1 */
+  static uint64_t r2 = 0;
+  if (!r2) {
+    u128 r = ((u128)1 << 64) % F64_P;
+    r2 = (uint64_t)((r * r) % F64_P);
+  }
+  return lfo_f64_mul(u, r2);
+}
+uint64_t lfo_f64_from_mont(uint64_t x) { return lfo_f64_mul(x, 1); }
+uint64_t lfo_f64_inv(uint64_t x) { /* x^(p-2) */
+  uint64_t r = lfo_f64_of_scalar(1), e = F64_P - 2;
+  for (; e; e >>= 1) {
+    if (e & 1) r = lfo_f64_mul(r, x);
+    x = lfo_f64_mul(x, x);
+  }
+  return r;
+}
+uint64_t lfo_f64_omega32(void) { return lfo_f64_of_scalar(2752994695033296049ull); } /* fft_test.cc:212 */
+/* Fp2 with i^2 = -1 (lib/algebra/fp2.h:79-123) */
+lfo_elt lfo_f64_2_add(lfo_elt a, lfo_elt b) { return (lfo_elt){{lfo_f64_add(a.l[0], b.l[0]), lfo_f64_add(a.l[1], b.l[1])}}; }
+lfo_elt lfo_f64_2_sub(lfo_elt a, lfo_elt b) { return (lfo_elt){{lfo_f64_sub(a.l[0], b.l[0]), lfo_f64_sub(a.l[1], b.l[1])}}; }
+lfo_elt lfo_f64_2_mul(lfo_elt a, lfo_elt b) {
+  uint64_t p0 = lfo_f64_mul(a.l[0], b.l[0]), p1 = lfo_f64_mul(a.l[1], b.l[1]);
+  uint64_t x = lfo_f64_mul(lfo_f64_add(a.l[0], a.l[1]), lfo_f64_add(b.l[0], b.l[1]));
+  return (lfo_elt){{lfo_f64_sub(p0, p1), lfo_f64_sub(lfo_f64_sub(x, p0), p1)}};
+}
+lfo_elt lfo_f64_2_inv(lfo_elt a) {
+  uint64_t d = lfo_f64_inv(lfo_f64_add(lfo_f64_mul(a.l[0], a.l[0]), lfo_f64_mul(a.l[1], a.l[1])));
+  return (lfo_elt){{lfo_f64_mul(a.l[0], d), lfo_f64_mul(lfo_f64_sub(0, a.l[1]), d)}};
+}
+/* FFT<Fp2<Fp<1>>>::fftb: the same iterative DFT as lfo_fp_fftb above, over F64_2 */
+void lfo_f64_2_fftb(lfo_elt* A, size_t n, lfo_elt omega_j, uint64_t j) {
+  if (n <= 1) return;
+  lfo_elt omega_n = omega_j;
+  for (uint64_t r = n; r < j; r += r) omega_n = lfo_f64_2_mul(omega_n, omega_n); /* twiddle.h:47-55 */
+  unsigned lg = 0;
+  while (((size_t)1 << lg) < n) ++lg;
+  for (size_t i = 0; i < n; ++i) {
+    size_t r = 0;
+    for (unsigned b = 0; b < lg; ++b)
+      if (i & ((size_t)1 << b)) r |= (size_t)1 << (lg - 1 - b);
+    if (i < r) {
+      lfo_elt t = A[i];
+      A[i] = A[r];
+      A[r] = t;
+    }
+  }
+  lfo_elt* w = (lfo_elt*)malloc(sizeof(lfo_elt) * (n / 2 ? n / 2 : 1));
+  w[0] = (lfo_elt){{lfo_f64_of_scalar(1), 0}};
+  for (size_t i = 1; i < n / 2; ++i) w[i] = lfo_f64_2_mul(w[i - 1], omega_n);
+  for (size_t m = 1; m < n; m <<= 1) {
+    size_t ws = n / (2 * m);
+    for (size_t k = 0; k < n; k += 2 * m)
+      for (size_t jj = 0; jj < m; ++jj) {
+        lfo_elt t = lfo_f64_2_mul(A[k + jj + m], w[jj * ws]);
+        lfo_elt a0 = A[k + jj];
+        A[k + jj] = lfo_f64_2_add(a0, t);
+        A[k + jj + m] = lfo_f64_2_sub(a0, t);
+      }
+  }
+  free(w);
+}
+void lfo_f64_2_fftf(lfo_elt* A, size_t n, lfo_elt omega_j, uint64_t j) { lfo_f64_2_fftb(A, n, lfo_f64_2_inv(omega_j), j); }
+
 /* ReedSolomon::interpolate + ctor (lib/algebra/reed_solomon.h:51-110) with
  * FFTConvolution (lib/algebra/convolution.h:56-106). */
 void lfo_fp_rs_interpolate(size_t n, size_t m, lfo_elt* y) {
@@ -489,6 +577,17 @@ void lfo_fp_bogorng_fill(uint64_t seed, size_t n, lfo_elt* out) {
   for (size_t i = 0; i < n; ++i) {
     x = lfo_fp_mul(x, mul);
     out[i] = x;
+  }
+}
+/* Bogorng<Fp<1>> (bogorng.h:39-51) lifted to F64_2 as in BM_FFT_F64_2 (fft_test.cc:216-220): real parts from one
+ * generator; imag != 0 fills the imaginary parts from a second one seeded seed + 17 */
+void lfo_f64_2_bogorng_fill(uint64_t seed, int imag, size_t n, lfo_elt* out) {
+  uint64_t re = lfo_f64_of_scalar(seed), im = lfo_f64_of_scalar(seed + 17), mul = lfo_f64_of_scalar(7300988u);
+  for (size_t i = 0; i < n; ++i) {
+    re = lfo_f64_mul(re, mul);
+    im = lfo_f64_mul(im, mul);
+    out[i].l[0] = re;
+    out[i].l[1] = imag ? im : 0;
   }
 }
 void lfo_gf_fill(uint64_t seed, size_t n, lfo_elt* out) {

@@ -73,6 +73,23 @@ void lfo_fp_fftf(lfo_elt* A, size_t n, lfo_elt omega_j, uint64_t j);
 /* y[0..n) = evaluations at 0..n-1 of deg<n poly -> fill y[n..m) (ReedSolomon::interpolate) */
 void lfo_fp_rs_interpolate(size_t n, size_t m, lfo_elt* y);
 
+/* ------------------------------------------------------------------ F64 = Fp<1> (p = 2^64 - 2^32 + 1) and F64_2 = Fp2<F64>
+ * (lib/algebra/fft_test.cc:205-229).  An F64_2 element is lfo_elt{l[0] = re, l[1] = im}: the memory image of Fp2<Fp<1>>::Elt. */
+uint64_t lfo_f64_add(uint64_t a, uint64_t b);
+uint64_t lfo_f64_sub(uint64_t a, uint64_t b);
+uint64_t lfo_f64_mul(uint64_t a, uint64_t b);  /* Montgomery product, R = 2^64 */
+uint64_t lfo_f64_of_scalar(uint64_t u);        /* u < p */
+uint64_t lfo_f64_from_mont(uint64_t x);
+uint64_t lfo_f64_inv(uint64_t x);
+uint64_t lfo_f64_omega32(void);                /* root of unity of order 2^32, Montgomery */
+lfo_elt lfo_f64_2_add(lfo_elt a, lfo_elt b);
+lfo_elt lfo_f64_2_sub(lfo_elt a, lfo_elt b);
+lfo_elt lfo_f64_2_mul(lfo_elt a, lfo_elt b);
+lfo_elt lfo_f64_2_inv(lfo_elt a);
+void lfo_f64_2_fftb(lfo_elt* A, size_t n, lfo_elt omega_j, uint64_t j);
+void lfo_f64_2_fftf(lfo_elt* A, size_t n, lfo_elt omega_j, uint64_t j);
+void lfo_f64_2_bogorng_fill(uint64_t seed, int imag, size_t n, lfo_elt* out);
+
 /* ------------------------------------------------------------------ field-generic (field = LFO_FIELD_*) */
 lfo_elt lfo_add(int field, lfo_elt a, lfo_elt b);
 lfo_elt lfo_sub(int field, lfo_elt a, lfo_elt b);

@@ -24,6 +24,7 @@
 #include "algebra/bogorng.h"
 #include "algebra/convolution.h"
 #include "algebra/fft.h"
+#include "algebra/fp.h"
 #include "algebra/fp2.h"
 #include "algebra/fp_p128.h"
 #include "algebra/fp_p256.h"
@@ -206,6 +207,47 @@ void ref_fp_fft(int dir, size_t n, void* A) {
   else
     FFT<FP>::fftf(a, n, omega32(), uint64_t(1) << 32, fp());
 }
+// ---- F64_2 = Fp2<Fp<1>> (lib/algebra/fft_test.cc:205-229)
+using F64 = Fp<1>;
+using F64_2 = Fp2<F64>;
+static const F64& f64() {
+  static const F64 f("18446744069414584321");
+  return f;
+}
+static const F64_2& f64_2() {
+  static const F64_2 f(f64());
+  return f;
+}
+static F64_2::Elt f64_2_omega32() {
+  static constexpr char kSmallRoot[] = "2752994695033296049";
+  return f64_2().of_string(kSmallRoot);
+}
+void ref_f64_2_binop(int op, const void* a, const void* b, void* out) {  // 0 add, 1 sub, 2 mul, 3 inverse of a
+  const auto x = ld<F64_2::Elt>(a), y = ld<F64_2::Elt>(b);
+  st(out, op == 0 ? f64_2().addf(x, y) : op == 1 ? f64_2().subf(x, y) : op == 2 ? f64_2().mulf(x, y) : f64_2().invertf(x));
+}
+void ref_f64_2_of_scalar(uint64_t re, uint64_t im, void* out) { st(out, f64_2().of_scalar_field(re, im)); }
+void ref_f64_2_omega32(void* out) { st(out, f64_2_omega32()); }
+// imag = 0: real elements as in BM_FFT_F64_2; imag = 1: a second generator fills the imaginary parts
+void ref_f64_2_bogorng_fill(uint64_t seed, int imag, size_t n, void* out) {
+  Bogorng<F64> re(&f64(), seed), im(&f64(), seed + 17);
+  auto* o = reinterpret_cast<F64_2::Elt*>(out);
+  for (size_t i = 0; i < n; ++i) {
+    o[i] = f64_2().of_scalar(re.next());
+    if (imag) o[i].im = im.next();
+  }
+}
+// omega == nullptr: the real root of order 2^32; else any root of that order (an Fp2 element)
+void ref_f64_2_fft(int dir, size_t n, const void* omega, void* A) {
+  static_assert(sizeof(F64_2::Elt) == 16, "F64_2 element is two 64-bit limbs");
+  auto* a = reinterpret_cast<F64_2::Elt*>(A);
+  const F64_2::Elt w = omega ? ld<F64_2::Elt>(omega) : f64_2_omega32();
+  if (dir == 0)
+    FFT<F64_2>::fftb(a, n, w, uint64_t(1) << 32, f64_2());
+  else
+    FFT<F64_2>::fftf(a, n, w, uint64_t(1) << 32, f64_2());
+}
+
 void ref_fp_rs_interpolate(size_t n, size_t m, void* y) {
   FFTConvolutionFactory<FP> cf(fp(), omega32(), uint64_t(1) << 32);
   ReedSolomonFactory<FP, FFTConvolutionFactory<FP>> rsf(cf, fp());

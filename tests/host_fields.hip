@@ -9,6 +9,12 @@ void hf_fp_add(const u64* a, const u64* b, u64* o) { elt_t r = fp_add(elt_t{a[0]
 void hf_fp_sub(const u64* a, const u64* b, u64* o) { elt_t r = fp_sub(elt_t{a[0], a[1]}, elt_t{b[0], b[1]}); o[0] = r.lo; o[1] = r.hi; }
 void hf_fp_reduce_limbs(const u64* a, u64* o) { elt_t r = fp_reduce_limbs(a[0], a[1], a[2], a[3]); o[0] = r.lo; o[1] = r.hi; }
 void hf_gf_mul(const u64* a, const u64* b, u64* o) { elt_t r = gf_mul(elt_t{a[0], a[1]}, elt_t{b[0], b[1]}); o[0] = r.lo; o[1] = r.hi; }
+// F64 (p = 2^64 - 2^32 + 1, shift-only Montgomery reduction) and F64_2 = Fp2<F64>: n pairs at once
+void hf_f64_mul_many(size_t n, const u64* a, const u64* b, u64* o) { for (size_t i = 0; i < n; ++i) o[i] = f64_mul(a[i], b[i]); }
+void hf_f64_add_many(size_t n, const u64* a, const u64* b, u64* o) { for (size_t i = 0; i < n; ++i) o[i] = f64_add(a[i], b[i]); }
+void hf_f64_sub_many(size_t n, const u64* a, const u64* b, u64* o) { for (size_t i = 0; i < n; ++i) o[i] = f64_sub(a[i], b[i]); }
+void hf_f64x2_mul(const u64* a, const u64* b, u64* o) { elt_t r = f64x2_mul(elt_t{a[0], a[1]}, elt_t{b[0], b[1]}); o[0] = r.lo; o[1] = r.hi; }
+void hf_f64x2_mul_real(const u64* a, const u64* b, u64* o) { elt_t r = f64x2_mul_real(elt_t{a[0], a[1]}, b[0]); o[0] = r.lo; o[1] = r.hi; }
 // SHA-256 of nblk whole 64-byte blocks (no padding): returns raw state words
 void hf_sha_blocks(const unsigned char* p, unsigned nblk, u32* h) {
   sha_state s;

@@ -100,6 +100,13 @@ def oracle():
         "lfo_fp_inv": (Elt, [Elt]), "lfo_fp_omega32": (Elt, []),
         "lfo_fp_fftb": (None, [vp, sz, Elt, u64]), "lfo_fp_fftf": (None, [vp, sz, Elt, u64]),
         "lfo_fp_rs_interpolate": (None, [sz, sz, vp]),
+        "lfo_f64_add": (u64, [u64, u64]), "lfo_f64_sub": (u64, [u64, u64]), "lfo_f64_mul": (u64, [u64, u64]),
+        "lfo_f64_of_scalar": (u64, [u64]), "lfo_f64_from_mont": (u64, [u64]), "lfo_f64_inv": (u64, [u64]),
+        "lfo_f64_omega32": (u64, []),
+        "lfo_f64_2_add": (Elt, [Elt, Elt]), "lfo_f64_2_sub": (Elt, [Elt, Elt]), "lfo_f64_2_mul": (Elt, [Elt, Elt]),
+        "lfo_f64_2_inv": (Elt, [Elt]),
+        "lfo_f64_2_fftb": (None, [vp, sz, Elt, u64]), "lfo_f64_2_fftf": (None, [vp, sz, Elt, u64]),
+        "lfo_f64_2_bogorng_fill": (None, [u64, ci, sz, vp]),
         "lfo_add": (Elt, [ci, Elt, Elt]), "lfo_sub": (Elt, [ci, Elt, Elt]), "lfo_mul": (Elt, [ci, Elt, Elt]),
         "lfo_sha256_init": (None, [vp]), "lfo_sha256_update": (None, [vp, vp, sz]),
         "lfo_sha256_final": (None, [vp, vp]),
@@ -168,6 +175,9 @@ def ref():
         "ref_fp_inv": (None, [vp, vp]), "ref_fp_of_scalar": (None, [u64, vp]), "ref_fp_from_mont": (None, [vp, vp]),
         "ref_fp_omega32": (None, [vp]), "ref_fp_bogorng_fill": (None, [u64, sz, vp]),
         "ref_fp_fft": (None, [ci, sz, vp]), "ref_fp_rs_interpolate": (None, [sz, sz, vp]),
+        "ref_f64_2_binop": (None, [ci, vp, vp, vp]), "ref_f64_2_of_scalar": (None, [u64, u64, vp]),
+        "ref_f64_2_omega32": (None, [vp]), "ref_f64_2_bogorng_fill": (None, [u64, ci, sz, vp]),
+        "ref_f64_2_fft": (None, [ci, sz, vp, vp]),
         "ref_merkle_build_tree": (None, [sz, vp, vp]),
         "ref_column_commit": (None, [ci, sz, sz, sz, sz, vp, vp, vp]),
         "ref_sumcheck_evaluations": (None, [ci, sz, vp, vp, vp, vp, vp]),

@@ -52,6 +52,36 @@ def test_fp_ops_match_oracle():
         assert (_bin(L.hf_fp_sub, x, y) == arr(o.lfo_fp_sub(elt(x), elt(y)))).all()
 
 
+def test_f64_ops_match_big_integers_and_oracle():
+    """F64 = Fp<1> over p = 2^64 - 2^32 + 1: the shift-only Montgomery reduction of fields.h (f64_mul) against Python
+    integers on edge values and 200 000 random pairs, then F64_2 products against the oracle"""
+    L, o = _lib(), ol.oracle()
+    p = 2**64 - 2**32 + 1
+    rinv = pow(1 << 64, -1, p)
+    rng = np.random.default_rng(11)
+    edge = [0, 1, 2, 0xFFFFFFFF, 1 << 32, (1 << 32) + 1, p - 1, p - 2, (p - 1) // 2, 0xFFFFFFFF00000000, 0xFFFFFFFE00000001,
+            0x8000000000000000, 0x7FFFFFFFFFFFFFFF, 0x00000000FFFFFFFE]
+    pairs = [(a, b) for a in edge for b in edge]
+    n = 200000
+    ra = (rng.integers(0, 1 << 63, size=n, dtype=np.uint64).astype(object) * 2 + rng.integers(0, 2, size=n).astype(object)) % p
+    rb = (rng.integers(0, 1 << 63, size=n, dtype=np.uint64).astype(object) * 2 + rng.integers(0, 2, size=n).astype(object)) % p
+    A = np.array([x for x, _ in pairs] + list(ra), dtype=np.uint64)
+    B = np.array([y for _, y in pairs] + list(rb), dtype=np.uint64)
+    out = np.zeros_like(A)
+    ai, bi = [int(x) for x in A], [int(x) for x in B]
+    L.hf_f64_mul_many(C.c_size_t(len(A)), P(A), P(B), P(out))
+    assert [int(x) for x in out] == [(x * y * rinv) % p for x, y in zip(ai, bi)]
+    L.hf_f64_add_many(C.c_size_t(len(A)), P(A), P(B), P(out))
+    assert [int(x) for x in out] == [(x + y) % p for x, y in zip(ai, bi)]
+    L.hf_f64_sub_many(C.c_size_t(len(A)), P(A), P(B), P(out))
+    assert [int(x) for x in out] == [(x - y) % p for x, y in zip(ai, bi)]
+    for i in range(0, 2000, 2):
+        a, b = A[i:i + 2].copy(), B[i:i + 2].copy()
+        assert (_bin(L.hf_f64x2_mul, a, b) == arr(o.lfo_f64_2_mul(elt(a), elt(b)))).all()
+        b[1] = 0
+        assert (_bin(L.hf_f64x2_mul_real, a, b) == arr(o.lfo_f64_2_mul(elt(a), elt(b)))).all()
+
+
 def test_fp_reduce_limbs_matches_big_integers():
     """fp_reduce_limbs: sum_k a_k 2^(32k) mod p for u64 limb accumulators, incl. the extreme words"""
     L = _lib()

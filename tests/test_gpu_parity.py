@@ -1,6 +1,7 @@
 """GPU parity: every kernel, called through the C ABI, against the CPU oracle on the same
 seeded inputs -- bit-exact (integer / GF(2) arithmetic, no tolerance)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -135,6 +136,93 @@ def test_fp128_fft_beyond_2pow20(G, logn, rows):
     nn = o.lfo_fp_of_scalar(n)
     for i in list(range(0, n, 262139))[:40] + [n - 1]:
         assert (got[0, i] == arr(o.lfo_fp_mul(elt(a[0, i]), nn))).all()
+
+
+# ---------------------------------------------------------------- K1 over F64_2 = Fp2<Fp<1>> (fft_test.cc:205-229)
+def _f64_2_roots(o):
+    w_real = np.array([o.lfo_f64_omega32(), 0], dtype=np.uint64)
+    w_cplx = arr(o.lfo_f64_2_mul(elt(w_real), elt(np.array([0, o.lfo_f64_of_scalar(1)], dtype=np.uint64))))  # omega * i: order 2^32 too
+    return {"real": w_real, "times_i": w_cplx}
+
+
+@pytest.mark.parametrize("n,rows", [(2, 1), (4, 3), (64, 5), (1024, 2), (4096, 9), (8192, 3), (1 << 14, 2), (1 << 16, 1), (1 << 17, 2)])
+@pytest.mark.parametrize("forward", [False, True])
+@pytest.mark.parametrize("root", ["real", "times_i"])
+def test_f64_2_fft(G, n, rows, forward, root):
+    """FFT<Fp2<Fp<1>>>::fftb / fftf against the oracle: the real root of the reference's test (two base-field products
+    per twiddle) and a root outside the base field (the general three-product Fp2 multiplication)"""
+    o = ol.oracle()
+    w = _f64_2_roots(o)[root]
+    a = np.zeros((rows, n, 2), dtype=np.uint64)
+    for r in range(rows):
+        o.lfo_f64_2_bogorng_fill(1234569 + r, 1, n, P(a[r]))
+    want = a.copy()
+    for r in range(rows):
+        (o.lfo_f64_2_fftf if forward else o.lfo_f64_2_fftb)(P(want[r]), n, elt(w), 1 << 32)
+    d = G.to_dev(a)
+    G.gpu().f64_2_fft(d.data_ptr(), rows, n, forward=forward, omega=(int(w[0]), int(w[1])))
+    assert (G.from_dev(d, np.uint64, (rows, n, 2)) == want).all()
+
+
+def test_f64_2_fft_golden_through_the_device(G):
+    """tests/golden/f64_2.json (outputs of the reference itself, oracle/gen_golden_f64.py) through the HIP path"""
+    import hashlib
+    import json
+    o = ol.oracle()
+    with open(os.path.join(ol.ROOT, "tests", "golden", "f64_2.json")) as f:
+        g64 = json.load(f)
+    roots = {k: np.frombuffer(bytes.fromhex(g64[k2]), dtype=np.uint64) for k, k2 in (("real", "omega32"), ("times_i", "omega32_times_i"))}
+    for v in g64["fft"]:
+        a = np.zeros((v["n"], 2), dtype=np.uint64)
+        o.lfo_f64_2_bogorng_fill(v["bogorng_seed"], v["imag"], v["n"], P(a))
+        w = roots[v["root"]]
+        G.gpu().f64_2_fft_host(a, forward=bool(v["dir"]), omega=(int(w[0]), int(w[1])))
+        assert hashlib.sha256(a.tobytes()).hexdigest() == v["out_sha256"], v["n"]
+
+
+def test_f64_2_fft_strided_rows_noop_and_errors(G):
+    o = ol.oracle()
+    n, ld, rows = 256, 300, 4
+    a = np.zeros((rows, ld, 2), dtype=np.uint64)
+    o.lfo_f64_2_bogorng_fill(99, 1, rows * ld, P(a))
+    w = _f64_2_roots(o)["real"]
+    want = a.copy()
+    for r in range(rows):
+        o.lfo_f64_2_fftb(P(want[r]), n, elt(w), 1 << 32)
+    d = G.to_dev(a)
+    G.gpu().f64_2_fft(d.data_ptr(), rows, n, ld=ld)
+    assert (G.from_dev(d, np.uint64, (rows, ld, 2)) == want).all()
+    G.gpu().f64_2_fft(d.data_ptr(), rows, 1, ld=ld)
+    G.gpu().f64_2_fft(d.data_ptr(), 0, n, ld=ld)
+    assert (G.from_dev(d, np.uint64, (rows, ld, 2)) == want).all()
+    with pytest.raises(G.pkg.LfGpuError):
+        G.gpu().f64_2_fft(d.data_ptr(), 1, 96, ld=ld)  # not a power of two
+    with pytest.raises(G.pkg.LfGpuError):
+        G.gpu().f64_2_fft(d.data_ptr(), 1, n, ld=ld, omega=(2**64 - 1, 0))  # not a reduced field element
+
+
+@pytest.mark.parametrize("logn,rows,root", [(20, 2, "real"), (20, 1, "times_i"), (22, 1, "real")])
+def test_f64_2_fft_benchmark_sizes_vs_oracle(G, logn, rows, root):
+    """the sizes of BM_FFT_F64_2 the two- and three-pass plans serve (2^20, 2^22 = the benchmark's largest), whole rows
+    against the oracle, then fftf(fftb(x)) = n x"""
+    o = ol.oracle()
+    w = _f64_2_roots(o)[root]
+    n = 1 << logn
+    a = np.zeros((rows, n, 2), dtype=np.uint64)
+    for r in range(rows):
+        o.lfo_f64_2_bogorng_fill(4242 + r + logn, 1, n, P(a[r]))
+    want = a.copy()
+    for r in range(rows):
+        o.lfo_f64_2_fftb(P(want[r]), n, elt(w), 1 << 32)
+    d = G.to_dev(a)
+    om = (int(w[0]), int(w[1]))
+    G.gpu().f64_2_fft(d.data_ptr(), rows, n, omega=om)
+    assert (G.from_dev(d, np.uint64, a.shape) == want).all()
+    G.gpu().f64_2_fft(d.data_ptr(), rows, n, forward=True, omega=om)
+    got = G.from_dev(d, np.uint64, a.shape)
+    nn = o.lfo_f64_of_scalar(n)
+    for i in list(range(0, n, 65521))[:64] + [n - 1]:
+        assert int(got[0, i, 0]) == o.lfo_f64_mul(int(a[0, i, 0]), nn) and int(got[0, i, 1]) == o.lfo_f64_mul(int(a[0, i, 1]), nn)
 
 
 @pytest.mark.parametrize("l,rows", [(21, 1), (22, 2), (21, 32), (22, 32)])

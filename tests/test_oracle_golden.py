@@ -216,3 +216,27 @@ def test_cpp_commitment_fixture():
     assert lay[1].tobytes() == root
     assert [all_nonces[i] for i in idx] == nonces
     assert host_open(lay, n, idx) == path
+
+
+def test_f64_2_fft_golden():
+    """FFT<Fp2<Fp<1>>> (lib/algebra/fft_test.cc:205-229): the oracle against tests/golden/f64_2.json, written from the
+    reference itself by oracle/gen_golden_f64.py"""
+    with open(os.path.join(ol.ROOT, "tests", "golden", "f64_2.json")) as f:
+        g64 = json.load(f)
+    o = ol.oracle()
+    fns = (o.lfo_f64_2_add, o.lfo_f64_2_sub, o.lfo_f64_2_mul)
+    for v in g64["binop"]:
+        a, b = np.frombuffer(bytes.fromhex(v["a"]), dtype=np.uint64), np.frombuffer(bytes.fromhex(v["b"]), dtype=np.uint64)
+        got = o.lfo_f64_2_inv(ol.elt(a)) if v["op"] == 3 else fns[v["op"]](ol.elt(a), ol.elt(b))
+        assert ol.arr(got).tobytes().hex() == v["out"]
+    roots = {"real": np.frombuffer(bytes.fromhex(g64["omega32"]), dtype=np.uint64),
+             "times_i": np.frombuffer(bytes.fromhex(g64["omega32_times_i"]), dtype=np.uint64)}
+    assert int(roots["real"][0]) == o.lfo_f64_omega32() and int(roots["real"][1]) == 0
+    for v in g64["fft"]:
+        a = np.zeros((v["n"], 2), dtype=np.uint64)
+        o.lfo_f64_2_bogorng_fill(v["bogorng_seed"], v["imag"], v["n"], P(a))
+        assert a[:2].tobytes().hex() == v["in_first"]
+        (o.lfo_f64_2_fftf if v["dir"] else o.lfo_f64_2_fftb)(P(a), v["n"], ol.elt(roots[v["root"]]), 1 << 32)
+        assert sha(a) == v["out_sha256"]
+        if v["out"]:
+            assert a.tobytes().hex() == v["out"]

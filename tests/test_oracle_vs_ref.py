@@ -267,3 +267,59 @@ def test_eval_quad_bind_g_raw_eq2(field, logv, logw, nterms, n_assert):
     nb = r.ref_quad_bind_g(field, L["n"], P(L["g"]), P(L["h0"]), P(L["h1"]), P(L["vi"]), len(L["kvec"]), P(L["kvec"]), logv,
                            P(G0), P(G1), P(alpha), P(beta), P(hb), P(vb))
     assert na == nb and (ha[:na] == hb[:nb]).all() and (va[:na] == vb[:nb]).all()
+
+
+# ---------------------------------------------------------------- F64_2 = Fp2<Fp<1>>, p = 2^64 - 2^32 + 1
+F64_P = 2**64 - 2**32 + 1
+
+
+def _f64_2_edge_and_random(n, seed):
+    rng = np.random.default_rng(seed)
+    edge = [0, 1, 2, 0xFFFFFFFF, 1 << 32, F64_P - 1, F64_P - 2, (F64_P - 1) // 2, 0xFFFFFFFF00000000]
+    vals = edge + [int(x) % F64_P for x in rng.integers(0, 2**63, size=n, dtype=np.uint64) * 2 + rng.integers(0, 2, size=n, dtype=np.uint64)]
+    return vals
+
+
+def test_f64_2_arithmetic():
+    """the oracle's one-limb Montgomery arithmetic and Fp2 against Fp2<Fp<1>> of the reference, edge values included"""
+    o, r = ol.oracle(), ol.ref()
+    vals = _f64_2_edge_and_random(40, 5)
+    out = np.zeros(2, dtype=np.uint64)
+    for i, re in enumerate(vals):
+        a = np.array([re, vals[(i * 7 + 3) % len(vals)]], dtype=np.uint64)
+        b = np.array([vals[(i * 5 + 1) % len(vals)], vals[(i * 11 + 2) % len(vals)]], dtype=np.uint64)
+        for op, fn in ((0, o.lfo_f64_2_add), (1, o.lfo_f64_2_sub), (2, o.lfo_f64_2_mul)):
+            r.ref_f64_2_binop(op, P(a), P(b), P(out))
+            assert (arr(fn(elt(a), elt(b))) == out).all(), (op, a, b)
+        if a.any():
+            r.ref_f64_2_binop(3, P(a), P(b), P(out))
+            assert (arr(o.lfo_f64_2_inv(elt(a))) == out).all()
+    for u in (0, 1, 2, 12345, F64_P - 1):
+        r.ref_f64_2_of_scalar(u, (u * 3) % F64_P, P(out))
+        assert int(out[0]) == o.lfo_f64_of_scalar(u) and int(out[1]) == o.lfo_f64_of_scalar((u * 3) % F64_P)
+        assert o.lfo_f64_from_mont(o.lfo_f64_of_scalar(u)) == u
+    r.ref_f64_2_omega32(P(out))
+    assert int(out[0]) == o.lfo_f64_omega32() and int(out[1]) == 0
+    a = np.zeros((50, 2), dtype=np.uint64)
+    b = np.zeros((50, 2), dtype=np.uint64)
+    for imag in (0, 1):
+        o.lfo_f64_2_bogorng_fill(1234569, imag, 50, P(a))
+        r.ref_f64_2_bogorng_fill(1234569, imag, 50, P(b))
+        assert (a == b).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 64, 1024, 1 << 14, 1 << 15, 1 << 17])
+def test_f64_2_fft(n):
+    """FFT<Fp2<Fp<1>>>::fftb / fftf (lib/algebra/fft_test.cc:205-229) -- basecase and the recursive path -- with the
+    real root of the reference's test and with a root that has an imaginary part (omega_real * i has order 2^32 too)"""
+    o, r = ol.oracle(), ol.ref()
+    a = np.zeros((n, 2), dtype=np.uint64)
+    o.lfo_f64_2_bogorng_fill(1234569 + n, 1, n, P(a))
+    w_real = np.array([o.lfo_f64_omega32(), 0], dtype=np.uint64)
+    w_cplx = arr(o.lfo_f64_2_mul(elt(w_real), elt(np.array([0, o.lfo_f64_of_scalar(1)], dtype=np.uint64))))
+    for w in (w_real, w_cplx):
+        for d, fn in ((0, o.lfo_f64_2_fftb), (1, o.lfo_f64_2_fftf)):
+            x, y = a.copy(), a.copy()
+            fn(P(x), n, elt(w), 1 << 32)
+            r.ref_f64_2_fft(d, n, P(w), P(y))
+            assert (x == y).all()
