@@ -472,19 +472,19 @@ LF_HD elt_t fp_reduce_limbs(u64 a0, u64 a1, u64 a2, u64 a3) {
 // in Montgomery form with R = 2^64, canonical in [0, p).  F64_2 = Fp2<F64> with i^2 = -1 (lib/algebra/fp2.h:36-52):
 // elt_t{lo = re, hi = im}, the memory image of Fp2<Fp<1>>::Elt.
 #define F64_P 0xFFFFFFFF00000001ull
-LF_HD u64 f64_add(u64 a, u64 b) {
+LF_HD u64 f64_add_c(u64 a, u64 b) {
   u64 s = a + b;
   if (s < a || s >= F64_P) s -= F64_P;
   return s;
 }
-LF_HD u64 f64_sub(u64 a, u64 b) {
+LF_HD u64 f64_sub_c(u64 a, u64 b) {
   u64 d = a - b;
   if (a < b) d += F64_P;
   return d;
 }
 // Montgomery product a b 2^-64 mod p.  p^-1 = 2^32 + 1 (mod 2^64), so m = lo (2^32 + 1) has m p = lo (mod 2^64) and
 // (a b - m p) / 2^64 = hi - floor(m p / 2^64) exactly; with m p = m 2^64 - m (2^32 - 1) the floor needs shifts only.
-LF_HD u64 f64_mul(u64 a, u64 b) {
+LF_HD u64 f64_mul_c(u64 a, u64 b) {
   u64 lo, hi;
   mul64(a, b, lo, hi);
   const u64 m = lo + (lo << 32);
@@ -494,6 +494,74 @@ LF_HD u64 f64_mul(u64 a, u64 b) {
   if (hi < mh) t += F64_P;
   return t;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 versions on 32-bit limbs (see the Fp128 ones above for the VCC wait states).  hipcc's lowering of the portable code
+// takes ~45 VALU instructions per product (64-bit compares and selects for every carry); these take 14, 5 and 7.
+__device__ __forceinline__ u64 f64_sub(u64 a, u64 b) {  // a - b, then - (2^32 - 1) (= + p mod 2^64) on borrow
+  u32 d0, d1, m;
+  asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %1, vcc, %4, %6, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+      : "=&v"(d0), "=&v"(d1), "=&v"(m)
+      : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+      : "vcc");
+  return ((u64)d1 << 32) | d0;
+}
+__device__ __forceinline__ u64 f64_add(u64 a, u64 b) {  // a - (p - b): p - b needs no reduction and b = 0 comes out right
+  u32 n0, n1;
+  asm("v_sub_co_u32 %0, vcc, 1, %2\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %1, vcc, -1, %3, vcc"
+      : "=&v"(n0), "=&v"(n1)
+      : "v"((u32)b), "v"((u32)(b >> 32))
+      : "vcc");
+  return f64_sub(a, ((u64)n1 << 32) | n0);
+}
+__device__ __forceinline__ u64 f64_mul(u64 a, u64 b) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 t0 = 0;
+  FP_MAD(t0, a0, b0);
+  u64 t1 = t0 >> 32;
+  FP_MAD(t1, a0, b1);  // < 2^64: (2^32 - 1)^2 + 2^32 - 1
+  u64 t2 = (u32)t1;
+  FP_MAD(t2, a1, b0);
+  u64 t3 = (t1 >> 32) + (t2 >> 32);
+  FP_MAD(t3, a1, b1);
+  // x = (l0, l1, h0, h1).  With a = lo + (lo << 32) (carry e) and b = a - (a >> 32) - e the result is hi - b, plus p on borrow:
+  // the same m and floor(m p / 2^64) as f64_mul_c, the carry e standing for its two comparisons.
+  u32 r0, r1, x, y, z;
+  asm("v_add_co_u32 %2, vcc, %6, %5\n\t"       // x = a1 = l1 + l0, e
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %3, vcc, %5, %2, vcc\n\t"  // y = b0 = l0 - a1 - e
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %2, vcc, 0, %2, vcc\n\t"  // x = b1 = a1 - borrow
+      "v_sub_co_u32 %0, vcc, %7, %3\n\t"        // r = hi - b
+      "s_nop 1\n\t"
+      "v_subb_co_u32 %1, vcc, %8, %2, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_cndmask_b32 %4, 0, -1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %4\n\t"
+      "s_nop 1\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(x), "=&v"(y), "=&v"(z)
+      : "v"((u32)t0), "v"((u32)t2), "v"((u32)t3), "v"((u32)(t3 >> 32))
+      : "vcc");
+  return ((u64)r1 << 32) | r0;
+}
+// host functions parsed during the device pass resolve to these overloads
+__host__ inline u64 f64_add(u64 a, u64 b) { return f64_add_c(a, b); }
+__host__ inline u64 f64_sub(u64 a, u64 b) { return f64_sub_c(a, b); }
+__host__ inline u64 f64_mul(u64 a, u64 b) { return f64_mul_c(a, b); }
+#else
+LF_HD u64 f64_add(u64 a, u64 b) { return f64_add_c(a, b); }
+LF_HD u64 f64_sub(u64 a, u64 b) { return f64_sub_c(a, b); }
+LF_HD u64 f64_mul(u64 a, u64 b) { return f64_mul_c(a, b); }
+#endif
 LF_HD elt_t f64x2_add(elt_t a, elt_t b) { return elt_t{f64_add(a.lo, b.lo), f64_add(a.hi, b.hi)}; }
 LF_HD elt_t f64x2_sub(elt_t a, elt_t b) { return elt_t{f64_sub(a.lo, b.lo), f64_sub(a.hi, b.hi)}; }
 LF_HD elt_t f64x2_mul(elt_t a, elt_t b) {  // Fp2::mul (fp2.h:87-101): three base-field products

@@ -600,7 +600,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   size_t nh = 0;
   static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
   auto clk = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t_large = 0, t_small_first = 0, t_cb = 0;
+  double t_large = 0, t_small_first = 0, t_cb = 0, t_think = 0, t_seen = 0;
   size_t n_large = 0;
   int cur = 0;
   const elt_t al{alpha[0], alpha[1]};
@@ -694,7 +694,9 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
         }
         resident = true;
         u64 out[8];
+        if (verbose && t_seen != 0) t_think += clk() - t_seen;  // post seen -> answer written: the host's share of the round trip
         LF_TRY(lf_sc_layer_next(c, have_r ? last_r : nullptr, out));
+        if (verbose) t_seen = clk();
         a0[0] = out[0]; a0[1] = out[1]; a2[0] = out[2]; a2[1] = out[3];
       } else if (small) {
         u64 out[8];
@@ -778,8 +780,8 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     LF_HIP(c, hipStreamSynchronize(c->stream));
   }
   if (verbose)
-    fprintf(stderr, "lfgpu sumcheck_layer: nterms %zu nh0 %zu nw %zu logw %zu | bind_g %.0f us | %zu large round-hands %.0f us | %zu small %.0f us | caller's round callback %.1f us in all\n",
-            nt, nh0, nw, logw, tv1 - tv0, n_large, t_large, 2 * logw - n_large, t_small_first ? clk() - t_small_first : 0.0, t_cb);
+    fprintf(stderr, "lfgpu sumcheck_layer: nterms %zu nh0 %zu nw %zu logw %zu | bind_g %.0f us | %zu large round-hands %.0f us | %zu small %.0f us | caller's round callback %.1f us in all, host between post and answer %.1f us\n",
+            nt, nh0, nw, logw, tv1 - tv0, n_large, t_large, 2 * logw - n_large, t_small_first ? clk() - t_small_first : 0.0, t_cb, t_think);
   wc_out[0][0] = tmp[0];
   wc_out[0][1] = tmp[1];
   wc_out[1][0] = tmp[2];

@@ -738,12 +738,12 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
     }
   }
 #ifdef LF_SC_PROF
-  u64 pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 pt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // [8]: round-hands counted
   u64 tl = wall_clock64();
 #ifdef LF_SC_PROF_LO  // only the round-hands whose largest array holds (LF_SC_PROF_LO, LF_SC_PROF_HI] entries
-#define SC_LAP(k) do { const u64 tn_ = wall_clock64(); const u32 bg_ = max(nh, max(nW[0], nW[1])); if (bg_ > LF_SC_PROF_LO && bg_ <= LF_SC_PROF_HI) pt[k] += tn_ - tl; tl = tn_; } while (0)
+#define SC_LAP(k) do { const u64 tn_ = wall_clock64(); const u32 bg_ = max(nh, max(nW[0], nW[1])); if (bg_ > LF_SC_PROF_LO && bg_ <= LF_SC_PROF_HI) { pt[k] += tn_ - tl; if (k == 1) ++pt[8]; } tl = tn_; } while (0)
 #else
-#define SC_LAP(k) do { const u64 tn_ = wall_clock64(); pt[k] += tn_ - tl; tl = tn_; } while (0)
+#define SC_LAP(k) do { const u64 tn_ = wall_clock64(); pt[k] += tn_ - tl; if (k == 1) ++pt[8]; tl = tn_; } while (0)
 #endif
 #else
 #define SC_LAP(k) do { } while (0)
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
   }
 #ifdef LF_SC_PROF
   if (g == 0 && tid == 0)
-    for (int k = 0; k < 8; ++k) a.post[16 + k] = pt[k];
+    for (int k = 0; k < 9; ++k) a.post[16 + k] = pt[k];
 #endif
   if (g == 0 && tid == 0) {  // end of the layer: W[R,C], W[L,C] and HQUAD->scalar()
     const elt_t w0 = nW[0] ? ld16(&W[0][0]) : elt_zero();
@@ -1318,14 +1318,14 @@ int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]) {
     }
   }
   if (c->poll_next == c->poll_seq + 1) {  // final post of a layer: fold the phase clocks
-    static u64 tot[8];
+    static u64 tot[9];
     static int layers = 0;
-    for (int k = 0; k < 8; ++k) tot[k] += c->poll_h[16 + k];
+    for (int k = 0; k < 9; ++k) tot[k] += c->poll_h[16 + k];
     if (++layers % 13 == 0) {
-      fprintf(stderr, "sc_grid phases (us, %d layers): bar1 %.0f shrink %.0f sums+post %.0f counts %.0f bar2 %.0f layout %.0f wait %.0f bind+scatter %.0f\n", layers,
-              tot[0] * 1e3 / c->wall_khz, tot[1] * 1e3 / c->wall_khz, tot[2] * 1e3 / c->wall_khz, tot[3] * 1e3 / c->wall_khz,
+      fprintf(stderr, "sc_grid phases (us, %d layers, %llu round-hands counted): bar1 %.0f shrink %.0f sums+post %.0f counts %.0f bar2 %.0f layout %.0f wait %.0f bind+scatter %.0f\n", layers,
+              (unsigned long long)tot[8], tot[0] * 1e3 / c->wall_khz, tot[1] * 1e3 / c->wall_khz, tot[2] * 1e3 / c->wall_khz, tot[3] * 1e3 / c->wall_khz,
               tot[4] * 1e3 / c->wall_khz, tot[5] * 1e3 / c->wall_khz, tot[6] * 1e3 / c->wall_khz, tot[7] * 1e3 / c->wall_khz);
-      for (int k = 0; k < 8; ++k) tot[k] = 0;
+      for (int k = 0; k < 9; ++k) tot[k] = 0;
     }
   }
 #endif
