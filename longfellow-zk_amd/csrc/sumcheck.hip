@@ -601,7 +601,9 @@ struct ScGrid {
   u32 two_level;    // 1: two-level arrival tickets (A/B)
   u32 split_waves;  // 1: with one workgroup left, independent products go to different waves
   u32 per_wg;       // entries of the largest array per active workgroup (the grid shrinks to keep it)
+  u32 wave_tail;    // 1: once everything fits 64 entries, ONE wave finishes the layer (no workgroup barriers)
 };
+#define SC_WAVE_TAIL 64u
 #define SC_TAIL 1024u
 #define SC_TAIL_LDS_BYTES (2 * SC_TAIL * 8 + 2 * SC_TAIL * 16 + 4 * SC_TAIL * 16 + SC_TAIL * 32 + SC_TAIL * 4)
 
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
   u64* QWn = a.QW2;  // of the next evaluation: filled while the current hand is bound (one buffer once in LDS)
   u32* src = a.src;
   elt_t* Wdst[2][2] = {{a.Wb[0][0], a.Wb[0][1]}, {a.Wb[1][0], a.Wb[1][1]}};
-  bool in_lds = false;
+  bool in_lds = false, wave_mode = false;
   extern __shared__ __attribute__((aligned(16))) unsigned char sc_dyn[];
   u32 gen = 0;
   u64 seq = a.seq0;
@@ -791,6 +793,158 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         src = (u32*)(qwL + 4 * SC_TAIL);
         in_lds = true;
       }
+    }
+    // ---- the last rounds of a layer: at most 64 entries in every array.  A lone wave issues one instruction at a time, so
+    // what a round-hand costs here is the number of instructions on its critical path plus a workgroup barrier (sixteen
+    // waves to collect) per phase.  From here on wave 0 finishes the layer alone: both sums in ONE product (lanes 0-31
+    // the a0 terms, lanes 32-63 the a2 terms), both binds in one product when they fit the wave together, the layout by
+    // ballot, reductions by shuffles -- no workgroup barrier is left (the other waves have ended; a barrier of one wave
+    // is a wait for its own memory operations).  Same field operations on the same operands as the phases below.
+    if (G == 1 && in_lds && a.wave_tail && !wave_mode && nh <= SC_WAVE_TAIL && nW[0] <= SC_WAVE_TAIL && nW[1] <= SC_WAVE_TAIL) {
+      if (wave != 0) return;  // the barrier at the top of the loop was their last one: everything they wrote is visible
+      wave_mode = true;
+    }
+    if (wave_mode) {
+      const u32 nq = nW[hand], nodd = nq / 2;
+      const elt_t* Wh = W[hand];
+      auto qw_at = [&](u32 j) -> elt_t {
+        if (F == FIELD_GF2_128) return elt_t{QW[2 * (size_t)j], QW[2 * (size_t)j + 1]};
+        const u64* q = QW + 4 * (size_t)j;
+        return fp_reduce_limbs(q[0], q[1], q[2], q[3]);
+      };
+      elt_t x = elt_zero(), y = elt_zero();
+      {
+        const u32 i = lane & 31;
+        if (i < nodd) {
+          const elt_t q0 = qw_at(2 * i), w0 = ld16(&Wh[2 * i]);
+          if (lane < 32) {
+            x = q0;
+            y = w0;
+          } else {
+            x = Fld<F>::sub(qw_at(2 * i + 1), q0);
+            y = Fld<F>::sub(ld16(&Wh[2 * i + 1]), w0);
+          }
+        } else if (i == nodd && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388): in both sums
+          x = qw_at(2 * nodd);
+          y = ld16(&Wh[2 * nodd]);
+        }
+      }
+      elt_t t = Fld<F>::mul(x, y);
+      for (int off = 16; off > 0; off >>= 1) {  // sums inside each half of the wave
+        elt_t o;
+        o.lo = __shfl_down(t.lo, off, 32);
+        o.hi = __shfl_down(t.hi, off, 32);
+        t = Fld<F>::add(t, o);
+      }
+      const elt_t a2{__shfl(t.lo, 32, 64), __shfl(t.hi, 32, 64)};
+      if (lane == 0) {
+        u64* po = (u64*)a.post;
+        __hip_atomic_store(&po[0], t.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[1], t.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[2], a2.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[3], a2.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[4], (u64)nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[8], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&po[5], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      // layout of HQuad::bind_h (no challenge needed): lane i looks at entry i
+      const bool head = lane < nh && !is_second(hc, lane, hand);
+      const u64 hmask = __ballot(head);
+      const u32 new_nh = (u32)__popcll(hmask);
+      if (head) {
+        const u32 off = (u32)__popcll(hmask & ((1ull << lane) - 1));
+        uint2 h = hc[lane];
+        const u32 hh = hand ? h.y : h.x;
+        const u32 kind = (lane + 1 < nh && is_second(hc, lane + 1, hand)) ? 0u : ((hh & 1) == 0 ? 1u : 2u);
+        if (hand) h.y = hh >> 1; else h.x = hh >> 1;
+        hc_o[off] = h;
+        src[off] = lane | (kind << 30);
+      }
+      // the challenge (see below for the protocol)
+      u64 w = 0;
+      {
+        const u64 t0 = wall_clock64();
+        const u64 tag = seq & 0xffffffffull;
+        for (;;) {
+          if (lane < 4) w = __hip_atomic_load((const u64*)&a.cmd[4 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (__all(lane >= 4 || (w >> 32) == tag)) break;
+          int stop = 0;
+          if (lane == 0 && wall_clock64() - t0 > a.timeout_ticks) {  // the host went away: report and leave
+            a.post[8] = 1;
+            __threadfence_system();
+            __hip_atomic_store((u64*)&a.post[5], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            stop = 1;
+          }
+          if (__shfl(stop, 0, 64)) return;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const u64 c0 = __shfl(w, 0, 64), c1 = __shfl(w, 1, 64), c2 = __shfl(w, 2, 64), c3 = __shfl(w, 3, 64);
+      const elt_t r{(c0 & 0xffffffffull) | (c1 << 32), (c2 & 0xffffffffull) | (c3 << 32)};
+      // this evaluation's sums are spent: clear for the next one (one buffer in LDS)
+      for (u32 i = lane; i < qwords * nW[1 - hand]; i += 64) QW[i] = 0;
+      __syncthreads();  // one wave: a wait for the stores above (layout, clear)
+      // Dense::bind of W[hand] and the HQuad::bind_h values: out = base + d * r for both (hquad.h:94-118, dense.h bind)
+      const elt_t* Wold = W[hand];
+      const u32 n0 = nW[hand], nout = (n0 + 1) / 2;
+      elt_t* const Wout = Wdst[hand][wsel[hand]];
+      const bool merged = new_nh + nout <= 64;  // both binds in one pass: HQUAD values on the low lanes, the hand array on the high ones
+      elt_t vbound = elt_zero();
+      for (int pass = 0; pass < (merged ? 1 : 2); ++pass) {
+        elt_t base = elt_zero(), d = elt_zero();
+        int job = 0;  // 1: HQUAD value `lane`, 2: hand entry j
+        u32 j = 0;
+        if (pass == 0 && lane < new_nh) {
+          job = 1;
+          const u32 sidx = src[lane], i = sidx & 0x3fffffffu, kind = sidx >> 30;
+          const elt_t v0 = ld16(&vc[i]);
+          if (kind == 0) { base = v0; d = Fld<F>::sub(ld16(&vc[i + 1]), v0); }
+          else if (kind == 1) { base = v0; d = Fld<F>::sub(elt_zero(), v0); }
+          else { d = v0; }
+        } else if (merged ? lane >= 64 - nout : (pass == 1 && lane < nout)) {
+          job = 2;
+          j = merged ? lane - (64 - nout) : lane;
+          const elt_t f0 = ld16(&Wold[2 * j]);
+          base = f0;
+          d = 2 * j + 1 < n0 ? Fld<F>::sub(ld16(&Wold[2 * j + 1]), f0) : Fld<F>::sub(elt_zero(), f0);
+        }
+        const elt_t out = Fld<F>::add(base, Fld<F>::mul(d, r));
+        if (job == 1) {
+          vbound = out;
+          st16(&vc_o[lane], out);
+        } else if (job == 2) {
+          st16(&Wout[j], out);
+        }
+      }
+      __syncthreads();
+      if (rh + 1 < a.rh1) {  // the next evaluation's sums (for the other hand)
+        const bool valid = lane < new_nh;
+        u32 key = 0xffffffffu;
+        elt_t tt = elt_zero();
+        if (valid) {
+          const uint2 h = hc_o[lane];
+          key = hand ? h.x : h.y;
+          tt = Fld<F>::mul(vbound, ld16(&Wout[hand ? h.y : h.x]));
+        }
+        qw_add(QWn, key, tt, valid);
+      }
+      W[hand] = Wout;
+      nW[hand] = nout;
+      wsel[hand] ^= 1;
+      {
+        nh = new_nh;
+        uint2* th = const_cast<uint2*>(hc);
+        elt_t* tv = const_cast<elt_t*>(vc);
+        hc = hc_o;
+        vc = vc_o;
+        hc_o = th;
+        vc_o = tv;
+        u64* tq = QW;
+        QW = QWn;
+        QWn = tq;
+      }
+      continue;
     }
     const u32 GT = G * SM_THREADS, gtid = (wave * G + g) * 64 + lane;  // 64-entry chunks dealt round-robin: few entries = few waves on EVERY workgroup
     SC_LAP(1);
@@ -1276,6 +1430,8 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   a.two_level = (u32)two_level_env;
   static const int split_env = getenv("LFGPU_SC_SPLIT") ? atoi(getenv("LFGPU_SC_SPLIT")) : -1;
   a.split_waves = split_env >= 0 ? (u32)split_env : 1u;
+  static const int wave_tail_env = getenv("LFGPU_SC_WAVE_TAIL") ? atoi(getenv("LFGPU_SC_WAVE_TAIL")) : 1;
+  a.wave_tail = (u32)wave_tail_env;
   {  // all G workgroups must be resident together (they synchronise through device memory)
     int pc = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, SM_THREADS, tail_ok ? SC_TAIL_LDS_BYTES : 0) != hipSuccess) pc = 0;
