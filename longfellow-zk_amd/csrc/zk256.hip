@@ -358,6 +358,7 @@ struct Grid256 {
   u32* counts;  // one word per workgroup
   u32* src;     // one word per HQUAD entry: where each bound entry comes from (+ its merge kind in the top bits)
   u32 per_wg;
+  u32 wave_tail;  // 1: once everything fits 64 entries, ONE wave finishes the layer
   E rsq;
 };
 // two-level arrival ticket (see sc_arrive in sumcheck.hip): true for the one workgroup that arrives last
@@ -427,6 +428,14 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
   u64* QWn = a.QW2;
   u32 gen = 0;
   u64 seq = a.seq0;
+  bool wave_mode = false;
+  __shared__ uint2 t_hc[2][64];  // the state of the single-wave tail (<= 64 entries per array)
+  __shared__ E t_vc[2][64];
+  __shared__ E t_w[2][128];      // per hand: current (64) + two bind destinations (32 each)
+  __shared__ u64 t_qw[2][8 * 64];
+  __shared__ u32 t_src[64];
+  E* Wd[2][2] = {{a.Wb[0][0], a.Wb[0][1]}, {a.Wb[1][0], a.Wb[1][1]}};
+  u32* srcp = a.src;
   const E rsq = a.rsq;
   {
     const u32 GT = G * G256_THREADS, gtid = (wave * G + g) * 64 + lane;  // 64-entry chunks dealt round-robin over the workgroups
@@ -461,6 +470,195 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
       want = want ? want : 1;
       if (want < G) G = want;
       if (g >= G) return;
+    }
+    // ---- the last rounds of a layer: at most 64 entries in every array.  Wave 0 finishes the layer alone (see the same
+    // block of sc_grid_layer_kernel, sumcheck.hip): both sums in ONE product (lanes 0-31 the a0 terms, lanes 32-63 the a2
+    // terms), both binds in one product when they fit the wave together, the layout by ballot, the sums by shuffles; no
+    // workgroup barrier is left -- the other waves have ended.  Same field operations on the same operands as below.
+    if (G == 1 && a.wave_tail && !wave_mode && nh <= 64 && nW[0] <= 64 && nW[1] <= 64) {
+      if (wave != 0) return;  // the barrier at the top of the loop was their last one: everything they wrote is visible
+      wave_mode = true;
+      // the whole state moves into LDS (21 KiB): every phase is then a product plus an LDS round trip instead of a product
+      // plus one or two trips to L2
+      if (lane < nh) {
+        t_hc[0][lane] = hc[lane];
+        st32(&t_vc[0][lane], ld32(&vc[lane]));
+      }
+      for (int h = 0; h < 2; ++h)
+        if (lane < nW[h]) st32(&t_w[h][lane], ld32(&W[h][lane]));
+      for (u32 i = lane; i < 8 * 64; i += 64) {
+        t_qw[0][i] = i < 8 * nW[hand] ? QW[i] : 0;  // the sums of this evaluation
+        t_qw[1][i] = 0;
+      }
+      hc = t_hc[0]; hc_o = t_hc[1]; vc = t_vc[0]; vc_o = t_vc[1];
+      for (int h = 0; h < 2; ++h) {
+        W[h] = t_w[h];
+        Wd[h][0] = t_w[h] + 64;
+        Wd[h][1] = t_w[h] + 96;
+        wsel[h] = 0;
+      }
+      QW = t_qw[0];
+      QWn = t_qw[1];
+      srcp = t_src;
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (wave_mode) {
+      const u32 nq = nW[hand], nodd = nq / 2;
+      const E* Wh = W[hand];
+      auto qw_at = [&](u32 j) -> E {
+        u64 q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = QW[8 * (size_t)j + k];
+        return fp256_reduce_limbs(q, rsq);
+      };
+      E x = e32_zero(), y = e32_zero();
+      {
+        const u32 i = lane & 31;
+        if (i < nodd) {
+          const E q0 = qw_at(2 * i), w0 = ld32(&Wh[2 * i]);
+          if (lane < 32) {
+            x = q0;
+            y = w0;
+          } else {
+            x = fp256_sub(qw_at(2 * i + 1), q0);
+            y = fp256_sub(ld32(&Wh[2 * i + 1]), w0);
+          }
+        } else if (i == nodd && 2 * nodd < nq) {  // odd tail (prover_layers.h:381-388): in both sums
+          x = qw_at(2 * nodd);
+          y = ld32(&Wh[2 * nodd]);
+        }
+      }
+      E t = fp256_mul(x, y);
+      for (int off = 16; off > 0; off >>= 1) {  // sums inside each half of the wave
+        E o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.l[k] = __shfl_down(t.l[k], off, 32);
+        t = fp256_add(t, o);
+      }
+      E a2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a2.l[k] = __shfl(t.l[k], 32, 64);
+      if (lane == 0) {
+        u64* po = (u64*)a.post;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          __hip_atomic_store(&po[k], t.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(&po[4 + k], a2.l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __hip_atomic_store(&po[8], (u64)nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&po[9], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&po[16], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      // layout of HQuad::bind_h (no challenge needed): lane i looks at entry i
+      const bool head = lane < nh && !is_second256(hc, lane, hand);
+      const u64 hmask = __ballot(head);
+      const u32 new_nh = (u32)__popcll(hmask);
+      if (head) {
+        const u32 off = (u32)__popcll(hmask & ((1ull << lane) - 1));
+        uint2 h = hc[lane];
+        const u32 hh = hand ? h.y : h.x;
+        const u32 kind = (lane + 1 < nh && is_second256(hc, lane + 1, hand)) ? 0u : ((hh & 1) == 0 ? 1u : 2u);
+        if (hand) h.y = hh >> 1;
+        else h.x = hh >> 1;
+        hc_o[off] = h;
+        srcp[off] = lane | (kind << 30);
+      }
+      // the challenge: eight tagged words (see below)
+      u64 w = 0;
+      {
+        const u64 t0 = wall_clock64();
+        const u64 tag = seq & 0xffffffffull;
+        for (;;) {
+          if (lane < 8) w = __hip_atomic_load((const u64*)&a.cmd[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (__all(lane >= 8 || (w >> 32) == tag)) break;
+          int stop = 0;
+          if (lane == 0 && wall_clock64() - t0 > a.timeout_ticks) {  // the host went away: report and leave
+            a.post[9] = 1;
+            __threadfence_system();
+            __hip_atomic_store((u64*)&a.post[16], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            stop = 1;
+          }
+          if (__shfl(stop, 0, 64)) return;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      E r;
+      {
+        const u64 lo32 = w & 0xffffffffull;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.l[k] = __shfl(lo32, 2 * k, 64) | (__shfl(lo32, 2 * k + 1, 64) << 32);
+      }
+      const E* Wold = W[hand];
+      const u32 n0 = nW[hand], nout = (n0 + 1) / 2;
+      for (u32 i = lane; i < 8 * nout; i += 64) QW[i] = 0;  // next written two round-hands from now, for this hand again
+      __threadfence_block();
+      __syncthreads();  // one wave: a wait for the stores above (layout, clear)
+      // Dense::bind of W[hand] and the HQuad::bind_h values: out = base + d * r for both (hquad.h:94-118)
+      E* const Wout = Wd[hand][wsel[hand]];
+      const bool merged = new_nh + nout <= 64;  // both binds in one pass: HQUAD values on the low lanes, the hand array on the high ones
+      E vbound = e32_zero();
+      for (int pass = 0; pass < (merged ? 1 : 2); ++pass) {
+        E base = e32_zero(), d = e32_zero();
+        int job = 0;  // 1: HQUAD value `lane`, 2: hand entry j
+        u32 j = 0;
+        if (pass == 0 && lane < new_nh) {
+          job = 1;
+          const u32 sidx = srcp[lane], i = sidx & 0x3fffffffu, kind = sidx >> 30;
+          const E v0 = ld32(&vc[i]);
+          if (kind == 0) {
+            base = v0;
+            d = fp256_sub(ld32(&vc[i + 1]), v0);
+          } else if (kind == 1) {
+            base = v0;
+            d = fp256_sub(e32_zero(), v0);
+          } else {
+            d = v0;
+          }
+        } else if (merged ? lane >= 64 - nout : (pass == 1 && lane < nout)) {
+          job = 2;
+          j = merged ? lane - (64 - nout) : lane;
+          const E f0 = ld32(&Wold[2 * j]);
+          base = f0;
+          d = 2 * j + 1 < n0 ? fp256_sub(ld32(&Wold[2 * j + 1]), f0) : fp256_sub(e32_zero(), f0);
+        }
+        const E out = fp256_add(base, fp256_mul(d, r));
+        if (job == 1) {
+          vbound = out;
+          st32(&vc_o[lane], out);
+        } else if (job == 2) {
+          st32(&Wout[j], out);
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      if (rh + 1 < a.rh1) {  // the next evaluation's accumulators (for the other hand)
+        u32 key = 0xffffffffu;
+        E tt = e32_zero();
+        if (lane < new_nh) {
+          const uint2 h = hc_o[lane];
+          key = hand ? h.x : h.y;
+          tt = fp256_mul(vbound, ld32(&Wout[hand ? h.y : h.x]));
+        }
+        run_fold_commit256(key, tt, QWn);
+      }
+      W[hand] = Wout;
+      nW[hand] = nout;
+      wsel[hand] ^= 1;
+      {
+        nh = new_nh;
+        uint2* th = const_cast<uint2*>(hc);
+        E* tv = const_cast<E*>(vc);
+        hc = hc_o;
+        vc = vc_o;
+        hc_o = th;
+        vc_o = tv;
+        u64* tq = QW;
+        QW = QWn;
+        QWn = tq;
+      }
+      continue;
     }
     const u32 GT = G * G256_THREADS, gtid = (wave * G + g) * 64 + lane;
     // ---- ProverLayers::evaluations: a0, a2 from the accumulators
@@ -1066,6 +1264,8 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
         a.counts = g_counts;
         a.src = g_src;
         a.per_wg = per_wg;
+        static const int wave_tail_env = getenv("LFGPU_P256_WAVE_TAIL") ? atoi(getenv("LFGPU_P256_WAVE_TAIL")) : 1;
+        a.wave_tail = (u32)wave_tail_env;
         a.rsq = F.rsq;
         LF_HIP(c, hipMemsetAsync(gsync, 0, sizeof(Grid256Sync), c->stream));
         hipLaunchKernelGGL(grid256_layer_kernel, dim3(G), dim3(G256_THREADS), 0, c->stream, a);
