@@ -32,6 +32,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <type_traits>
 #include <vector>
 
 #include "lfgpu.h"
@@ -130,19 +131,28 @@ class GpuReedSolomonFactory {
 };
 
 // ---------------------------------------------------------------- FFTs
+namespace detail {
+// Fp2<Fp<1>> (lib/algebra/fp2.h:36-41 names its BaseField; the prime fields do not): the F64_2 of lib/algebra/fft_test.cc:205-229
+template <class Field, class = void>
+struct is_f64_2 : std::false_type {};
 template <class Field>
-struct GpuFFT {  // FFT<Field>::fftb / fftf (lib/algebra/fft.h:185-201), host buffers
+struct is_f64_2<Field, std::void_t<typename Field::BaseField>> : std::bool_constant<Field::kBytes == 16 && Field::BaseField::kBytes == 8> {};
+}  // namespace detail
+
+template <class Field>
+struct GpuFFT {  // FFT<Field>::fftb / fftf (lib/algebra/fft.h:185-201), host buffers; Field = Fp128<> or Fp2<Fp<1>>
   using Elt = typename Field::Elt;
-  static void fftb(const Context& c, Elt A[/*n*/], size_t n, const Elt& omega_j, uint64_t j) {
+  static_assert(sizeof(Elt) == 16, "16-byte elements");
+  static void run(const Context& c, int dir, Elt A[/*n*/], size_t n, const Elt& omega_j, uint64_t j) {
     uint64_t w[2];
     std::memcpy(w, &omega_j, 16);
-    check(c.get(), lfgpu_fp128_fft_host(c.get(), 0, n, w, j, A), "lfgpu_fp128_fft_host");
+    if constexpr (detail::is_f64_2<Field>::value)
+      check(c.get(), lfgpu_f64_2_fft_host(c.get(), dir, n, w, j, A), "lfgpu_f64_2_fft_host");
+    else
+      check(c.get(), lfgpu_fp128_fft_host(c.get(), dir, n, w, j, A), "lfgpu_fp128_fft_host");
   }
-  static void fftf(const Context& c, Elt A[/*n*/], size_t n, const Elt& omega_j, uint64_t j) {
-    uint64_t w[2];
-    std::memcpy(w, &omega_j, 16);
-    check(c.get(), lfgpu_fp128_fft_host(c.get(), 1, n, w, j, A), "lfgpu_fp128_fft_host");
-  }
+  static void fftb(const Context& c, Elt A[/*n*/], size_t n, const Elt& omega_j, uint64_t j) { run(c, 0, A, n, omega_j, j); }
+  static void fftf(const Context& c, Elt A[/*n*/], size_t n, const Elt& omega_j, uint64_t j) { run(c, 1, A, n, omega_j, j); }
 };
 
 template <class Field>

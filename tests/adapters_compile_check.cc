@@ -11,6 +11,8 @@
 #include "random/random.h"
 #include "random/transcript.h"
 
+#include "algebra/fp.h"
+#include "algebra/fp2.h"
 #include "algebra/fp_p256.h"
 #include "arrays/dense.h"
 #include "sumcheck/circuit.h"
@@ -72,6 +74,14 @@ void lfgpu_adapters_compile_check(const lfgpu::Context& ctx, proofs::RandomEngin
   lfgpu::GpuLCH14<GF> lch(ctx);
   lch.FFT(3, 0, nullptr);
   lfgpu::GpuFFT<FP>::fftb(ctx, nullptr, 8, fp.one(), 8);
+  {  // the F64_2 of lib/algebra/fft_test.cc:205-229
+    using F64 = proofs::Fp<1>;
+    using F64_2 = proofs::Fp2<F64>;
+    static_assert(lfgpu::detail::is_f64_2<F64_2>::value && !lfgpu::detail::is_f64_2<FP>::value, "field detection");
+    static const F64 f64("18446744069414584321");
+    static const F64_2 f64_2(f64);
+    lfgpu::GpuFFT<F64_2>::fftf(ctx, nullptr, 8, f64_2.one(), 8);
+  }
   lfgpu::GpuSumcheckRound<GF> sc(ctx);
   GF::Elt a0, a2;
   sc.partials(0, nullptr, nullptr, a0, a2);
