@@ -21,6 +21,17 @@ CASES = [
     ("32", {"LFGPU_SC_WGS": "7", "LFGPU_SC_PER_WG": "1024"}),
     ("1 fp128", {"LFGPU_SC_PER_WG": "128", "LFGPU_SC_SPLIT": "0"}),
     ("1 fp128", {"LFGPU_SC_MODE": "resident"}),
+    # the single-wave tail (<= 64 entries; on by default, so every case above runs through it): off, for both fields,
+    # and on without the LDS tail it lives in (then it must not engage)
+    ("1", {"LFGPU_SC_WAVE_TAIL": "0"}),
+    ("1 fp128", {"LFGPU_SC_WAVE_TAIL": "0"}),
+    ("32", {"LFGPU_SC_WAVE_TAIL": "1", "LFGPU_SC_TAIL": "0"}),
+    # Fp256Base (csrc/zk256.hip) on the mdoc signature circuit: without the single-wave tail, without the resident grid
+    # (three launches per round-hand all the way), and with other hand-off points / workgroup shares
+    ("sig", {"LFGPU_P256_WAVE_TAIL": "0"}),
+    ("sig", {"LFGPU_P256_GRID": "0"}),
+    ("sig", {"LFGPU_P256_GRID_MAX": "65536", "LFGPU_P256_PER_WG": "128"}),
+    ("sig", {"LFGPU_P256_GRID_MAX": "300", "LFGPU_P256_PER_WG": "2048"}),
 ]
 
 
@@ -29,7 +40,7 @@ CASES = [
 def test_proof_bytes_under_every_driver(args, env):
     e = dict(os.environ)
     for k in list(e):
-        if k.startswith("LFGPU_SC_"):
+        if k.startswith("LFGPU_SC_") or k.startswith("LFGPU_P256_"):
             del e[k]
     e.update(env)
     r = subprocess.run([sys.executable, CHILD] + args.split(), env=e, capture_output=True, text=True, timeout=300)

@@ -1,6 +1,6 @@
 """Child process of test_sumcheck_drivers.py: the tuning switches are read once per process, so every combination
 gets its own.  Proves the fixture circuit with the fixture's RandomEngine / transcript seed, requires the wire bytes
-of the reference and that the verifier accepts them.  Usage: zk_mode_child.py <nb> [fp128]"""
+of the reference and that the verifier accepts them.  Usage: zk_mode_child.py <nb> [fp128] | sig"""
 import hashlib, json, lzma, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,16 +8,23 @@ import numpy as np
 import gpu_util as G
 import ligero_fixture as lf
 
-nb = int(sys.argv[1])
-fp = len(sys.argv) > 2 and sys.argv[2] == "fp128"
-stem = ("flatsha_fp_nb%d" if fp else "flatsha_nb%d") % nb
 gold = os.path.join(ROOT, "tests", "golden")
+sig = sys.argv[1] == "sig"  # the mdoc signature circuit over Fp256Base (32-byte elements, csrc/zk256.hip)
+if sig:
+    stem = "mdoc_sig"
+    info = json.load(open(os.path.join(gold, "mdoc.json")))["sig"]
+    be = info["block_enc"]
+else:
+    nb = int(sys.argv[1])
+    fp = len(sys.argv) > 2 and sys.argv[2] == "fp128"
+    stem = ("flatsha_fp_nb%d" if fp else "flatsha_nb%d") % nb
+    info = json.load(open(os.path.join(gold, stem + ".json")))
+    be = 0
 raw = lzma.decompress(open(os.path.join(gold, stem + ".lfc1.xz"), "rb").read())
-W = np.frombuffer(lzma.decompress(open(os.path.join(gold, stem + ".w.xz"), "rb").read()), dtype=np.uint64).reshape(-1, 2).copy()
-info = json.load(open(os.path.join(gold, stem + ".json")))
+W = np.frombuffer(lzma.decompress(open(os.path.join(gold, stem + ".w.xz"), "rb").read()), dtype=np.uint64).reshape(-1, 4 if sig else 2).copy()
 pkg, gpu = G.pkg, G.gpu()
 circ = pkg.Circuit(gpu, raw)
-zk = pkg.ZkProver(gpu, circ, 7, 132)
+zk = pkg.ZkProver(gpu, circ, 7, 132, be)
 for rep in range(2):  # twice: the second run reuses cached buffers and the warmed-up drivers
     ts = pkg.FsTranscript(b"test")
     zk.commit(W, lf.LcgRng(100).bytes, ts)
@@ -26,7 +33,7 @@ for rep in range(2):  # twice: the second run reuses cached buffers and the warm
     ts.close()
     assert len(wire) == info["zk_wire_bytes"] and hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"], "wire differs from the reference"
 ts = pkg.FsTranscript(b"test")
-ok, why = pkg.zk_verify(gpu, circ, wire, W[:circ.info.npub_in], ts)
+ok, why = pkg.zk_verify(gpu, circ, wire, W[:circ.info.npub_in], ts, 7, 132, be)
 ts.close()
 assert ok, why
 print("OK", stem)
