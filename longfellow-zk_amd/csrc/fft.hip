@@ -119,7 +119,9 @@ __device__ __forceinline__ void fp_radix_round(elt_t* s, const elt_t* Wl, u32 ws
 // tw_hi == nullptr with tw_lo != nullptr: tw_lo is the FULL inter-pass table [j][column] (one product per element
 // instead of two; rows of the grid then vary fastest so that a tile's slice of the table stays in L2 while the
 // batch rows stream past it).
-template <class O, int FFT_THREADS>
+// WLDS: the stage twiddles sit in LDS behind the tile (p.wlds; always, for 2^12-element tiles) -- a template parameter so that
+// their reads are LDS instructions with 32-bit addresses instead of flat loads through a generic pointer
+template <class O, int FFT_THREADS, bool WLDS>
 __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt_t* __restrict__ W, u32 wshift,
                                                            const elt_t* __restrict__ tw_lo,
                                                            const elt_t* __restrict__ tw_hi, u32 row_fast) {
@@ -139,14 +141,10 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
   }
   // the T/2 stage twiddles w_T^i go behind the tile in LDS: three twiddle reads per radix-4 step then cost an LDS
   // access instead of a vector-memory instruction each
-  const elt_t* Wl = W;  // stage twiddle i at Wl[i << wsh]
-  u32 wsh = wshift;
-  if (p.wlds) {
-    elt_t* const wl = s + ((size_t)T << p.logC);
+  elt_t* const wl = s + (T << p.logC);  // stage twiddle i at Wl[i << wsh]
+  if (WLDS)
     for (u32 i = tid; i < (T >> 1); i += FFT_THREADS) st16(&wl[i], ld16(&W[(size_t)i << wshift]));
-    Wl = wl;
-    wsh = 0;
-  }
+  const u32 wsh = WLDS ? 0 : wshift;
   __syncthreads();
   // R stages per LDS round trip on 2^R register-resident points x[a] = s[i0 + a*m]: sub-stage t pairs (a, a + 2^t)
   // with w_T^(jj * T / (2m 2^t)), jj = j + (a mod 2^t) * m.  Same products as radix 2, 1/R of the LDS traffic and
@@ -155,9 +153,15 @@ __global__ __launch_bounds__(FFT_THREADS) void fp_fft_tile(TilePlan p, const elt
   while (st < p.logT) {
     const u32 rem = p.logT - st;
     const u32 R = (rem == 3 || rem > 4) ? 3 : (rem >= 2 ? 2 : 1);
-    if (R == 3) fp_radix_round<O, 3, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
-    else if (R == 2) fp_radix_round<O, 2, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
-    else fp_radix_round<O, 1, FFT_THREADS>(s, Wl, wsh, p.logT, p.logC, st, tid);
+    if (WLDS) {
+      if (R == 3) fp_radix_round<O, 3, FFT_THREADS>(s, wl, wsh, p.logT, p.logC, st, tid);
+      else if (R == 2) fp_radix_round<O, 2, FFT_THREADS>(s, wl, wsh, p.logT, p.logC, st, tid);
+      else fp_radix_round<O, 1, FFT_THREADS>(s, wl, wsh, p.logT, p.logC, st, tid);
+    } else {
+      if (R == 3) fp_radix_round<O, 3, FFT_THREADS>(s, W, wsh, p.logT, p.logC, st, tid);
+      else if (R == 2) fp_radix_round<O, 2, FFT_THREADS>(s, W, wsh, p.logT, p.logC, st, tid);
+      else fp_radix_round<O, 1, FFT_THREADS>(s, W, wsh, p.logT, p.logC, st, tid);
+    }
     __syncthreads();
     st += R;
   }
@@ -247,8 +251,10 @@ __global__ __launch_bounds__(FFT_THREADS) void lch_fft_tile(TilePlan p, int inve
 // ------------------------------------------------------------------ host side
 template <class O>
 static int set_lds_limit_fp(lfgpu_ctx* c) {
-  LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<O, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<O, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<O, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<O, 1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<O, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  LF_HIP(c, hipFuncSetAttribute((const void*)fp_fft_tile<O, 512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return LFGPU_OK;
 }
 static int set_lds_limit(lfgpu_ctx* c) {
@@ -274,11 +280,14 @@ static size_t fp_lds_bytes(TilePlan& p) {
   return p.wlds ? tile + tw : tile;
 }
 template <class O, class... Args>
-static void launch_fp(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
-  if (c->tile_log == 13)
-    hipLaunchKernelGGL((fp_fft_tile<O, 1024>), grid, dim3(1024), lds, c->stream, args...);
-  else
-    hipLaunchKernelGGL((fp_fft_tile<O, 512>), grid, dim3(512), lds, c->stream, args...);
+static void launch_fp(lfgpu_ctx* c, dim3 grid, size_t lds, const TilePlan& p, Args... args) {
+  if (c->tile_log == 13) {
+    if (p.wlds) hipLaunchKernelGGL((fp_fft_tile<O, 1024, true>), grid, dim3(1024), lds, c->stream, p, args...);
+    else hipLaunchKernelGGL((fp_fft_tile<O, 1024, false>), grid, dim3(1024), lds, c->stream, p, args...);
+  } else {
+    if (p.wlds) hipLaunchKernelGGL((fp_fft_tile<O, 512, true>), grid, dim3(512), lds, c->stream, p, args...);
+    else hipLaunchKernelGGL((fp_fft_tile<O, 512, false>), grid, dim3(512), lds, c->stream, p, args...);
+  }
 }
 template <class... Args>
 static void launch_lch(lfgpu_ctx* c, dim3 grid, size_t lds, Args... args) {
