@@ -295,6 +295,7 @@ extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t le
   lfgpu_circuit_info& I = C->info;
   I.field = field;
   I.nv = nv; I.nc = nc; I.npub_in = npub; I.subfield_boundary = sfb; I.ninputs = nin; I.nl = nl; I.nterms = nterms;
+  C->zeros.assign(nterms, 0);
   I.logv = lf_log2(nv);
   memcpy(I.id, b + pos, 32);
   *out = C.release();
@@ -733,10 +734,7 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
   ts.write_bytes(I.id, 32);
   for (size_t i = 0; i < zk->npub; ++i) ts.write_elt(W[i]);
   ts.write_elt(elt_t{0, 0});
-  {
-    std::vector<uint8_t> z(I.nterms, 0);
-    ts.write_bytes(z.data(), z.size());
-  }
+  ts.write_bytes(C->zeros.data(), I.nterms);
   void* cl = tso->clone(tso->user);
   if (!cl) {
     hipStreamSynchronize(c->stream);
@@ -1163,10 +1161,7 @@ static int zk_verify_impl(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, 
   ts.write_bytes(I.id, 32);
   for (size_t i = 0; i < npub; ++i) ts.write_elt(pub[i]);
   ts.write_elt(elt_t{0, 0});
-  {
-    std::vector<uint8_t> z(I.nterms, 0);
-    ts.write_bytes(z.data(), z.size());
-  }
+  ts.write_bytes(C->zeros.data(), I.nterms);
 
   // verifier_constraints with aux == nullptr: the bound quad of every layer comes from bind_gh_all
   ConstraintSet cs;

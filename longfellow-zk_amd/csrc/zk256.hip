@@ -1942,10 +1942,7 @@ int zk256_prove(Zk256* z, const void* h_W, const lfgpu_transcript_ops* tso, int*
   ts.write_bytes(I.id, 32);
   for (size_t i = 0; i < z->npub; ++i) ts.write_elt(W[i]);
   ts.write_elt(F.zero);
-  {
-    std::vector<uint8_t> zb(I.nterms, 0);
-    ts.write_bytes(zb.data(), zb.size());
-  }
+  ts.write_bytes(C->zeros.data(), I.nterms);
   void* cl = tso->clone(tso->user);
   if (!cl) {
     (void)hipStreamSynchronize(c->stream);
@@ -2215,10 +2212,7 @@ int zk256_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nr
   ts.write_bytes(I.id, 32);
   for (size_t i = 0; i < npub; ++i) ts.write_elt(pub[i]);
   ts.write_elt(F.zero);
-  {
-    std::vector<uint8_t> zb(I.nterms, 0);
-    ts.write_bytes(zb.data(), zb.size());
-  }
+  ts.write_bytes(C->zeros.data(), I.nterms);
   // device buffers: EQ table of the input constraint | rows [0, nwqrow) = [0^r | A_i], then y_ldt, y_dot, y_quad | gathered columns
   const size_t nrows_dev = p.nwqrow + 3, ld = p.block_enc;
   void* dv = nullptr;

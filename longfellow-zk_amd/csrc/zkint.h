@@ -14,6 +14,7 @@ struct lfgpu_circuit {
     lfgpu_quad* q;
   };
   std::vector<Layer> layers;
+  std::vector<uint8_t> zeros;  // nterms zero bytes: what initialize_sumcheck_fiat_shamir hashes per proof (zk_common.h:177-179)
   ~lfgpu_circuit() {
     for (auto& l : layers)
       if (l.q) lfgpu_quad_free(l.q);
