@@ -144,9 +144,18 @@ int lf_sc_small_step(lfgpu_ctx* c, const ScSmall& a, u64 out[8]);
 int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_W_shared, void* wtmp);
 int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]);
 bool lf_sc_resident_ok(lfgpu_ctx* c);
+// Where each workgroup's range of HQuad::bind_h lands in the output, per round-hand of the shrinking grid, and the size after
+// the bind: circuit constants (which entries merge depends on the corner indices only), recorded by the first proof that runs
+// the layer through the grid and replayed by the later ones -- their round-hands then need neither the count nor the
+// device-wide barrier in front of the offsets.  Lives with the layer's quad.
+struct ScGridOffCache {
+  u32* d = nullptr;                 // [64 round-hands][LF_SC_GRID_WGS + 1] words
+  u32 key[4] = {0, 0, 0, 0};        // {first round-hand, workgroups, HQUAD size, entries per workgroup} of the record
+  int state = 0;                    // 0 none, 1 being recorded (valid once the layer ends well), 2 valid
+};
 int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, const u32* d_nh, void* W0, size_t nW0,
                      void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
-                     size_t logw, void* d_state);
+                     size_t logw, void* d_state, ScGridOffCache* oc = nullptr);
 #define LF_SC_GRID_WGS 128                         // most workgroups the shrinking-grid kernel starts with
 #define LF_SC_GRID_MAX (256 * 1024)             // largest HQUAD / hand array it takes
 #define LF_SC_GRID_STATE_BYTES (64 + 1024 + 32 * LF_SC_GRID_WGS + 4 * LF_SC_GRID_WGS + 64 + 36 * LF_SC_GRID_MAX)

@@ -31,6 +31,7 @@ struct lfgpu_quad {
     size_t n_in, n_out;
   };
   std::vector<BindShape> bind_shape;  // indexed by round-hand
+  ScGridOffCache grid_off;            // ... and for the round-hands that run on the shrinking grid
 };
 
 // lfgpu_quad_upload for corners that are already packed and range-checked (g < nv, vi < nk; hmax = largest hand index): the

@@ -233,6 +233,7 @@ extern "C" int lfgpu_quad_free(lfgpu_quad* q) {
   if (q->d_nh) (void)hipFree(q->d_nh);
   for (auto& b : q->bind_shape)
     if (b.d_off) (void)hipFree(b.d_off);
+  if (q->grid_off.d) (void)hipFree(q->grid_off.d);
   delete q;
   return LFGPU_OK;
 }
@@ -676,7 +677,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
         if (!resident && sc_mode == 3) {  // hand the rest of the layer to the shrinking grid
           uint8_t* wb = (uint8_t*)wtmp;
           LF_TRY(lf_sc_grid_begin(c, field, hc[cur], vc[cur], hc[1 - cur], vc[1 - cur], nh, nullptr,
-                                  WH[0], nW[0], WH[1], nW[1], wb, wb + half, wb + 2 * half, wb + 3 * half, qw, 2 * rnd + hand, logw, grid_state));
+                                  WH[0], nW[0], WH[1], nW[1], wb, wb + half, wb + 2 * half, wb + 3 * half, qw, 2 * rnd + hand, logw, grid_state, &q->grid_off));
         } else if (!resident) {  // ... or to the resident workgroup
           ScSmall a{};
           a.field = field;
@@ -768,6 +769,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   if (resident) {  // last challenge in, W[0][0], W[1][0] and the HQUAD scalar out
     u64 out[8];
     LF_TRY(lf_sc_layer_next(c, last_r, out));
+    if (q->grid_off.state == 1) q->grid_off.state = 2;  // the layer ran to its end: the recorded bind offsets are good
     tmp[0] = out[0]; tmp[1] = out[1]; tmp[2] = out[2]; tmp[3] = out[3]; tmp[4] = out[6]; tmp[5] = out[7];
   } else if (small) {  // last binds + read-out of W[0][0], W[1][0], HQUAD scalar in one step
     u64 out[8];

@@ -602,6 +602,8 @@ struct ScGrid {
   u32 split_waves;  // 1: with one workgroup left, independent products go to different waves
   u32 per_wg;       // entries of the largest array per active workgroup (the grid shrinks to keep it)
   u32 wave_tail;    // 1: once everything fits 64 entries, ONE wave finishes the layer (no workgroup barriers)
+  u32* off_cache;   // ScGridOffCache::d
+  u32 off_mode;     // 0 no cache, 1 record, 2 replay
 };
 #define SC_WAVE_TAIL 64u
 #define SC_TAIL 1024u
@@ -1057,7 +1059,14 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         s_tot = 0;
       }
       __syncthreads();
-      if (G > 1) {
+      u32* const oc = a.off_cache + (size_t)rh * (LF_SC_GRID_WGS + 1);
+      if (G > 1 && a.off_mode == 2) {  // recorded by an earlier proof (ScGridOffCache): no count, no barrier
+        if (tid == 0) {
+          s_off = oc[g];
+          s_tot = oc[LF_SC_GRID_WGS];
+        }
+        __syncthreads();
+      } else if (G > 1) {
         u32 mine = 0;
         for (u32 base = lo; base < hi; base += SM_THREADS) {
           const u32 i = base + tid;
@@ -1078,6 +1087,10 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
           }
         }
         __syncthreads();
+        if (a.off_mode == 1 && tid == 0) {
+          oc[g] = s_off;
+          if (g == 0) oc[LF_SC_GRID_WGS] = s_tot;
+        }
       }
       my_off = s_off;
       __syncthreads();
@@ -1376,7 +1389,7 @@ int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_
 // d_state: LF_SC_GRID_STATE_BYTES of device scratch (ScGridSync + the per-workgroup counts)
 int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, const u32* d_nh, void* W0, size_t nW0,
                      void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
-                     size_t logw, void* d_state) {
+                     size_t logw, void* d_state, ScGridOffCache* oc) {
   const size_t big = std::max(nh, std::max(nW0, nW1));
   if (rh0 >= 2 * logw || big > LF_SC_GRID_MAX) return lf_fail(c, LFGPU_ERR_ARG, "sc_grid_begin: bad operands");
   static_assert(sizeof(ScGridSync) + 4 * LF_SC_GRID_WGS + 36 * LF_SC_GRID_MAX <= LF_SC_GRID_STATE_BYTES, "grid state size");
@@ -1432,6 +1445,25 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   a.split_waves = split_env >= 0 ? (u32)split_env : 1u;
   static const int wave_tail_env = getenv("LFGPU_SC_WAVE_TAIL") ? atoi(getenv("LFGPU_SC_WAVE_TAIL")) : 1;
   a.wave_tail = (u32)wave_tail_env;
+  static const bool off_cache_env = !(getenv("LFGPU_SC_OFFCACHE") && atoi(getenv("LFGPU_SC_OFFCACHE")) == 0);
+  if (oc && off_cache_env && !d_nh && 2 * logw <= 64) {
+    const u32 key[4] = {(u32)rh0, G, (u32)nh, per_wg};
+    if (!oc->d && hipMalloc((void**)&oc->d, 64 * (LF_SC_GRID_WGS + 1) * sizeof(u32)) != hipSuccess) {
+      oc->d = nullptr;
+      (void)hipGetLastError();
+    }
+    if (oc->d) {
+      const bool same = oc->key[0] == key[0] && oc->key[1] == key[1] && oc->key[2] == key[2] && oc->key[3] == key[3];
+      if (oc->state == 2 && same) {
+        a.off_mode = 2;
+      } else {  // first proof through this layer (or other knobs): record
+        for (int k = 0; k < 4; ++k) oc->key[k] = key[k];
+        oc->state = 1;
+        a.off_mode = 1;
+      }
+      a.off_cache = oc->d;
+    }
+  }
   {  // all G workgroups must be resident together (they synchronise through device memory)
     int pc = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, SM_THREADS, tail_ok ? SC_TAIL_LDS_BYTES : 0) != hipSuccess) pc = 0;
