@@ -26,6 +26,8 @@ CASES = [
     ("1", {"LFGPU_SC_WAVE_TAIL": "0"}),
     ("1 fp128", {"LFGPU_SC_WAVE_TAIL": "0"}),
     ("32", {"LFGPU_SC_WAVE_TAIL": "1", "LFGPU_SC_TAIL": "0"}),
+    # the recorded bind offsets of the grid (second proof of every case above replays them): never recorded
+    ("32", {"LFGPU_SC_OFFCACHE": "0"}),
     # Fp256Base (csrc/zk256.hip) on the mdoc signature circuit: without the single-wave tail, without the resident grid
     # (three launches per round-hand all the way), and with other hand-off points / workgroup shares
     ("sig", {"LFGPU_P256_WAVE_TAIL": "0"}),
