@@ -671,6 +671,15 @@ LF_HD void sha_init(sha_state& s) {
   s.h[4] = 0x510e527f; s.h[5] = 0x9b05688c; s.h[6] = 0x1f83d9ab; s.h[7] = 0x5be0cd19;
 }
 // one compression; w[16] is the big-endian-decoded message block (clobbered)
+// three-input boolean operations: gfx950 has one instruction for any of them (v_bitop3_b32); hipcc finds it for Ch but
+// spends two v_xor_b32 on every three-way XOR and an extra v_and_b32 on Maj
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ u32 sha_xor3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ u32 sha_maj(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+#else
+inline u32 sha_xor3(u32 a, u32 b, u32 c) { return a ^ b ^ c; }
+inline u32 sha_maj(u32 a, u32 b, u32 c) { return (a & b) ^ (a & c) ^ (b & c); }
+#endif
 LF_HD void sha_compress(sha_state& s, u32 w[16]) {
   u32 a = s.h[0], b = s.h[1], c = s.h[2], d = s.h[3], e = s.h[4], f = s.h[5], g = s.h[6], h = s.h[7];
 #pragma unroll
@@ -680,16 +689,16 @@ LF_HD void sha_compress(sha_state& s, u32 w[16]) {
       wi = w[i];
     } else {
       u32 w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-      u32 s0 = ror32(w15, 7) ^ ror32(w15, 18) ^ (w15 >> 3);
-      u32 s1 = ror32(w2, 17) ^ ror32(w2, 19) ^ (w2 >> 10);
+      u32 s0 = sha_xor3(ror32(w15, 7), ror32(w15, 18), w15 >> 3);
+      u32 s1 = sha_xor3(ror32(w2, 17), ror32(w2, 19), w2 >> 10);
       wi = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
       w[i & 15] = wi;
     }
-    u32 S1 = ror32(e, 6) ^ ror32(e, 11) ^ ror32(e, 25);
+    u32 S1 = sha_xor3(ror32(e, 6), ror32(e, 11), ror32(e, 25));
     u32 ch = (e & f) ^ (~e & g);
     u32 t1 = h + S1 + ch + kSha256K[i] + wi;
-    u32 S0 = ror32(a, 2) ^ ror32(a, 13) ^ ror32(a, 22);
-    u32 mj = (a & b) ^ (a & c) ^ (b & c);
+    u32 S0 = sha_xor3(ror32(a, 2), ror32(a, 13), ror32(a, 22));
+    u32 mj = sha_maj(a, b, c);
     u32 t2 = S0 + mj;
     h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
   }
