@@ -578,6 +578,43 @@ LF_HD elt_t gf_add(elt_t a, elt_t b) { return elt_t{a.lo ^ b.lo, a.hi ^ b.hi}; }
 // (8 bits per masked operand, at most 8 partial products per hole < 16): same
 // idea as the reference's portable clmul64_lo (lib/gf2k/sysdep.h:348-358),
 // resized to the 32-bit multiplier of CDNA4 (v_mad_u64_u32).
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950: the sums of four partial products and the final interleave through the three-input boolean instruction
+// (v_bitop3_b32: 0x96 = a ^ b ^ c, 0xCA = bit select src0 ? src1 : src2) -- 46 instead of 62 instructions per 32 x 32 product
+__device__ __forceinline__ u64 clmul_x4(u64 p, u64 q, u64 r, u64 s) {
+  const u32 lo = __builtin_amdgcn_bitop3_b32((u32)p, (u32)q, (u32)r, 0x96) ^ (u32)s;
+  const u32 hi = __builtin_amdgcn_bitop3_b32((u32)(p >> 32), (u32)(q >> 32), (u32)(r >> 32), 0x96) ^ (u32)(s >> 32);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u32 clmul_sel4(u32 z0, u32 z1, u32 z2, u32 z3) {  // bit i of every nibble from z_i
+  const u32 t01 = __builtin_amdgcn_bitop3_b32(0x55555555u, z0, z1, 0xCA), t23 = __builtin_amdgcn_bitop3_b32(0x55555555u, z2, z3, 0xCA);
+  return __builtin_amdgcn_bitop3_b32(0x33333333u, t01, t23, 0xCA);
+}
+__device__ __forceinline__ u64 clmul32(u32 x, u32 y) {
+  const u32 m0 = 0x11111111u, m1 = 0x22222222u, m2 = 0x44444444u, m3 = 0x88888888u;
+  const u32 x0 = x & m0, x1 = x & m1, x2 = x & m2, x3 = x & m3;
+  const u32 y0 = y & m0, y1 = y & m1, y2 = y & m2, y3 = y & m3;
+  const u64 z0 = clmul_x4((u64)x0 * y0, (u64)x1 * y3, (u64)x2 * y2, (u64)x3 * y1);
+  const u64 z1 = clmul_x4((u64)x0 * y1, (u64)x1 * y0, (u64)x2 * y3, (u64)x3 * y2);
+  const u64 z2 = clmul_x4((u64)x0 * y2, (u64)x1 * y1, (u64)x2 * y0, (u64)x3 * y3);
+  const u64 z3 = clmul_x4((u64)x0 * y3, (u64)x1 * y2, (u64)x2 * y1, (u64)x3 * y0);
+  const u32 lo = clmul_sel4((u32)z0, (u32)z1, (u32)z2, (u32)z3);
+  const u32 hi = clmul_sel4((u32)(z0 >> 32), (u32)(z1 >> 32), (u32)(z2 >> 32), (u32)(z3 >> 32));
+  return ((u64)hi << 32) | lo;
+}
+// host functions parsed during the device pass resolve to this overload
+__host__ inline u64 clmul32(u32 x, u32 y) {
+  const u32 m0 = 0x11111111u, m1 = 0x22222222u, m2 = 0x44444444u, m3 = 0x88888888u;
+  u32 x0 = x & m0, x1 = x & m1, x2 = x & m2, x3 = x & m3;
+  u32 y0 = y & m0, y1 = y & m1, y2 = y & m2, y3 = y & m3;
+  u64 z0 = ((u64)x0 * y0) ^ ((u64)x1 * y3) ^ ((u64)x2 * y2) ^ ((u64)x3 * y1);
+  u64 z1 = ((u64)x0 * y1) ^ ((u64)x1 * y0) ^ ((u64)x2 * y3) ^ ((u64)x3 * y2);
+  u64 z2 = ((u64)x0 * y2) ^ ((u64)x1 * y1) ^ ((u64)x2 * y0) ^ ((u64)x3 * y3);
+  u64 z3 = ((u64)x0 * y3) ^ ((u64)x1 * y2) ^ ((u64)x2 * y1) ^ ((u64)x3 * y0);
+  return (z0 & 0x1111111111111111ull) | (z1 & 0x2222222222222222ull) | (z2 & 0x4444444444444444ull) |
+         (z3 & 0x8888888888888888ull);
+}
+#else
 LF_HD u64 clmul32(u32 x, u32 y) {
   const u32 m0 = 0x11111111u, m1 = 0x22222222u, m2 = 0x44444444u, m3 = 0x88888888u;
   u32 x0 = x & m0, x1 = x & m1, x2 = x & m2, x3 = x & m3;
@@ -589,23 +626,35 @@ LF_HD u64 clmul32(u32 x, u32 y) {
   return (z0 & 0x1111111111111111ull) | (z1 & 0x2222222222222222ull) | (z2 & 0x4444444444444444ull) |
          (z3 & 0x8888888888888888ull);
 }
+#endif
+
+// a ^ b ^ c on 64-bit words: two v_bitop3_b32 on the device
+LF_HD u64 gf_x3(u64 a, u64 b, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const u32 lo = __builtin_amdgcn_bitop3_b32((u32)a, (u32)b, (u32)c, 0x96);
+  const u32 hi = __builtin_amdgcn_bitop3_b32((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32), 0x96);
+  return ((u64)hi << 32) | lo;
+#else
+  return a ^ b ^ c;
+#endif
+}
 
 // 64x64 -> 128 (Karatsuba over 32-bit halves)
 LF_HD void clmul64(u64 x, u64 y, u64& lo, u64& hi) {
   u32 xl = (u32)x, xh = (u32)(x >> 32), yl = (u32)y, yh = (u32)(y >> 32);
   u64 z0 = clmul32(xl, yl);
   u64 z2 = clmul32(xh, yh);
-  u64 z1 = clmul32(xl ^ xh, yl ^ yh) ^ z0 ^ z2;
+  u64 z1 = gf_x3(clmul32(xl ^ xh, yl ^ yh), z0, z2);
   lo = z0 ^ (z1 << 32);
   hi = z2 ^ (z1 >> 32);
 }
 
 // fold a 256-bit carry-less product: x^128 = x^7 + x^2 + x + 1
 LF_HD elt_t gf_reduce256(u64 t0, u64 t1, u64 t2, u64 t3) {
-  t1 ^= t3 ^ (t3 << 1) ^ (t3 << 2) ^ (t3 << 7);
-  t2 ^= (t3 >> 63) ^ (t3 >> 62) ^ (t3 >> 57);
-  t0 ^= t2 ^ (t2 << 1) ^ (t2 << 2) ^ (t2 << 7);
-  t1 ^= (t2 >> 63) ^ (t2 >> 62) ^ (t2 >> 57);
+  t1 = gf_x3(gf_x3(t1, t3, t3 << 1), t3 << 2, t3 << 7);
+  t2 ^= gf_x3(t3 >> 63, t3 >> 62, t3 >> 57);
+  t0 = gf_x3(gf_x3(t0, t2, t2 << 1), t2 << 2, t2 << 7);
+  t1 ^= gf_x3(t2 >> 63, t2 >> 62, t2 >> 57);
   return elt_t{t0, t1};
 }
 
@@ -615,8 +664,8 @@ LF_HD elt_t gf_mul(elt_t a, elt_t b) {
   clmul64(a.lo, b.lo, z0l, z0h);
   clmul64(a.hi, b.hi, z2l, z2h);
   clmul64(a.lo ^ a.hi, b.lo ^ b.hi, z1l, z1h);
-  z1l ^= z0l ^ z2l;
-  z1h ^= z0h ^ z2h;
+  z1l = gf_x3(z1l, z0l, z2l);
+  z1h = gf_x3(z1h, z0h, z2h);
   return gf_reduce256(z0l, z0h ^ z1l, z2l ^ z1h, z2h);
 }
 
