@@ -66,7 +66,89 @@ LF_HD void cond_sub_p(u32 (&t)[8], u32 hi) {
 }
 }  // namespace fp256_detail
 
-LF_HD elt32_t fp256_add(const elt32_t& a, const elt32_t& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 versions: 32-bit limb carry chains through VCC (see the Fp128 ones in fields.h for the wait states).  hipcc's lowering
+// of the portable code below is 122 / 96 instructions per add / sub (64-bit carries rebuilt with moves and v_lshl_add_u64);
+// these are 26 / 18 -- and a round-hand of the Fp256Base sumcheck is a chain of ~20 of them on one wave.
+#define P256_NOP "s_nop 1\n\t"
+__device__ __forceinline__ elt32_t fp256_add(const elt32_t& a, const elt32_t& b) {
+  u32 x[8], y[8], d[8], c;
+  fp256_detail::to_w(a, x);
+  fp256_detail::to_w(b, y);
+  asm("v_add_co_u32 %0, vcc, %0, %9\n\t" P256_NOP
+      "v_addc_co_u32 %1, vcc, %1, %10, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %2, vcc, %2, %11, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %3, vcc, %3, %12, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %4, vcc, %4, %13, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %5, vcc, %5, %14, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %6, vcc, %6, %15, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %7, vcc, %7, %16, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %8, vcc, 0, 0, vcc"
+      : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "=&v"(c)
+      : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7])
+      : "vcc");
+  // (c : x) - p, p = {-1, -1, -1, 0, 0, 0, 1, -1}; the final borrow is set iff the sum is below p
+  asm("v_subrev_co_u32 %0, vcc, -1, %8\n\t" P256_NOP
+      "v_subbrev_co_u32 %1, vcc, -1, %9, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %2, vcc, -1, %10, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %3, vcc, 0, %11, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %4, vcc, 0, %12, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %5, vcc, 0, %13, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %6, vcc, 1, %14, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %7, vcc, -1, %15, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %16, vcc, 0, %16, vcc\n\t" P256_NOP
+      "v_cndmask_b32 %8, %0, %8, vcc\n\t"
+      "v_cndmask_b32 %9, %1, %9, vcc\n\t"
+      "v_cndmask_b32 %10, %2, %10, vcc\n\t"
+      "v_cndmask_b32 %11, %3, %11, vcc\n\t"
+      "v_cndmask_b32 %12, %4, %12, vcc\n\t"
+      "v_cndmask_b32 %13, %5, %13, vcc\n\t"
+      "v_cndmask_b32 %14, %6, %14, vcc\n\t"
+      "v_cndmask_b32 %15, %7, %15, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "+v"(x[0]), "+v"(x[1]),
+        "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(c)
+      :
+      : "vcc");
+  return fp256_detail::from_w(x);
+}
+__device__ __forceinline__ elt32_t fp256_sub(const elt32_t& a, const elt32_t& b) {
+  u32 x[8], y[8], m;
+  fp256_detail::to_w(a, x);
+  fp256_detail::to_w(b, y);
+  asm("v_sub_co_u32 %0, vcc, %0, %9\n\t" P256_NOP
+      "v_subb_co_u32 %1, vcc, %1, %10, vcc\n\t" P256_NOP
+      "v_subb_co_u32 %2, vcc, %2, %11, vcc\n\t" P256_NOP
+      "v_subb_co_u32 %3, vcc, %3, %12, vcc\n\t" P256_NOP
+      "v_subb_co_u32 %4, vcc, %4, %13, vcc\n\t" P256_NOP
+      "v_subb_co_u32 %5, vcc, %5, %14, vcc\n\t" P256_NOP
+      "v_subb_co_u32 %6, vcc, %6, %15, vcc\n\t" P256_NOP
+      "v_subb_co_u32 %7, vcc, %7, %16, vcc\n\t" P256_NOP
+      "v_cndmask_b32 %8, 0, -1, vcc"
+      : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "=&v"(m)
+      : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7])
+      : "vcc");
+  const u32 one = m & 1u;  // borrow: add p = {m, m, m, 0, 0, 0, m & 1, m} back
+  asm("v_add_co_u32 %0, vcc, %0, %8\n\t" P256_NOP
+      "v_addc_co_u32 %1, vcc, %1, %8, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %6, vcc, %6, %9, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %7, vcc, %7, %8, vcc"
+      : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+      : "v"(m), "v"(one)
+      : "vcc");
+  return fp256_detail::from_w(x);
+}
+// host functions parsed during the device pass resolve to these overloads
+__host__ inline elt32_t fp256_add(const elt32_t& a, const elt32_t& b);
+__host__ inline elt32_t fp256_sub(const elt32_t& a, const elt32_t& b);
+#define P256_HOSTDEV __host__ inline
+#else
+#define P256_HOSTDEV LF_HD
+#endif
+P256_HOSTDEV elt32_t fp256_add(const elt32_t& a, const elt32_t& b) {
   u32 x[8], y[8], t[8];
   fp256_detail::to_w(a, x);
   fp256_detail::to_w(b, y);
@@ -80,7 +162,7 @@ LF_HD elt32_t fp256_add(const elt32_t& a, const elt32_t& b) {
   fp256_detail::cond_sub_p(t, (u32)c);
   return fp256_detail::from_w(t);
 }
-LF_HD elt32_t fp256_sub(const elt32_t& a, const elt32_t& b) {
+P256_HOSTDEV elt32_t fp256_sub(const elt32_t& a, const elt32_t& b) {
   u32 x[8], y[8], t[8];
   fp256_detail::to_w(a, x);
   fp256_detail::to_w(b, y);
