@@ -141,6 +141,111 @@ __device__ __forceinline__ elt32_t fp256_sub(const elt32_t& a, const elt32_t& b)
       : "vcc");
   return fp256_detail::from_w(x);
 }
+// x = (c : x) - p if that is not negative (x < 2p with its carry bit c): the second half of fp256_add
+__device__ __forceinline__ void p256_cond_sub(u32 (&x)[8], u32 c) {
+  u32 d[8];
+  // (c : x) - p, p = {-1, -1, -1, 0, 0, 0, 1, -1}; the final borrow is set iff the sum is below p
+  asm("v_subrev_co_u32 %0, vcc, -1, %8\n\t" P256_NOP
+      "v_subbrev_co_u32 %1, vcc, -1, %9, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %2, vcc, -1, %10, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %3, vcc, 0, %11, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %4, vcc, 0, %12, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %5, vcc, 0, %13, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %6, vcc, 1, %14, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %7, vcc, -1, %15, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %16, vcc, 0, %16, vcc\n\t" P256_NOP
+      "v_cndmask_b32 %8, %0, %8, vcc\n\t"
+      "v_cndmask_b32 %9, %1, %9, vcc\n\t"
+      "v_cndmask_b32 %10, %2, %10, vcc\n\t"
+      "v_cndmask_b32 %11, %3, %11, vcc\n\t"
+      "v_cndmask_b32 %12, %4, %12, vcc\n\t"
+      "v_cndmask_b32 %13, %5, %13, vcc\n\t"
+      "v_cndmask_b32 %14, %6, %14, vcc\n\t"
+      "v_cndmask_b32 %15, %7, %15, vcc"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "+v"(x[0]), "+v"(x[1]),
+        "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(c)
+      :
+      : "vcc");
+}
+// Montgomery product on the device: 8 x 8 product scanning (64 v_mad_u64_u32 into a 64-bit column accumulator + carry count, as
+// fp_mul in fields.h), then the reduction in FOUR 64-bit steps -- p = -1 (mod 2^64), so the quotient digit m = (T[i+1] : T[i]) is
+// the two low limbs themselves and m p = m 2^256 - m 2^224 + m 2^192 + m 2^96 - m only adds and subtracts m at limb offsets
+// 3, 6, 8 and 7: one add chain over limbs i+3 .. i+9 and one subtract chain over i+7 .. i+9 per step; what would ripple beyond
+// limb i+9 cannot reach a later quotient digit (those are limbs <= 7), so the four carry and four borrow bits are applied
+// together at the end.  255 instead of hipcc's 507 instructions for the portable code below (checked against Python integers
+// in tests/test_device_arith_on_host.py via the same limb algorithm, and by every GPU parity test of the field).
+__device__ __forceinline__ elt32_t fp256_mul(const elt32_t& a, const elt32_t& b) {
+  u32 x[8], y[8], T[17];
+  fp256_detail::to_w(a, x);
+  fp256_detail::to_w(b, y);
+  u64 acc = 0;
+  u32 ov = 0;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+#pragma unroll
+    for (int i = (k > 7 ? k - 7 : 0); i <= (k < 7 ? k : 7); ++i) {
+      if (k == 0 || (k == 1 && i == 0)) FP_MAD(acc, x[i], y[k - i]);  // cannot carry out of 64 bits yet
+      else FP_MADC(acc, ov, x[i], y[k - i]);
+    }
+    FP_COL(T[k], acc, ov);
+  }
+  T[15] = (u32)acc;
+  T[16] = 0;
+  u32 cc[4], bb[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int i = 2 * s;
+    const u32 m0 = T[i], m1 = T[i + 1];
+    asm(
+      "v_add_co_u32 %0, vcc, %0, %8\n\t" P256_NOP
+      "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %2, vcc, 0, %2, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %3, vcc, %3, %8, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %4, vcc, %4, %9, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %5, vcc, %5, %8, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %6, vcc, %6, %9, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %7, vcc, 0, 0, vcc"
+        : "+v"(T[i + 3]), "+v"(T[i + 4]), "+v"(T[i + 5]), "+v"(T[i + 6]), "+v"(T[i + 7]), "+v"(T[i + 8]), "+v"(T[i + 9]), "=&v"(cc[s])
+        : "v"(m0), "v"(m1)
+        : "vcc");
+    asm(
+      "v_sub_co_u32 %0, vcc, %0, %4\n\t" P256_NOP
+      "v_subb_co_u32 %1, vcc, %1, %5, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %2, vcc, 0, %2, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %3, vcc, 0, 0, vcc"
+        : "+v"(T[i + 7]), "+v"(T[i + 8]), "+v"(T[i + 9]), "=&v"(bb[s])
+        : "v"(m0), "v"(m1)
+        : "vcc");
+  }
+  asm(
+      "v_add_co_u32 %0, vcc, %0, %7\n\t" P256_NOP
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %3, vcc, 0, %3, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %4, vcc, %4, %9, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %5, vcc, 0, %5, vcc\n\t" P256_NOP
+      "v_addc_co_u32 %6, vcc, %6, %10, vcc"
+      : "+v"(T[10]), "+v"(T[11]), "+v"(T[12]), "+v"(T[13]), "+v"(T[14]), "+v"(T[15]), "+v"(T[16])
+      : "v"(cc[0]), "v"(cc[1]), "v"(cc[2]), "v"(cc[3])
+      : "vcc");
+  asm(
+      "v_sub_co_u32 %0, vcc, %0, %7\n\t" P256_NOP
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\t" P256_NOP
+      "v_subb_co_u32 %2, vcc, %2, %8, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %3, vcc, 0, %3, vcc\n\t" P256_NOP
+      "v_subb_co_u32 %4, vcc, %4, %9, vcc\n\t" P256_NOP
+      "v_subbrev_co_u32 %5, vcc, 0, %5, vcc\n\t" P256_NOP
+      "v_subb_co_u32 %6, vcc, %6, %10, vcc"
+      : "+v"(T[10]), "+v"(T[11]), "+v"(T[12]), "+v"(T[13]), "+v"(T[14]), "+v"(T[15]), "+v"(T[16])
+      : "v"(bb[0]), "v"(bb[1]), "v"(bb[2]), "v"(bb[3])
+      : "vcc");
+  u32 r[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = T[8 + k];
+  p256_cond_sub(r, T[16]);
+  return fp256_detail::from_w(r);
+}
+__host__ inline elt32_t fp256_mul(const elt32_t& a, const elt32_t& b);
 // host functions parsed during the device pass resolve to these overloads
 __host__ inline elt32_t fp256_add(const elt32_t& a, const elt32_t& b);
 __host__ inline elt32_t fp256_sub(const elt32_t& a, const elt32_t& b);
@@ -187,7 +292,7 @@ LF_HD elt32_t fp256_neg(const elt32_t& a) { return fp256_sub(e32_zero(), a); }
 
 // Montgomery product a * b / 2^256 mod p: operand scanning over 32-bit limbs, one multiplication-free reduction step per
 // limb (m = t[0]: t += m * p, then drop the zero limb).
-LF_HD elt32_t fp256_mul(const elt32_t& a, const elt32_t& b) {
+P256_HOSTDEV elt32_t fp256_mul(const elt32_t& a, const elt32_t& b) {
   u32 x[8], y[8];
   fp256_detail::to_w(a, x);
   fp256_detail::to_w(b, y);
