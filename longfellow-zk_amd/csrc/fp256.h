@@ -180,15 +180,211 @@ __device__ __forceinline__ elt32_t fp256_mul(const elt32_t& a, const elt32_t& b)
   fp256_detail::to_w(b, y);
   u64 acc = 0;
   u32 ov = 0;
-#pragma unroll
-  for (int k = 0; k < 15; ++k) {
-#pragma unroll
-    for (int i = (k > 7 ? k - 7 : 0); i <= (k < 7 ? k : 7); ++i) {
-      if (k == 0 || (k == 1 && i == 0)) FP_MAD(acc, x[i], y[k - i]);  // cannot carry out of 64 bits yet
-      else FP_MADC(acc, ov, x[i], y[k - i]);
-    }
-    FP_COL(T[k], acc, ov);
-  }
+  // one column of the product per statement: its products first, each with the carry out of the 64-bit accumulator in an SGPR
+  // pair of its own, then the carries into the count -- a carry link is then separated from its producer by the column's other
+  // instructions instead of by the two wait states (s_nop 1) gfx950 wants between a VALU that writes a carry and its consumer
+  u64 sc[8];
+  FP_MAD(acc, x[0], y[0]);
+  FP_COL(T[0], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %4, %5, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %6, %7, %0\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1])
+      : "v"(x[0]), "v"(y[1]), "v"(x[1]), "v"(y[0])
+      : "vcc");
+  FP_COL(T[1], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %5, %6, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %7, %8, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %9, %10, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2])
+      : "v"(x[0]), "v"(y[2]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[0])
+      : "vcc");
+  FP_COL(T[2], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %6, %7, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %8, %9, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %10, %11, %0\n\t"
+      "v_mad_u64_u32 %0, %5, %12, %13, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %5"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2]), "=&s"(sc[3])
+      : "v"(x[0]), "v"(y[3]), "v"(x[1]), "v"(y[2]), "v"(x[2]), "v"(y[1]), "v"(x[3]), "v"(y[0])
+      : "vcc");
+  FP_COL(T[3], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %7, %8, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %9, %10, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %11, %12, %0\n\t"
+      "v_mad_u64_u32 %0, %5, %13, %14, %0\n\t"
+      "v_mad_u64_u32 %0, %6, %15, %16, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %5\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %6"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2]), "=&s"(sc[3]), "=&s"(sc[4])
+      : "v"(x[0]), "v"(y[4]), "v"(x[1]), "v"(y[3]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[1]), "v"(x[4]), "v"(y[0])
+      : "vcc");
+  FP_COL(T[4], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %8, %9, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %10, %11, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %12, %13, %0\n\t"
+      "v_mad_u64_u32 %0, %5, %14, %15, %0\n\t"
+      "v_mad_u64_u32 %0, %6, %16, %17, %0\n\t"
+      "v_mad_u64_u32 %0, %7, %18, %19, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %5\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %6\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %7"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2]), "=&s"(sc[3]), "=&s"(sc[4]), "=&s"(sc[5])
+      : "v"(x[0]), "v"(y[5]), "v"(x[1]), "v"(y[4]), "v"(x[2]), "v"(y[3]), "v"(x[3]), "v"(y[2]), "v"(x[4]), "v"(y[1]), "v"(x[5]), "v"(y[0])
+      : "vcc");
+  FP_COL(T[5], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %9, %10, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %11, %12, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %13, %14, %0\n\t"
+      "v_mad_u64_u32 %0, %5, %15, %16, %0\n\t"
+      "v_mad_u64_u32 %0, %6, %17, %18, %0\n\t"
+      "v_mad_u64_u32 %0, %7, %19, %20, %0\n\t"
+      "v_mad_u64_u32 %0, %8, %21, %22, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %5\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %6\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %7\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %8"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2]), "=&s"(sc[3]), "=&s"(sc[4]), "=&s"(sc[5]), "=&s"(sc[6])
+      : "v"(x[0]), "v"(y[6]), "v"(x[1]), "v"(y[5]), "v"(x[2]), "v"(y[4]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[2]), "v"(x[5]), "v"(y[1]), "v"(x[6]), "v"(y[0])
+      : "vcc");
+  FP_COL(T[6], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %10, %11, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %12, %13, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %14, %15, %0\n\t"
+      "v_mad_u64_u32 %0, %5, %16, %17, %0\n\t"
+      "v_mad_u64_u32 %0, %6, %18, %19, %0\n\t"
+      "v_mad_u64_u32 %0, %7, %20, %21, %0\n\t"
+      "v_mad_u64_u32 %0, %8, %22, %23, %0\n\t"
+      "v_mad_u64_u32 %0, %9, %24, %25, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %5\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %6\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %7\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %8\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %9"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2]), "=&s"(sc[3]), "=&s"(sc[4]), "=&s"(sc[5]), "=&s"(sc[6]), "=&s"(sc[7])
+      : "v"(x[0]), "v"(y[7]), "v"(x[1]), "v"(y[6]), "v"(x[2]), "v"(y[5]), "v"(x[3]), "v"(y[4]), "v"(x[4]), "v"(y[3]), "v"(x[5]), "v"(y[2]), "v"(x[6]), "v"(y[1]), "v"(x[7]), "v"(y[0])
+      : "vcc");
+  FP_COL(T[7], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %9, %10, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %11, %12, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %13, %14, %0\n\t"
+      "v_mad_u64_u32 %0, %5, %15, %16, %0\n\t"
+      "v_mad_u64_u32 %0, %6, %17, %18, %0\n\t"
+      "v_mad_u64_u32 %0, %7, %19, %20, %0\n\t"
+      "v_mad_u64_u32 %0, %8, %21, %22, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %5\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %6\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %7\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %8"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2]), "=&s"(sc[3]), "=&s"(sc[4]), "=&s"(sc[5]), "=&s"(sc[6])
+      : "v"(x[1]), "v"(y[7]), "v"(x[2]), "v"(y[6]), "v"(x[3]), "v"(y[5]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[3]), "v"(x[6]), "v"(y[2]), "v"(x[7]), "v"(y[1])
+      : "vcc");
+  FP_COL(T[8], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %8, %9, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %10, %11, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %12, %13, %0\n\t"
+      "v_mad_u64_u32 %0, %5, %14, %15, %0\n\t"
+      "v_mad_u64_u32 %0, %6, %16, %17, %0\n\t"
+      "v_mad_u64_u32 %0, %7, %18, %19, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %5\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %6\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %7"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2]), "=&s"(sc[3]), "=&s"(sc[4]), "=&s"(sc[5])
+      : "v"(x[2]), "v"(y[7]), "v"(x[3]), "v"(y[6]), "v"(x[4]), "v"(y[5]), "v"(x[5]), "v"(y[4]), "v"(x[6]), "v"(y[3]), "v"(x[7]), "v"(y[2])
+      : "vcc");
+  FP_COL(T[9], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %7, %8, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %9, %10, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %11, %12, %0\n\t"
+      "v_mad_u64_u32 %0, %5, %13, %14, %0\n\t"
+      "v_mad_u64_u32 %0, %6, %15, %16, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %5\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %6"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2]), "=&s"(sc[3]), "=&s"(sc[4])
+      : "v"(x[3]), "v"(y[7]), "v"(x[4]), "v"(y[6]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[4]), "v"(x[7]), "v"(y[3])
+      : "vcc");
+  FP_COL(T[10], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %6, %7, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %8, %9, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %10, %11, %0\n\t"
+      "v_mad_u64_u32 %0, %5, %12, %13, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %5"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2]), "=&s"(sc[3])
+      : "v"(x[4]), "v"(y[7]), "v"(x[5]), "v"(y[6]), "v"(x[6]), "v"(y[5]), "v"(x[7]), "v"(y[4])
+      : "vcc");
+  FP_COL(T[11], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %5, %6, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %7, %8, %0\n\t"
+      "v_mad_u64_u32 %0, %4, %9, %10, %0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %4"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1]), "=&s"(sc[2])
+      : "v"(x[5]), "v"(y[7]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[5])
+      : "vcc");
+  FP_COL(T[12], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %4, %5, %0\n\t"
+      "v_mad_u64_u32 %0, %3, %6, %7, %0\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %3"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0]), "=&s"(sc[1])
+      : "v"(x[6]), "v"(y[7]), "v"(x[7]), "v"(y[6])
+      : "vcc");
+  FP_COL(T[13], acc, ov);
+  asm(
+      "v_mad_u64_u32 %0, %2, %3, %4, %0\n\t"
+      "s_nop 1\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, %2"
+      : "+v"(acc), "+v"(ov), "=&s"(sc[0])
+      : "v"(x[7]), "v"(y[7])
+      : "vcc");
+  FP_COL(T[14], acc, ov);
   T[15] = (u32)acc;
   T[16] = 0;
   u32 cc[4], bb[4];

@@ -9,4 +9,5 @@ import json
 d = json.loads(open("/tmp/o.json").read().strip().splitlines()[-1])
 print("mdoc sig", d["wire_bytes_identical_to_reference"], d["gpu_cxx_driver_ms"], sorted(d["gpu_cxx_driver_total_ms_all_reps"]))
 PY
-timeout -k 10 300 python tools/stress_zk256.py 200 2>&1 | tail -1
+timeout -k 10 300 python tools/stress_zk256.py 300 2>&1 | tail -1
+timeout -k 5 120 ./tools/ubench_p256 2>&1 | tail -2
