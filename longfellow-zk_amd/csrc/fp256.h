@@ -172,8 +172,9 @@ __device__ __forceinline__ void p256_cond_sub(u32 (&x)[8], u32 c) {
 // the two low limbs themselves and m p = m 2^256 - m 2^224 + m 2^192 + m 2^96 - m only adds and subtracts m at limb offsets
 // 3, 6, 8 and 7: one add chain over limbs i+3 .. i+9 and one subtract chain over i+7 .. i+9 per step; what would ripple beyond
 // limb i+9 cannot reach a later quotient digit (those are limbs <= 7), so the four carry and four borrow bits are applied
-// together at the end.  255 instead of hipcc's 507 instructions for the portable code below (checked against Python integers
-// in tests/test_device_arith_on_host.py via the same limb algorithm, and by every GPU parity test of the field).
+// together at the end.  255 instead of hipcc's 507 instructions for the portable code below (the limb algorithm is restated and
+// checked against Python integers in tests/test_p256_cpu.py::test_device_montgomery_limb_algorithm; the instructions themselves by
+// the GPU parity tests of the field, tests/test_p256_gpu.py::test_p256_binops with its edge values, and the proof-byte tests).
 __device__ __forceinline__ elt32_t fp256_mul(const elt32_t& a, const elt32_t& b) {
   u32 x[8], y[8], T[17];
   fp256_detail::to_w(a, x);

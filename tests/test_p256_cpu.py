@@ -141,3 +141,64 @@ def test_small_p256_fixture_is_consistent():
     Rinv = pow(1 << 256, -1, p)
     one, n, m, s_ = (int.from_bytes(w[32 * i:32 * i + 32], "little") * Rinv % p for i in range(4))
     assert one == 1 and (2 * n - ((s_ - 2) * m * m - (s_ - 4) * m)) % p == 0
+
+
+def test_device_montgomery_limb_algorithm():
+    """The device's Fp256Base product (csrc/fp256.h, __HIP_DEVICE_COMPILE__ path) restated limb by limb: 8 x 8 product scanning,
+    then the Montgomery reduction in four 64-bit steps -- quotient digit = the two low limbs (p = -1 mod 2^64), one add chain
+    over limbs i+3 .. i+9 and one subtract chain over i+7 .. i+9 per step, the four carry and four borrow bits that would ripple
+    further applied together at the end, one conditional subtraction -- against Python integers, edge values included.  (The
+    instructions themselves are checked on the GPU: tests/test_p256_gpu.py.)"""
+    import random
+    p = 2**256 - 2**224 + 2**192 + 2**96 - 1
+    M32 = 2**32 - 1
+    rinv = pow(2**256, -1, p)
+
+    def mont(a, b):
+        x = [(a >> (32 * i)) & M32 for i in range(8)]
+        y = [(b >> (32 * i)) & M32 for i in range(8)]
+        T, acc = [0] * 17, 0
+        for k in range(15):
+            for i in range(max(0, k - 7), min(7, k) + 1):
+                acc += x[i] * y[k - i]
+            T[k] = acc & M32
+            acc >>= 32
+        T[15] = acc & M32
+        assert acc >> 32 == 0
+        cs, bs = [], []
+        for i in (0, 2, 4, 6):
+            m0, m1 = T[i], T[i + 1]
+            c = 0
+            for k, add in enumerate((m0, m1, 0, m0, m1, m0, m1)):
+                s = T[i + 3 + k] + add + c
+                T[i + 3 + k], c = s & M32, s >> 32
+            cs.append(c)
+            bo = 0
+            for k, sub in enumerate((m0, m1, 0)):
+                d = T[i + 7 + k] - sub - bo
+                T[i + 7 + k], bo = d & M32, 1 if d < 0 else 0
+            bs.append(bo)
+        c = 0
+        for k, add in enumerate((cs[0], 0, cs[1], 0, cs[2], 0, cs[3])):
+            s = T[10 + k] + add + c
+            T[10 + k], c = s & M32, s >> 32
+        bo = 0
+        for k, sub in enumerate((bs[0], 0, bs[1], 0, bs[2], 0, bs[3])):
+            d = T[10 + k] - sub - bo
+            T[10 + k], bo = d & M32, 1 if d < 0 else 0
+        v = sum(T[8 + k] << (32 * k) for k in range(8)) + (T[16] << 256)
+        assert T[16] in (0, 1) and v < 2 * p
+        return v - p if v >= p else v
+
+    rng = random.Random(7)
+    edge = [0, 1, 2, p - 1, p - 2, 2**255, 2**224, 2**192 - 1, 2**96, 2**96 - 1, (p - 1) // 2, M32, 2**64 - 1, 2**256 - 2**224]
+    for a in edge:
+        for b in edge:
+            assert mont(a, b) == (a * b * rinv) % p
+    for _ in range(20000):
+        a, b = rng.randrange(p), rng.randrange(p)
+        if rng.random() < 0.1:
+            a = rng.choice(edge)
+        if rng.random() < 0.1:
+            b = p - rng.randrange(1, 2**70)
+        assert mont(a, b) == (a * b * rinv) % p
