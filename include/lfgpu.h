@@ -40,6 +40,9 @@ extern "C" {
 #define LFGPU_ERR_UNSUPPORTED 3 /* valid request outside what this build covers */
 #define LFGPU_ERR_NOMEM 4
 #define LFGPU_ERR_ASSERT 5      /* a reference check() would have failed (e.g. assert-zero term) */
+#define LFGPU_ERR_BUSY 6        /* the device could not place a resident kernel's workgroups together (another tenant holds
+                                   CUs); the prover-level entry points handle it themselves by falling back to per-launch
+                                   kernels -- only a direct caller of the resident-kernel internals can see it */
 
 #define LFGPU_FIELD_GF2_128 4 /* FieldID, lib/proto/circuit_io.h:24-36 */
 #define LFGPU_FIELD_FP128 6
@@ -57,6 +60,12 @@ int lfgpu_init(int device, lfgpu_ctx** out);
 int lfgpu_shutdown(lfgpu_ctx* ctx);
 const char* lfgpu_last_error(const lfgpu_ctx* ctx);
 int lfgpu_set_stream(lfgpu_ctx* ctx, void* hip_stream); /* NULL = default stream */
+/* Gives the context a non-blocking stream of its own (destroyed by lfgpu_shutdown).  Contexts are independent -- nothing
+ * below this ABI is process-global except the per-device CU budget of the resident sumcheck kernels -- so K host threads
+ * may each drive one context (its circuits, provers and transcripts) on the same device concurrently; with the default
+ * (NULL) stream their work would serialise.  This is the throughput mode of BM_ShaZK's loop
+ * (lib/circuits/sha/flatsha256_circuit_test.cc:510-536, one proof after the other) on a GPU that one proof leaves idle. */
+int lfgpu_own_stream(lfgpu_ctx* ctx);
 int lfgpu_sync(lfgpu_ctx* ctx);
 /* device-memory helpers so that C / ctypes / cgo callers need no HIP runtime */
 int lfgpu_malloc(lfgpu_ctx* ctx, size_t bytes, void** d_out);

@@ -79,6 +79,10 @@ typedef struct {
 /* CircuitRep::from_bytes (lib/proto/circuit.h): parses the LFC1 bytes, delta-decodes every layer's corners
  * (circuit_reader.h:55-233) and uploads them with lfgpu_quad_upload.  LFGPU_ERR_ARG on malformed input. */
 int lfgpu_circuit_from_lfc1(lfgpu_ctx* ctx, const uint8_t* bytes, size_t len, lfgpu_circuit** out);
+/* A second handle on the same uploaded circuit for ANOTHER context of the same device (throughput mode: K host threads, each
+ * with its own context -- lfgpu_own_stream -- prover and transcript, one copy of the circuit in HBM).  The device arrays are
+ * reference-counted: the handles may be freed in any order.  `src` must not be in use by another thread during the call. */
+int lfgpu_circuit_share(lfgpu_ctx* ctx, const lfgpu_circuit* src, lfgpu_circuit** out);
 int lfgpu_circuit_get_info(const lfgpu_circuit* c, lfgpu_circuit_info* info);
 int lfgpu_circuit_layer_info(const lfgpu_circuit* c, size_t layer, size_t* logw, size_t* nw, size_t* nterms);
 int lfgpu_circuit_free(lfgpu_circuit* c);

@@ -26,7 +26,7 @@ F64_P = 2**64 - 2**32 + 1
 F64_OMEGA32 = 2752994695033296049
 
 ABI_SYMBOLS = [
-    "lfgpu_init", "lfgpu_shutdown", "lfgpu_last_error", "lfgpu_set_stream", "lfgpu_sync", "lfgpu_malloc",
+    "lfgpu_init", "lfgpu_shutdown", "lfgpu_last_error", "lfgpu_set_stream", "lfgpu_own_stream", "lfgpu_sync", "lfgpu_malloc",
     "lfgpu_free", "lfgpu_memcpy_h2d", "lfgpu_memcpy_d2h", "lfgpu_fp128_fft", "lfgpu_f64_2_fft", "lfgpu_gf2128_lch14_fft",
     "lfgpu_gf2128_rs_encode_rows", "lfgpu_gf2128_rs_encode_tableau", "lfgpu_fp128_rs_encode_rows", "lfgpu_fp256_rs_encode_rows", "lfgpu_column_commit", "lfgpu_column_leaves", "lfgpu_merkle_build_tree",
     "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     # include/lfgpu_zk.h
     "lfgpu_transcript_new", "lfgpu_transcript_free", "lfgpu_transcript_get_ops", "lfgpu_transcript_write_bytes",
     "lfgpu_transcript_write_elt", "lfgpu_transcript_write_elt_array", "lfgpu_transcript_bytes", "lfgpu_sha256",
-    "lfgpu_aes256_ecb_block", "lfgpu_host_gf2128_mul", "lfgpu_crypto_hw", "lfgpu_circuit_from_lfc1", "lfgpu_circuit_get_info", "lfgpu_circuit_layer_info",
+    "lfgpu_aes256_ecb_block", "lfgpu_host_gf2128_mul", "lfgpu_crypto_hw", "lfgpu_circuit_from_lfc1", "lfgpu_circuit_share", "lfgpu_circuit_get_info", "lfgpu_circuit_layer_info",
     "lfgpu_circuit_free", "lfgpu_zk_prover_new", "lfgpu_zk_prover_param", "lfgpu_zk_commit", "lfgpu_zk_prove",
     "lfgpu_zk_proof_write", "lfgpu_zk_timings", "lfgpu_zk_prover_free", "lfgpu_zk_verify", "lfgpu_zk_verify_committed",
 ]
@@ -96,7 +96,7 @@ def load_library():
     vp, sz, u64, ci = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
     pu64 = C.POINTER(C.c_uint64)
     sig = {
-        "lfgpu_init": [ci, C.POINTER(vp)], "lfgpu_shutdown": [vp], "lfgpu_set_stream": [vp, vp], "lfgpu_sync": [vp],
+        "lfgpu_init": [ci, C.POINTER(vp)], "lfgpu_shutdown": [vp], "lfgpu_set_stream": [vp, vp], "lfgpu_own_stream": [vp], "lfgpu_sync": [vp],
         "lfgpu_malloc": [vp, sz, C.POINTER(vp)], "lfgpu_free": [vp, vp],
         "lfgpu_memcpy_h2d": [vp, vp, vp, sz], "lfgpu_memcpy_d2h": [vp, vp, vp, sz],
         "lfgpu_fp128_fft": [vp, ci, sz, sz, pu64, u64, vp, sz],
@@ -145,6 +145,7 @@ def load_library():
         "lfgpu_raw_eq2": [vp, ci, sz, sz, vp, vp, pu64, vp],
         "lfgpu_quad_bind_gh_all": [vp, sz, vp, vp, pu64, pu64, sz, sz, vp, vp, pu64],
         "lfgpu_circuit_from_lfc1": [vp, vp, sz, C.POINTER(vp)],
+        "lfgpu_circuit_share": [vp, vp, C.POINTER(vp)],
         "lfgpu_circuit_get_info": [vp, C.POINTER(CircuitInfo)],
         "lfgpu_circuit_layer_info": [vp, sz, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)],
         "lfgpu_circuit_free": [vp],
@@ -236,6 +237,11 @@ class LfGpu:
 
     def set_stream(self, stream):
         self._ck(self.L.lfgpu_set_stream(self.h, C.c_void_p(int(stream))))
+
+    def own_stream(self):
+        """a non-blocking stream of the context's own: K contexts in K host threads then run concurrently on one device"""
+        self._ck(self.L.lfgpu_own_stream(self.h))
+        return self
 
     def sync(self):
         self._ck(self.L.lfgpu_sync(self.h))
@@ -595,14 +601,21 @@ def aes256_ecb_block(key, block):
 class Circuit:
     """A circuit parsed from the reference's LFC1 wire bytes, layers resident on the device (lfgpu_circuit)."""
 
-    def __init__(self, gpu, lfc1_bytes):
+    def __init__(self, gpu, lfc1_bytes, _shared_from=None):
         self.gpu = gpu
         h = C.c_void_p()
-        raw = bytes(lfc1_bytes)
-        gpu._ck(gpu.L.lfgpu_circuit_from_lfc1(gpu.h, raw, len(raw), C.byref(h)))
+        if _shared_from is not None:
+            gpu._ck(gpu.L.lfgpu_circuit_share(gpu.h, _shared_from.h, C.byref(h)))
+        else:
+            raw = bytes(lfc1_bytes)
+            gpu._ck(gpu.L.lfgpu_circuit_from_lfc1(gpu.h, raw, len(raw), C.byref(h)))
         self.h = h
         self.info = CircuitInfo()
         gpu._ck(gpu.L.lfgpu_circuit_get_info(self.h, C.byref(self.info)))
+
+    def share(self, gpu):
+        """a handle on the same device-resident circuit for another context of the same device (lfgpu_circuit_share)"""
+        return Circuit(gpu, None, _shared_from=self)
 
     def layer(self, i):
         a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()

@@ -136,6 +136,34 @@ elt_t h_lch14_twiddle(const GfHostCtx* g, unsigned i, u64 u) {
   return t;
 }
 
+// ------------------------------------------------------------------ CU budget of the resident kernels (ctx.h)
+#include <mutex>
+namespace {
+struct CuBudget {
+  std::mutex m;
+  int used[64] = {0};
+} g_cu;
+int cu_limit(const lfgpu_ctx* c) {
+  static const int env = getenv("LFGPU_CU_BUDGET") ? atoi(getenv("LFGPU_CU_BUDGET")) : -1;
+  return env >= 0 ? env : c->num_cu;
+}
+}  // namespace
+bool lf_cu_acquire(lfgpu_ctx* c, int n) {
+  if (n <= 0 || c->device < 0 || c->device >= 64) return false;
+  std::lock_guard<std::mutex> lk(g_cu.m);
+  if (g_cu.used[c->device] + n > cu_limit(c)) return false;
+  g_cu.used[c->device] += n;
+  c->cu_held += n;
+  return true;
+}
+void lf_cu_release(lfgpu_ctx* c, int n) {
+  if (n < 0 || n > c->cu_held) n = c->cu_held;
+  if (n == 0) return;
+  std::lock_guard<std::mutex> lk(g_cu.m);
+  g_cu.used[c->device] -= n;
+  c->cu_held -= n;
+}
+
 // first launch of any kernel of this library loads its code object onto the device (~150 ms for the 2 MiB of gfx950 code):
 // lfgpu_init pays that, so that the first FFT / circuit upload / proof of a process is not the one that does
 __global__ void lf_warm_kernel(u32* p) {
@@ -187,6 +215,11 @@ int lfgpu_shutdown(lfgpu_ctx* c) {
   if (!c) return LFGPU_ERR_ARG;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  lf_cu_release(c, -1);
+  if (c->own_stream) {
+    if (c->stream == c->own_stream) c->stream = nullptr;
+    hipStreamDestroy(c->own_stream);
+  }
   for (auto& kv : c->tables) hipFree(kv.second);
   if (c->scratch) hipFree(c->scratch);
   if (c->scratch2) hipFree(c->scratch2);
@@ -210,6 +243,14 @@ const char* lfgpu_last_error(const lfgpu_ctx* c) { return c ? c->err : "null con
 int lfgpu_set_stream(lfgpu_ctx* c, void* s) {
   if (!c) return LFGPU_ERR_ARG;
   c->stream = (hipStream_t)s;
+  return LFGPU_OK;
+}
+int lfgpu_own_stream(lfgpu_ctx* c) {
+  if (!c) return LFGPU_ERR_ARG;
+  LF_HIP(c, hipSetDevice(c->device));
+  if (!c->own_stream) LF_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  LF_HIP(c, hipStreamSynchronize(c->stream));  // what was enqueued on the old stream is complete before the switch
+  c->stream = c->own_stream;
   return LFGPU_OK;
 }
 int lfgpu_sync(lfgpu_ctx* c) {

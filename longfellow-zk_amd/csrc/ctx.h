@@ -70,7 +70,21 @@ struct lfgpu_ctx {
   int sc_tail_ok = -1;     // the shrinking-grid kernel may use its LDS tail (-1 undecided)
   int num_cu = 256;
   u64 wall_khz = 100000;  // rate of wall_clock64() (hipDeviceAttributeWallClockRate)
+  hipStream_t own_stream = nullptr;  // lfgpu_own_stream: created by the library, destroyed with the context
+  // resident (spin-barrier) kernels: CUs this context holds of its device's budget (lf_cu_acquire), and how often a grid
+  // could not be placed although the budget said so (another process on the device): after two strikes the context stops
+  // launching resident grids
+  int cu_held = 0;
+  int grid_strikes = 0;
 };
+// Per-device CU budget of the kernels whose workgroups wait for each other (sc_grid_layer_kernel, grid256_layer_kernel, the
+// single-workgroup resident kernel).  Such a grid is only safe when ALL its workgroups are placed together; two grids each
+// half placed would wait for CUs the other holds until their timeouts.  Every launch therefore first takes its workgroup
+// count from a process-wide counter per device (budget = the device's CU count, LFGPU_CU_BUDGET overrides) and gives it back
+// as the grid shrinks / ends: the sum over all live grids never exceeds the CUs, so every one of them gets placed whatever
+// else (ordinary kernels, which always finish) shares the device.  All or nothing; false = take another driver this time.
+bool lf_cu_acquire(lfgpu_ctx* c, int n);
+void lf_cu_release(lfgpu_ctx* c, int n);  // n < 0: everything the context holds
 
 int lf_fail(lfgpu_ctx* c, int code, const char* fmt, ...);
 #define LF_HIP(c, call)                                                                 \
@@ -150,12 +164,13 @@ bool lf_sc_resident_ok(lfgpu_ctx* c);
 // device-wide barrier in front of the offsets.  Lives with the layer's quad.
 struct ScGridOffCache {
   u32* d = nullptr;                 // [64 round-hands][LF_SC_GRID_WGS + 1] words
-  u32 key[4] = {0, 0, 0, 0};        // {first round-hand, workgroups, HQUAD size, entries per workgroup} of the record
+  u32 key[7] = {0, 0, 0, 0, 0, 0, 0};  // {first round-hand, workgroups, HQUAD size, entries per workgroup, both hand sizes, logw} of the record
   int state = 0;                    // 0 none, 1 being recorded (valid once the layer ends well), 2 valid
 };
 int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, const u32* d_nh, void* W0, size_t nW0,
                      void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
-                     size_t logw, void* d_state, ScGridOffCache* oc = nullptr);
+                     size_t logw, void* d_state, ScGridOffCache* oc = nullptr, u32* G_out = nullptr, u32* per_wg_out = nullptr);
+// ^ LFGPU_ERR_BUSY (nothing launched, no message): the device's CU budget is short of the grid -- use another driver now
 #define LF_SC_GRID_WGS 128                         // most workgroups the shrinking-grid kernel starts with
 #define LF_SC_GRID_MAX (256 * 1024)             // largest HQUAD / hand array it takes
 #define LF_SC_GRID_STATE_BYTES (64 + 1024 + 32 * LF_SC_GRID_WGS + 4 * LF_SC_GRID_WGS + 64 + 36 * LF_SC_GRID_MAX)

@@ -42,6 +42,17 @@ LF_HD void st16(elt_t* p, elt_t e) {
   *reinterpret_cast<uint4*>(p) = v;
 }
 
+// Payload-before-sequence ordering for words a RUNNING kernel posts to pinned host memory with relaxed system-scope stores:
+// the stores are separate vector-memory instructions (the post spans several 64-byte lines) and gfx950 gives no order among
+// them, and a workgroup-scope release fence emits NO wait here.  s_waitcnt vmcnt(0) holds the lane until every store it has
+// issued is acknowledged (gfx9 counts stores in vmcnt), without the L2 write-back an agent / system release would cost; the
+// sequence word is stored only after it.  (ISA pinned by tests/test_abi_and_adapters.py::test_post_publish_waits_for_payload.)
+__device__ __forceinline__ void lf_wait_stores_before_publish() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // ===================================================================== Fp128
 #define FP_P_LO 0x0000000000000001ull
 #define FP_P_HI 0xFFFFF00000000000ull

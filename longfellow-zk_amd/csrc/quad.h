@@ -1,5 +1,6 @@
 // quad.h -- an uploaded circuit layer (lfgpu_quad) as quad.hip, sumcheck.hip and zk256.hip see it.
 #pragma once
+#include <memory>
 #include <vector>
 
 #include "ctx.h"
@@ -10,8 +11,16 @@ struct __attribute__((aligned(16))) corner4 {
   u32 g, h0, h1, vi;
 };
 
+// the device arrays of an uploaded layer: immutable after lf_quad_upload_corners, so the quads of several contexts on the
+// same device may read them (lf_quad_share: K provers in K host threads, one copy of the circuit)
+struct QuadArrays {
+  void* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  ~QuadArrays();
+};
+
 struct lfgpu_quad {
   lfgpu_ctx* c;
+  std::shared_ptr<QuadArrays> arrays;  // owner of the six pointers below once the upload has succeeded
   int field;
   size_t n, nk, nv;
   size_t hmax;        // largest hand index (h0 or h1) of any corner: every consumer needs nw > hmax
@@ -37,3 +46,6 @@ struct lfgpu_quad {
 // lfgpu_quad_upload for corners that are already packed and range-checked (g < nv, vi < nk; hmax = largest hand index): the
 // canonical order goes up once, the by-gate order and its offsets are built on the device (quad.hip)
 int lf_quad_upload_corners(lfgpu_ctx* c, int field, size_t n, const corner4* corners, size_t hmax, size_t nk, const void* h_kvec, size_t nv, lfgpu_quad** out);
+// a second handle on the same device arrays for another context of the same device (its own stream, scratch and per-proof
+// caches: the recorded bind shapes / grid offsets are filled by each handle's first proof)
+int lf_quad_share(lfgpu_ctx* c, const lfgpu_quad* src, lfgpu_quad** out);

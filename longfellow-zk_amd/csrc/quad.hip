@@ -223,14 +223,22 @@ __global__ __launch_bounds__(QD_THREADS) void fp_limb_normalize4_kernel(const u3
       hipLaunchKernelGGL(KERNEL<FIELD_FP128>, grid, block, 0, c->stream, __VA_ARGS__);   \
   } while (0)
 
+QuadArrays::~QuadArrays() {
+  for (void* x : p)
+    if (x) (void)hipFree(x);
+}
 extern "C" int lfgpu_quad_free(lfgpu_quad* q) {
   if (!q) return LFGPU_ERR_ARG;
-  if (q->d_morton) (void)hipFree(q->d_morton);
-  if (q->d_bygate) (void)hipFree(q->d_bygate);
-  if (q->d_goff) (void)hipFree(q->d_goff);
-  if (q->d_kvec) (void)hipFree(q->d_kvec);
-  if (q->d_runoff) (void)hipFree(q->d_runoff);
-  if (q->d_nh) (void)hipFree(q->d_nh);
+  if (q->arrays) {
+    q->arrays.reset();  // the last handle frees them
+  } else {  // an upload that failed half-way
+    if (q->d_morton) (void)hipFree(q->d_morton);
+    if (q->d_bygate) (void)hipFree(q->d_bygate);
+    if (q->d_goff) (void)hipFree(q->d_goff);
+    if (q->d_kvec) (void)hipFree(q->d_kvec);
+    if (q->d_runoff) (void)hipFree(q->d_runoff);
+    if (q->d_nh) (void)hipFree(q->d_nh);
+  }
   for (auto& b : q->bind_shape)
     if (b.d_off) (void)hipFree(b.d_off);
   if (q->grid_off.d) (void)hipFree(q->grid_off.d);
@@ -338,6 +346,22 @@ int lf_quad_upload_corners(lfgpu_ctx* c, int field, size_t n, const corner4* cor
     return lf_fail(c, LFGPU_ERR_NOMEM, "quad_upload: device allocation / copy / run structure failed");
   }
   q->nh0 = total;
+  q->arrays = std::make_shared<QuadArrays>();
+  void* const owned[6] = {q->d_morton, q->d_bygate, q->d_goff, q->d_kvec, q->d_runoff, q->d_nh};
+  for (int i = 0; i < 6; ++i) q->arrays->p[i] = owned[i];
+  *out = q;
+  return LFGPU_OK;
+}
+int lf_quad_share(lfgpu_ctx* c, const lfgpu_quad* src, lfgpu_quad** out) {
+  if (!c || !src || !out || !src->arrays || c->device != src->c->device) return lf_fail(c, LFGPU_ERR_ARG, "quad_share: contexts must be on the same device");
+  lfgpu_quad* q = new lfgpu_quad();
+  q->c = c;
+  q->arrays = src->arrays;
+  q->field = src->field;
+  q->n = src->n; q->nk = src->nk; q->nv = src->nv; q->hmax = src->hmax;
+  q->d_morton = src->d_morton; q->d_bygate = src->d_bygate; q->d_goff = src->d_goff; q->d_kvec = src->d_kvec;
+  q->d_runoff = src->d_runoff; q->d_nh = src->d_nh;
+  q->nh0 = src->nh0;
   *out = q;
   return LFGPU_OK;
 }
@@ -626,15 +650,28 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     const size_t v = e ? (size_t)atol(e) : (size_t)128 * 1024;
     return std::min<size_t>(std::max<size_t>(v, 1024), LF_SC_GRID_MAX);
   }();
-  const size_t small_max = (sc_mode == 3 && use_resident) ? grid_max : LF_SC_SMALL_MAX;
+  const size_t resident_max = sc_mode == 3 ? grid_max : LF_SC_SMALL_MAX;  // largest array a resident kernel takes over at
   // Quad::bind_g: enqueued on the stream, nothing read back (the HQUAD size is a circuit constant)
   const double tv0 = verbose ? clk() : 0;
   LF_TRY(lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], &nh));
   const double tv1 = verbose ? clk() : 0;
   const size_t nh0 = nh;
   bool resident = false, have_r = false;
+  // A resident kernel holds CUs of the device's budget (ctx.h); whatever way this function is left, they go back -- after
+  // the kernel has ended, so that the budget never undercounts workgroups that still spin.
+  struct CuGuard {
+    lfgpu_ctx* c;
+    ~CuGuard() {
+      if (c->cu_held) {
+        (void)hipStreamSynchronize(c->stream);  // bounded: every wait of the kernel has a timeout
+        lf_cu_release(c, -1);
+      }
+    }
+  } cu_guard{c};
+  bool resident_off = !use_resident || no_fuse || c->grid_strikes >= 2;  // no (further) hand-off to a resident kernel in this layer
+  u32 grid_G = 0, grid_per_wg = 1;  // the grid's workgroups as the kernel shrinks them (mirrored here to return CUs early)
   u64 last_r[2] = {0, 0};
-  bool small = false, pending = false;  // pending: the binds of (phand, pr) ride in the next fused step
+  bool pending = false;  // the binds of (phand, pr) ride in the next fused step
   int phand = 0;
   elt_t pr{0, 0};
   // the fused step with the current host-side state; applies the pending bind's bookkeeping after it ran
@@ -669,16 +706,23 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   };
   for (size_t rnd = 0; rnd < logw; ++rnd) {
     for (int hand = 0; hand < 2; ++hand) {
-      if (!small && !no_fuse && nh <= small_max && nW[0] <= small_max && nW[1] <= small_max) small = true;
       uint64_t a0[2], a2[2];
-      const double tr0 = (verbose && !small) ? clk() : 0;
-      if (verbose && small && t_small_first == 0) t_small_first = clk();
-      if (small && use_resident) {
-        if (!resident && sc_mode == 3) {  // hand the rest of the layer to the shrinking grid
+      bool fused = false;  // this round-hand ran as a fused single-workgroup step: its binds ride in the next one
+      const double tr0 = verbose ? clk() : 0;
+      // ---- hand the rest of the layer to a resident kernel once the arrays are small enough AND the device's CU budget has
+      // room for its workgroups; without room this round-hand runs on per-launch kernels and the next one asks again
+      if (!resident && !resident_off && std::max(nh, std::max(nW[0], nW[1])) <= resident_max) {
+        // (with a bind still pending the sizes above are the ones before it: the bind only halves them)
+        if (pending) {
+          u64 out[8];
+          LF_TRY(small_step(0, 0, out));
+        }
+        int rc;
+        if (sc_mode == 3) {  // the shrinking grid
           uint8_t* wb = (uint8_t*)wtmp;
-          LF_TRY(lf_sc_grid_begin(c, field, hc[cur], vc[cur], hc[1 - cur], vc[1 - cur], nh, nullptr,
-                                  WH[0], nW[0], WH[1], nW[1], wb, wb + half, wb + 2 * half, wb + 3 * half, qw, 2 * rnd + hand, logw, grid_state, &q->grid_off));
-        } else if (!resident) {  // ... or to the resident workgroup
+          rc = lf_sc_grid_begin(c, field, hc[cur], vc[cur], hc[1 - cur], vc[1 - cur], nh, nullptr, WH[0], nW[0], WH[1], nW[1], wb, wb + half, wb + 2 * half,
+                                wb + 3 * half, qw, 2 * rnd + hand, logw, grid_state, &q->grid_off, &grid_G, &grid_per_wg);
+        } else if (lf_cu_acquire(c, 1)) {  // the resident single workgroup
           ScSmall a{};
           a.field = field;
           a.hc_in = (uint2*)hc[cur];
@@ -691,21 +735,61 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
           a.nW[0] = (u32)nW[0];
           a.nW[1] = (u32)nW[1];
           a.QW = (u64*)qw;
-                LF_TRY(lf_sc_layer_begin(c, a, (u32)(2 * rnd + hand), (u32)(2 * logw), d_W, wtmp));
+          grid_G = 1;
+          rc = lf_sc_layer_begin(c, a, (u32)(2 * rnd + hand), (u32)(2 * logw), d_W, wtmp);
+        } else {
+          rc = LFGPU_ERR_BUSY;
         }
-        resident = true;
+        if (rc == LFGPU_OK) {
+          resident = true;
+          have_r = false;
+          if (verbose && t_small_first == 0) t_small_first = clk();
+        } else if (rc != LFGPU_ERR_BUSY) {
+          return rc;
+        }
+      }
+      if (resident) {
         u64 out[8];
         if (verbose && t_seen != 0) t_think += clk() - t_seen;  // post seen -> answer written: the host's share of the round trip
-        LF_TRY(lf_sc_layer_next(c, have_r ? last_r : nullptr, out));
-        if (verbose) t_seen = clk();
-        a0[0] = out[0]; a0[1] = out[1]; a2[0] = out[2]; a2[1] = out[3];
-      } else if (small) {
-        u64 out[8];
-        LF_TRY(small_step(1, hand, out));
-        a0[0] = out[0]; a0[1] = out[1]; a2[0] = out[2]; a2[1] = out[3];
-      } else {
-        LF_TRY(lfgpu_qw_scatter(c, field, nh, hc[cur], vc[cur], hand, WH[1 - hand], nW[hand], qw));
-        LF_TRY(lfgpu_sumcheck_partials(c, field, nW[hand], qw, WH[hand], a0, a2));
+        const int rc = lf_sc_layer_next(c, have_r ? last_r : nullptr, out);
+        if (rc == LFGPU_ERR_BUSY && !have_r) {
+          // The grid's workgroups were not placed together (its first barrier is that check, and nothing but scratch is
+          // written before it).  The budget makes this impossible within one process; another process on the device can
+          // still hold CUs.  The kernel has left: drive this layer with per-launch kernels from here, on the same state.
+          LF_HIP(c, hipStreamSynchronize(c->stream));
+          lf_cu_release(c, -1);
+          resident = false;
+          resident_off = true;
+          ++c->grid_strikes;
+          if (q->grid_off.state == 1) q->grid_off.state = 0;  // a record that never completed
+          if (verbose) fprintf(stderr, "lfgpu sumcheck_layer: resident grid not placed (strike %d): per-launch kernels for this layer\n", c->grid_strikes);
+        } else if (rc != LFGPU_OK) {
+          return rc;
+        } else {
+          if (verbose) t_seen = clk();
+          a0[0] = out[0]; a0[1] = out[1]; a2[0] = out[2]; a2[1] = out[3];
+          if (sc_mode == 3 && grid_G > 1) {  // the kernel has shrunk its grid to ceil(largest array / per_wg) before this post: those CUs are free
+            nh = (size_t)out[4];
+            const size_t big = std::max(nh, std::max(nW[0], nW[1]));
+            const u32 want = (u32)std::max<size_t>(1, (big + grid_per_wg - 1) / grid_per_wg);
+            if (want < grid_G) {
+              lf_cu_release(c, (int)(grid_G - want));
+              grid_G = want;
+            }
+          }
+        }
+      }
+      if (!resident) {
+        if (!no_fuse && std::max(nh, std::max(nW[0], nW[1])) <= LF_SC_SMALL_MAX) {  // one fused single-workgroup launch per round-hand
+          if (verbose && t_small_first == 0) t_small_first = clk();
+          u64 out[8];
+          LF_TRY(small_step(1, hand, out));
+          a0[0] = out[0]; a0[1] = out[1]; a2[0] = out[2]; a2[1] = out[3];
+          fused = true;
+        } else {
+          LF_TRY(lfgpu_qw_scatter(c, field, nh, hc[cur], vc[cur], hand, WH[1 - hand], nW[hand], qw));
+          LF_TRY(lfgpu_sumcheck_partials(c, field, nW[hand], qw, WH[hand], a0, a2));
+        }
       }
       // coef[0] = eq0*a0, coef[2] = eq0*a2 with eq0 = 1 (logc = 0); coef[1] from sum (prover_layers.h:390-396)
       elt_t coef[3];
@@ -725,13 +809,14 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
       g_out[(hand * logw + rnd) * 2] = r[0];
       g_out[(hand * logw + rnd) * 2 + 1] = r[1];
       sum = F.eval_lagrange(ev, elt_t{r[0], r[1]});
-      if (resident) {  // the challenge goes to the resident workgroup with the next wait
+      if (resident) {  // the challenge goes to the resident kernel with the next wait
         last_r[0] = r[0];
         last_r[1] = r[1];
         have_r = true;
+        nW[hand] = (nW[hand] + 1) / 2;  // what the kernel does with it (the host only mirrors the sizes)
         continue;
       }
-      if (small) {  // the binds run at the head of the next fused step
+      if (fused) {  // the binds run at the head of the next fused step
         pending = true;
         phand = hand;
         pr = elt_t{r[0], r[1]};
@@ -770,8 +855,9 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     u64 out[8];
     LF_TRY(lf_sc_layer_next(c, last_r, out));
     if (q->grid_off.state == 1) q->grid_off.state = 2;  // the layer ran to its end: the recorded bind offsets are good
+    lf_cu_release(c, -1);  // the final post is the kernel's last action
     tmp[0] = out[0]; tmp[1] = out[1]; tmp[2] = out[2]; tmp[3] = out[3]; tmp[4] = out[6]; tmp[5] = out[7];
-  } else if (small) {  // last binds + read-out of W[0][0], W[1][0], HQUAD scalar in one step
+  } else if (pending) {  // last binds + read-out of W[0][0], W[1][0], HQUAD scalar in one step
     u64 out[8];
     LF_TRY(small_step(0, 0, out));
     tmp[0] = out[0]; tmp[1] = out[1]; tmp[2] = out[2]; tmp[3] = out[3]; tmp[4] = out[6]; tmp[5] = out[7];

@@ -10,6 +10,7 @@
 // elements through a pinned mailbox and receives one challenge.
 #include "ctx.h"
 #include "runfold.h"
+#include <atomic>
 #include <chrono>
 #include <utility>
 #include <vector>
@@ -617,6 +618,8 @@ struct ScGrid {
   u32 wave_tail;    // 1: once everything fits 64 entries, ONE wave finishes the layer (no workgroup barriers)
   u32* off_cache;   // ScGridOffCache::d
   u32 off_mode;     // 0 no cache, 1 record, 2 replay
+  u64 place_ticks;  // how long the FIRST barrier waits: it is the check that all workgroups were placed together
+  u32 test_drop;    // test only: the last workgroup leaves at once, as if it had never been placed
 };
 #define SC_WAVE_TAIL 64u
 #define SC_TAIL 1024u
@@ -637,13 +640,14 @@ __device__ __forceinline__ bool sc_arrive(u32* lvl1, u32* lvl2, u32 G, u32 g, bo
   return true;
 }
 
-// barrier among the first `G` workgroups; false = aborted (every caller then returns)
-__device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen, u64 timeout_ticks, bool two_level = true) {
+// barrier among the first `G` workgroups, waiting at most `limit_ticks`; 0 = passed, 1 = aborted by another workgroup,
+// 2 = THIS workgroup's wait ran out and it raised the abort flag first (every caller returns on non-zero)
+__device__ __forceinline__ int sc_grid_barrier_ex(ScGridSync* gs, u32 G, u32& gen, u64 limit_ticks, bool two_level = true) {
   __shared__ u32 s_abort;
   if (G == 1) {
     __threadfence_block();
     __syncthreads();
-    return true;
+    return 0;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -652,16 +656,17 @@ __device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen,
     u32 ab = 0;
     const u64 t0 = wall_clock64();
     if (sc_arrive(gs->l1_bar, &gs->count, G, blockIdx.x, two_level)) {
-      __hip_atomic_fetch_add(&gs->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      // a workgroup that was placed only after the others gave up arrives last: it must not open the barrier for itself
+      if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ab = 1;
+      else __hip_atomic_fetch_add(&gs->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       while (__hip_atomic_load(&gs->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
         if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           ab = 1;
           break;
         }
-        if (wall_clock64() - t0 > 2 * timeout_ticks) {  // never reached in a healthy run: no wait is unbounded
-          __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-          ab = 1;
+        if (wall_clock64() - t0 > limit_ticks) {  // never reached in a healthy run: no wait is unbounded
+          ab = __hip_atomic_exchange(&gs->abort, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0 ? 2u : 1u;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -672,7 +677,10 @@ __device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen,
   }
   ++gen;
   __syncthreads();
-  return s_abort == 0;
+  return (int)s_abort;
+}
+__device__ __forceinline__ bool sc_grid_barrier(ScGridSync* gs, u32 G, u32& gen, u64 timeout_ticks, bool two_level = true) {
+  return sc_grid_barrier_ex(gs, G, gen, 2 * timeout_ticks, two_level) == 0;
 }
 
 template <int F>
@@ -736,7 +744,21 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
     for (u32 i = gtid; i < qwords * nW[h0]; i += GT) QW[i] = 0;
     for (u32 i = gtid; i < qwords * nW[1 - h0]; i += GT) QWn[i] = 0;
   }
-  if (!sc_grid_barrier(gs, G, gen, a.timeout_ticks, a.two_level != 0)) return;
+  // Placement check.  Nothing but scratch (QW) has been written yet: when not every workgroup shows up within place_ticks --
+  // the CU budget (lf_cu_acquire) rules that out inside one process, another process holding CUs does not -- the workgroup whose wait
+  // runs out first reports status 2 and all leave; the host then drives this round-hand with per-launch kernels on the untouched state.
+  if (a.test_drop && G > 1 && g == G - 1) return;
+  {
+    const int br = sc_grid_barrier_ex(gs, G, gen, a.place_ticks, a.two_level != 0);
+    if (br) {
+      if (br == 2 && tid == 0) {
+        a.post[8] = 2;
+        __threadfence_system();
+        __hip_atomic_store((u64*)&a.post[5], a.seq0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+  }
   {  // first evaluation of the hand-off: QW[h[hand]] += v * Wother[h[1-hand]] over the whole HQUAD
     const int hand = (int)(a.rh0 & 1);
     const u32 GT = G * SM_THREADS;
@@ -860,7 +882,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         __hip_atomic_store(&po[3], a2.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&po[4], (u64)nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&po[8], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lf_wait_stores_before_publish();  // payload acknowledged before the sequence word leaves
         __hip_atomic_store(&po[5], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       // layout of HQuad::bind_h (no challenge needed): lane i looks at entry i
@@ -1047,7 +1069,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
       }
       if (poster) {
         // the post words live in uncached pinned host memory: write them with system-scope stores, wait until they
-        // have left (workgroup-scope release = s_waitcnt, no L2 write-back), then publish the sequence number
+        // have been acknowledged (s_waitcnt vmcnt(0): no L2 write-back), then publish the sequence number
         u64* po = (u64*)a.post;
         __hip_atomic_store(&po[0], a0.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&po[1], a0.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1055,7 +1077,7 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
         __hip_atomic_store(&po[3], a2.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&po[4], (u64)nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&po[8], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lf_wait_stores_before_publish();  // payload acknowledged before the sequence word leaves
         __hip_atomic_store(&po[5], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
@@ -1305,6 +1327,7 @@ static int sc_wait_post(lfgpu_ctx* c, u64 seq) {
       if (q != hipErrorNotReady) return lf_fail(c, LFGPU_ERR_HIP, "sumcheck step: %s", hipGetErrorString(q));
     }
   }
+  if (c->poll_h[8] == 2) return lf_fail(c, LFGPU_ERR_BUSY, "sumcheck grid kernel: its workgroups were not placed together (another tenant holds CUs)");
   if (c->poll_h[8] != 0) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck layer kernel: challenge wait timed out");
   return LFGPU_OK;
 }
@@ -1402,7 +1425,7 @@ int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_
 // d_state: LF_SC_GRID_STATE_BYTES of device scratch (ScGridSync + the per-workgroup counts)
 int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, const u32* d_nh, void* W0, size_t nW0,
                      void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
-                     size_t logw, void* d_state, ScGridOffCache* oc) {
+                     size_t logw, void* d_state, ScGridOffCache* oc, u32* G_out, u32* per_wg_out) {
   const size_t big = std::max(nh, std::max(nW0, nW1));
   if (rh0 >= 2 * logw || big > LF_SC_GRID_MAX) return lf_fail(c, LFGPU_ERR_ARG, "sc_grid_begin: bad operands");
   static_assert(sizeof(ScGridSync) + 4 * LF_SC_GRID_WGS + 36 * LF_SC_GRID_MAX <= LF_SC_GRID_STATE_BYTES, "grid state size");
@@ -1416,6 +1439,26 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   static const u32 wgs_cap = getenv("LFGPU_SC_WGS") ? (u32)std::min(LF_SC_GRID_WGS, std::max(1, atoi(getenv("LFGPU_SC_WGS")))) : 64u;
   if (G > wgs_cap) G = wgs_cap;
   if ((int)G > c->num_cu) G = (u32)c->num_cu;
+  int& tail_ok = c->sc_tail_ok;  // dynamic LDS for the tail (112 KiB) needs the attribute once per kernel and context
+  if (tail_ok < 0) {
+    const bool off = getenv("LFGPU_SC_TAIL") && atoi(getenv("LFGPU_SC_TAIL")) == 0;
+    tail_ok = !off && hipFuncSetAttribute((const void*)sc_grid_layer_kernel<FIELD_GF2_128>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_TAIL_LDS_BYTES) == hipSuccess &&
+                      hipFuncSetAttribute((const void*)sc_grid_layer_kernel<FIELD_FP128>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_TAIL_LDS_BYTES) == hipSuccess
+                  ? 1 : 0;
+    (void)hipGetLastError();
+  }
+  {  // all G workgroups must be resident together (they synchronise through device memory): one fits a CU ...
+    const void* fn0 = field == LFGPU_FIELD_GF2_128 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
+    int pc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn0, SM_THREADS, tail_ok ? SC_TAIL_LDS_BYTES : 0) != hipSuccess) pc = 0;
+    if (pc < 1) return LFGPU_ERR_BUSY;  // the caller takes another driver
+  }
+  // ... and the device's budget has G CUs left for them (ctx.h: the sum over every live grid of the process stays within the
+  // CU count, so each gets placed).  Short of that the caller runs this round-hand with per-launch kernels and asks again at
+  // the next one, when the arrays -- and the grid -- are half the size.
+  if (!lf_cu_acquire(c, (int)G)) return LFGPU_ERR_BUSY;
+  if (G_out) *G_out = G;
+  if (per_wg_out) *per_wg_out = per_wg;
   ScGrid a{};
   a.field = field;
   a.hcA = (uint2*)hc_cur; a.vcA = (elt_t*)vc_cur; a.hcB = (uint2*)hc_oth; a.vcB = (elt_t*)vc_oth;
@@ -1431,6 +1474,12 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   c->poll_seq += (2 * logw - rh0) + 1;
   c->poll_next = a.seq0;
   a.timeout_ticks = 5000ull * c->wall_khz;
+  static const u64 place_ms = getenv("LFGPU_SC_PLACE_MS") ? (u64)std::max(1, atoi(getenv("LFGPU_SC_PLACE_MS"))) : 250ull;
+  a.place_ticks = place_ms * c->wall_khz;
+  {  // test hook: the first LFGPU_SC_TEST_DROP grid launches of the process lose their last workgroup (a grid that is not placed whole)
+    static std::atomic<int> drops{getenv("LFGPU_SC_TEST_DROP") ? atoi(getenv("LFGPU_SC_TEST_DROP")) : 0};
+    if (G > 1 && drops.load() > 0 && drops.fetch_sub(1) > 0) a.test_drop = 1;
+  }
   a.post = c->poll_h;
   a.cmd = c->poll_h + 64;
   a.gs = (ScGridSync*)d_state;
@@ -1440,14 +1489,6 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   LF_HIP(c, hipMemsetAsync(d_state, 0, 64 + 1024, c->stream));  // counters (both levels), abort flag, challenge slot
   void* args[] = {&a};
   const void* fn = field == LFGPU_FIELD_GF2_128 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
-  int& tail_ok = c->sc_tail_ok;  // dynamic LDS for the tail (112 KiB) needs the attribute once per kernel and context
-  if (tail_ok < 0) {
-    const bool off = getenv("LFGPU_SC_TAIL") && atoi(getenv("LFGPU_SC_TAIL")) == 0;
-    tail_ok = !off && hipFuncSetAttribute((const void*)sc_grid_layer_kernel<FIELD_GF2_128>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_TAIL_LDS_BYTES) == hipSuccess &&
-                      hipFuncSetAttribute((const void*)sc_grid_layer_kernel<FIELD_FP128>, hipFuncAttributeMaxDynamicSharedMemorySize, SC_TAIL_LDS_BYTES) == hipSuccess
-                  ? 1 : 0;
-    (void)hipGetLastError();
-  }
   a.tail_lds = (u32)tail_ok;
   a.per_wg = per_wg;
   static const int all_poll_env = getenv("LFGPU_SC_ALLPOLL") ? atoi(getenv("LFGPU_SC_ALLPOLL")) : 0;
@@ -1460,29 +1501,28 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   a.wave_tail = (u32)wave_tail_env;
   static const bool off_cache_env = !(getenv("LFGPU_SC_OFFCACHE") && atoi(getenv("LFGPU_SC_OFFCACHE")) == 0);
   if (oc && off_cache_env && !d_nh && 2 * logw <= 64) {
-    const u32 key[4] = {(u32)rh0, G, (u32)nh, per_wg};
+    // the offsets of every later round-hand follow from how the grid shrinks, i.e. from all three array sizes
+    const u32 key[7] = {(u32)rh0, G, (u32)nh, per_wg, (u32)nW0, (u32)nW1, (u32)logw};
     if (!oc->d && hipMalloc((void**)&oc->d, 64 * (LF_SC_GRID_WGS + 1) * sizeof(u32)) != hipSuccess) {
       oc->d = nullptr;
       (void)hipGetLastError();
     }
     if (oc->d) {
-      const bool same = oc->key[0] == key[0] && oc->key[1] == key[1] && oc->key[2] == key[2] && oc->key[3] == key[3];
+      const bool same = memcmp(oc->key, key, sizeof(key)) == 0;
       if (oc->state == 2 && same) {
         a.off_mode = 2;
       } else {  // first proof through this layer (or other knobs): record
-        for (int k = 0; k < 4; ++k) oc->key[k] = key[k];
+        memcpy(oc->key, key, sizeof(key));
         oc->state = 1;
         a.off_mode = 1;
       }
       a.off_cache = oc->d;
     }
   }
-  {  // all G workgroups must be resident together (they synchronise through device memory)
-    int pc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, SM_THREADS, tail_ok ? SC_TAIL_LDS_BYTES : 0) != hipSuccess) pc = 0;
-    if (pc < 1 || (long)G > (long)pc * c->num_cu) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "sc_grid_begin: %u workgroups cannot be co-resident", G);
+  if (hipLaunchKernel(fn, dim3(G), dim3(SM_THREADS), args, tail_ok ? SC_TAIL_LDS_BYTES : 0, c->stream) != hipSuccess) {
+    lf_cu_release(c, (int)G);
+    return lf_fail(c, LFGPU_ERR_HIP, "sc_grid_begin: launch failed: %s", hipGetErrorString(hipGetLastError()));
   }
-  LF_HIP(c, hipLaunchKernel(fn, dim3(G), dim3(SM_THREADS), args, tail_ok ? SC_TAIL_LDS_BYTES : 0, c->stream));
   return LFGPU_OK;
 }
 

@@ -295,9 +295,28 @@ extern "C" int lfgpu_circuit_from_lfc1(lfgpu_ctx* c, const uint8_t* b, size_t le
   lfgpu_circuit_info& I = C->info;
   I.field = field;
   I.nv = nv; I.nc = nc; I.npub_in = npub; I.subfield_boundary = sfb; I.ninputs = nin; I.nl = nl; I.nterms = nterms;
-  C->zeros.assign(nterms, 0);
+  C->zeros = std::make_shared<const std::vector<uint8_t>>(nterms, (uint8_t)0);
   I.logv = lf_log2(nv);
   memcpy(I.id, b + pos, 32);
+  *out = C.release();
+  return LFGPU_OK;
+}
+// A second handle on an uploaded circuit for another context of the same device: the device arrays of every layer and the
+// preamble's zero run are shared (reference-counted; either handle may be freed first), the per-proof caches are the handle's own.
+extern "C" int lfgpu_circuit_share(lfgpu_ctx* c, const lfgpu_circuit* src, lfgpu_circuit** out) {
+  if (!c || !src || !out) return LFGPU_ERR_ARG;
+  if (c->device != src->c->device) return lf_fail(c, LFGPU_ERR_ARG, "circuit_share: the contexts are on different devices");
+  LF_HIP(c, hipSetDevice(c->device));
+  LF_HIP(c, hipStreamSynchronize(src->c->stream));  // the upload is complete (lfgpu_circuit_from_lfc1 synchronises; cheap)
+  std::unique_ptr<lfgpu_circuit> C(new lfgpu_circuit());
+  C->c = c;
+  C->info = src->info;
+  C->zeros = src->zeros;
+  for (const auto& l : src->layers) {
+    lfgpu_circuit::Layer L{l.logw, l.nw, l.nterms, nullptr};
+    LF_TRY(lf_quad_share(c, l.q, &L.q));
+    C->layers.push_back(L);
+  }
   *out = C.release();
   return LFGPU_OK;
 }
@@ -734,7 +753,7 @@ extern "C" int lfgpu_zk_prove(lfgpu_zk_prover* zk, const void* h_W, const lfgpu_
   ts.write_bytes(I.id, 32);
   for (size_t i = 0; i < zk->npub; ++i) ts.write_elt(W[i]);
   ts.write_elt(elt_t{0, 0});
-  ts.write_bytes(C->zeros.data(), I.nterms);
+  ts.write_bytes(C->zeros->data(), I.nterms);
   void* cl = tso->clone(tso->user);
   if (!cl) {
     hipStreamSynchronize(c->stream);
@@ -1161,7 +1180,7 @@ static int zk_verify_impl(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, 
   ts.write_bytes(I.id, 32);
   for (size_t i = 0; i < npub; ++i) ts.write_elt(pub[i]);
   ts.write_elt(elt_t{0, 0});
-  ts.write_bytes(C->zeros.data(), I.nterms);
+  ts.write_bytes(C->zeros->data(), I.nterms);
 
   // verifier_constraints with aux == nullptr: the bound quad of every layer comes from bind_gh_all
   ConstraintSet cs;

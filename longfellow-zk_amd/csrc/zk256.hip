@@ -15,6 +15,7 @@
 // Row extension and column hashing are csrc/p256.hip.  The verifier (ZkVerifier::verify, lib/zk/zk_verifier.h:68-94) is at
 // the end of the file.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -359,6 +360,8 @@ struct Grid256 {
   u32* src;     // one word per HQUAD entry: where each bound entry comes from (+ its merge kind in the top bits)
   u32 per_wg;
   u32 wave_tail;  // 1: once everything fits 64 entries, ONE wave finishes the layer
+  u32 test_drop;  // test only: the last workgroup leaves at once, as if it had never been placed
+  u64 place_ticks;  // how long the FIRST barrier waits: the check that all workgroups were placed together
   E rsq;
 };
 // two-level arrival ticket (see sc_arrive in sumcheck.hip): true for the one workgroup that arrives last
@@ -371,29 +374,31 @@ __device__ __forceinline__ bool g256_arrive(u32* lvl1, u32* lvl2, u32 G, u32 g) 
   __hip_atomic_store(lvl2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return true;
 }
-// barrier among the first G workgroups; false = aborted (every caller then returns)
-__device__ __forceinline__ bool g256_barrier(Grid256Sync* gs, u32 G, u32& gen, u64 timeout_ticks) {
+// barrier among the first G workgroups, waiting at most limit_ticks; 0 = passed, 1 = aborted by another workgroup, 2 = this
+// workgroup's wait ran out and it raised the abort flag first (every caller returns on non-zero)
+__device__ __forceinline__ int g256_barrier_ex(Grid256Sync* gs, u32 G, u32& gen, u64 limit_ticks) {
   __shared__ u32 s_abort;
   if (G == 1) {
     __threadfence_block();
     __syncthreads();
-    return true;
+    return 0;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     u32 ab = 0;
     const u64 t0 = wall_clock64();
     if (g256_arrive(gs->l1_bar, &gs->count, G, blockIdx.x)) {
-      __hip_atomic_fetch_add(&gs->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      // a workgroup that was placed only after the others gave up arrives last: it must not open the barrier for itself
+      if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ab = 1;
+      else __hip_atomic_fetch_add(&gs->gen, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       while (__hip_atomic_load(&gs->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
         if (__hip_atomic_load(&gs->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
           ab = 1;
           break;
         }
-        if (wall_clock64() - t0 > 2 * timeout_ticks) {  // never reached in a healthy run: no wait is unbounded
-          __hip_atomic_store(&gs->abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-          ab = 1;
+        if (wall_clock64() - t0 > limit_ticks) {  // never reached in a healthy run: no wait is unbounded
+          ab = __hip_atomic_exchange(&gs->abort, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0 ? 2u : 1u;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -404,7 +409,10 @@ __device__ __forceinline__ bool g256_barrier(Grid256Sync* gs, u32 G, u32& gen, u
   }
   ++gen;
   __syncthreads();
-  return s_abort == 0;
+  return (int)s_abort;
+}
+__device__ __forceinline__ bool g256_barrier(Grid256Sync* gs, u32 G, u32& gen, u64 timeout_ticks) {
+  return g256_barrier_ex(gs, G, gen, 2 * timeout_ticks) == 0;
 }
 
 __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) {
@@ -443,7 +451,20 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
     for (u32 i = gtid; i < 8 * nW[h0]; i += GT) QW[i] = 0;
     for (u32 i = gtid; i < 8 * nW[1 - h0]; i += GT) QWn[i] = 0;
   }
-  if (!g256_barrier(gs, G, gen, a.timeout_ticks)) return;
+  // placement check (see sc_grid_layer_kernel, sumcheck.hip): only scratch has been written so far; when not every workgroup
+  // shows up, the one whose wait runs out first reports status 2 and the host continues with per-launch kernels
+  if (a.test_drop && G > 1 && g == G - 1) return;
+  {
+    const int br = g256_barrier_ex(gs, G, gen, a.place_ticks);
+    if (br) {
+      if (br == 2 && tid == 0) {
+        a.post[9] = 2;
+        __threadfence_system();
+        __hip_atomic_store((u64*)&a.post[16], a.seq0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+  }
   {  // first evaluation of the hand-off: QW[h[hand]] += v * Wother[h[1-hand]] over the whole HQUAD
     const int hand = (int)(a.rh0 & 1);
     const u32 GT = G * G256_THREADS;
@@ -548,7 +569,7 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
         }
         __hip_atomic_store(&po[8], (u64)nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&po[9], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lf_wait_stores_before_publish();  // payload acknowledged before the sequence word leaves
         __hip_atomic_store(&po[16], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       // layout of HQuad::bind_h (no challenge needed): lane i looks at entry i
@@ -781,7 +802,7 @@ __global__ __launch_bounds__(G256_THREADS) void grid256_layer_kernel(Grid256 a) 
         }
         __hip_atomic_store(&po[8], (u64)nh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&po[9], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lf_wait_stores_before_publish();  // payload acknowledged before the sequence word leaves
         __hip_atomic_store(&po[16], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
@@ -1216,7 +1237,16 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   // co-resident workgroups that take every challenge through pinned memory (grid256_layer_kernel); 0 = three launches per
   // round-hand throughout (A/B, and the fallback where a running kernel cannot see host writes)
   static const int grid_env = getenv("LFGPU_P256_GRID") ? atoi(getenv("LFGPU_P256_GRID")) : 1;
-  const bool grid_ok = grid_env && lf_sc_resident_ok(c);
+  bool grid_ok = grid_env && lf_sc_resident_ok(c) && c->grid_strikes < 2;
+  struct CuGuard {  // the grid's CUs go back to the device's budget (ctx.h) however this function is left, after the kernel has ended
+    lfgpu_ctx* c;
+    ~CuGuard() {
+      if (c->cu_held) {
+        (void)hipStreamSynchronize(c->stream);
+        lf_cu_release(c, -1);
+      }
+    }
+  } cu_guard{c};
   for (size_t rnd = 0; rnd < logw; ++rnd)
     for (int hand = 0; hand < 2; ++hand) {
       // hand-off point: above it a round-hand is three launches spread over the whole chip.  Measured on the mdoc signature
@@ -1230,15 +1260,20 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
         const char* e = getenv("LFGPU_P256_GRID_MAX");
         return std::min<size_t>(e ? (size_t)atol(e) : (size_t)2048, G256_MAX);
       }();
+      static const u32 grid_per_wg = getenv("LFGPU_P256_PER_WG") ? (u32)std::max(64, atoi(getenv("LFGPU_P256_PER_WG"))) : 512u;
+      u32 want_G = 0;  // workgroups of the grid this round-hand could hand the layer to (0: not now)
       if (grid_ok && nh <= grid_max && nW[0] <= grid_max && nW[1] <= grid_max) {
-        static const u32 per_wg = getenv("LFGPU_P256_PER_WG") ? (u32)std::max(64, atoi(getenv("LFGPU_P256_PER_WG"))) : 512u;
-        const size_t big = std::max(nh, std::max(nW[0], nW[1]));
-        u32 G = (u32)((big + per_wg - 1) / per_wg);
-        G = std::min<u32>(std::max<u32>(G, 1), G256_WGS);
-        if ((int)G > c->num_cu) G = (u32)c->num_cu;
-        int pc = 0;  // all G workgroups must be resident together (they synchronise through device memory)
+        int pc = 0;  // all of them must be resident together (they synchronise through device memory): one fits a CU ...
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, (const void*)grid256_layer_kernel, G256_THREADS, 0) != hipSuccess) pc = 0;
         if (pc < 1) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "sumcheck_layer256: the grid kernel does not fit a CU");
+        const size_t big = std::max(nh, std::max(nW[0], nW[1]));
+        want_G = std::min<u32>(std::max<u32>((u32)((big + grid_per_wg - 1) / grid_per_wg), 1), std::min<u32>(G256_WGS, (u32)c->num_cu));
+      }
+      // ... and the device's CU budget must have room for them (ctx.h); without it this round-hand takes the three launches
+      // below and the next one asks again
+      if (want_G && lf_cu_acquire(c, (int)want_G)) {
+        const u32 per_wg = grid_per_wg, G = want_G;
+        const size_t big = std::max(nh, std::max(nW[0], nW[1]));
         Grid256 a{};
         a.hcA = hc[cur];
         a.vcA = vc[cur];
@@ -1267,11 +1302,18 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
         static const int wave_tail_env = getenv("LFGPU_P256_WAVE_TAIL") ? atoi(getenv("LFGPU_P256_WAVE_TAIL")) : 1;
         a.wave_tail = (u32)wave_tail_env;
         a.rsq = F.rsq;
+        static const u64 place_ms = getenv("LFGPU_SC_PLACE_MS") ? (u64)std::max(1, atoi(getenv("LFGPU_SC_PLACE_MS"))) : 250ull;
+        a.place_ticks = place_ms * c->wall_khz;
+        {  // test hook: the first LFGPU_P256_TEST_DROP grid launches of the process lose their last workgroup
+          static std::atomic<int> drops{getenv("LFGPU_P256_TEST_DROP") ? atoi(getenv("LFGPU_P256_TEST_DROP")) : 0};
+          if (G > 1 && drops.load() > 0 && drops.fetch_sub(1) > 0) a.test_drop = 1;
+        }
         LF_HIP(c, hipMemsetAsync(gsync, 0, sizeof(Grid256Sync), c->stream));
         hipLaunchKernelGGL(grid256_layer_kernel, dim3(G), dim3(G256_THREADS), 0, c->stream, a);
         LF_HIP(c, hipGetLastError());
         u64 seq = a.seq0;
         size_t r2 = rnd;
+        bool not_placed = false;
         static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
         double t_wait = 0, t_host = 0, tp0 = verbose ? now_ms() : 0;
         for (u32 rh = a.rh0; rh < a.rh1; ++rh, ++seq) {
@@ -1282,6 +1324,10 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
             const double t = now_ms();
             t_wait += t - tp0;
             tp0 = t;
+          }
+          if (post[9] == 2 && rh == a.rh0) {  // the grid was not placed whole: nothing but scratch was written
+            not_placed = true;
+            break;
           }
           if (post[9] != 0) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: the grid kernel timed out waiting for a challenge");
           E coef[3], ev[3], r;
@@ -1306,7 +1352,16 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
         if (verbose)
           fprintf(stderr, "lfgpu sumcheck_layer256 grid: %u round-hands from %zu entries: waiting for the device %.1f us, host's turn %.1f us per round-hand\n",
                   a.rh1 - a.rh0, big, 1e3 * t_wait / (a.rh1 - a.rh0), 1e3 * t_host / (a.rh1 - a.rh0));
+        if (not_placed) {  // another process holds CUs (the budget rules it out within this one): per-launch kernels from here on
+          LF_HIP(c, hipStreamSynchronize(c->stream));
+          lf_cu_release(c, -1);
+          grid_ok = false;
+          ++c->grid_strikes;
+          LF_HIP(c, hipMemsetAsync(acc, 0, acc_n * 64, c->stream));  // the kernel's clears / first sums may have touched the accumulators
+          if (verbose) fprintf(stderr, "lfgpu sumcheck_layer256: resident grid not placed (strike %d): per-launch kernels for this layer\n", c->grid_strikes);
+        } else {
         LF_TRY(wait_post(seq));  // the layer's last post: W[0][0], W[1][0], the HQUAD scalar
+        lf_cu_release(c, -1);
         if (post[9] != 0 || post[8] != 1) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: HQUAD did not fold to one entry (%llu)", (unsigned long long)post[8]);
         for (int k = 0; k < 4; ++k) {
           wc_out[0].l[k] = post[k];
@@ -1314,6 +1369,7 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
           if (bound_quad) bound_quad->l[k] = post[12 + k];
         }
         return LFGPU_OK;
+        }
       }
       // QW scatter (prover_layers.h:239-243) + evaluations: two launches, one read-back
       if (nh) hipLaunchKernelGGL(qw_scatter256_kernel, dim3(nblk(nh)), dim3(Z_THREADS), 0, c->stream, nh, (const uint2*)hc[cur], (const E*)vc[cur], hand,
@@ -1942,7 +1998,7 @@ int zk256_prove(Zk256* z, const void* h_W, const lfgpu_transcript_ops* tso, int*
   ts.write_bytes(I.id, 32);
   for (size_t i = 0; i < z->npub; ++i) ts.write_elt(W[i]);
   ts.write_elt(F.zero);
-  ts.write_bytes(C->zeros.data(), I.nterms);
+  ts.write_bytes(C->zeros->data(), I.nterms);
   void* cl = tso->clone(tso->user);
   if (!cl) {
     (void)hipStreamSynchronize(c->stream);
@@ -2212,7 +2268,7 @@ int zk256_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nr
   ts.write_bytes(I.id, 32);
   for (size_t i = 0; i < npub; ++i) ts.write_elt(pub[i]);
   ts.write_elt(F.zero);
-  ts.write_bytes(C->zeros.data(), I.nterms);
+  ts.write_bytes(C->zeros->data(), I.nterms);
   // device buffers: EQ table of the input constraint | rows [0, nwqrow) = [0^r | A_i], then y_ldt, y_dot, y_quad | gathered columns
   const size_t nrows_dev = p.nwqrow + 3, ld = p.block_enc;
   void* dv = nullptr;

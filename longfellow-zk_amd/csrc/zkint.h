@@ -1,5 +1,6 @@
 // zkint.h -- what zk.hip (the 16-byte fields) and zk256.hip (Fp256Base, 32-byte elements) share below the C ABI.
 #pragma once
+#include <memory>
 #include <vector>
 
 #include "../../include/lfgpu_zk.h"
@@ -14,7 +15,8 @@ struct lfgpu_circuit {
     lfgpu_quad* q;
   };
   std::vector<Layer> layers;
-  std::vector<uint8_t> zeros;  // nterms zero bytes: what initialize_sumcheck_fiat_shamir hashes per proof (zk_common.h:177-179)
+  // nterms zero bytes: what initialize_sumcheck_fiat_shamir hashes per proof (zk_common.h:177-179); shared by the handles of lfgpu_circuit_share
+  std::shared_ptr<const std::vector<uint8_t>> zeros;
   ~lfgpu_circuit() {
     for (auto& l : layers)
       if (l.q) lfgpu_quad_free(l.q);

@@ -15,11 +15,23 @@ class LcgRng:
     def __init__(self, seed):
         self.state = seed
 
+    A, Cc = 6364136223846793005, 1442695040888963407
+
     def bytes(self, n):
+        if n > 32:  # vectorised: s_i = A^i s_0 + C (1 + A + ... + A^(i-1)) in wrapping 64-bit arithmetic
+            with np.errstate(over="ignore"):
+                ap = np.cumprod(np.full(n, self.A, dtype=np.uint64))
+                g = np.empty(n, dtype=np.uint64)
+                g[0] = 1
+                if n > 1:
+                    g[1:] = np.cumsum(ap[:-1], dtype=np.uint64) + np.uint64(1)
+                st = ap * np.uint64(self.state) + g * np.uint64(self.Cc)
+            self.state = int(st[-1])
+            return ((st >> np.uint64(32)) & np.uint64(0xFF)).astype(np.uint8).tobytes()
         out = bytearray(n)
         s = self.state
         for i in range(n):
-            s = (s * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+            s = (s * self.A + self.Cc) & 0xFFFFFFFFFFFFFFFF
             out[i] = (s >> 32) & 0xFF
         self.state = s
         return bytes(out)

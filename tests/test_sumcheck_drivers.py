@@ -34,6 +34,20 @@ CASES = [
     ("sig", {"LFGPU_P256_GRID": "0"}),
     ("sig", {"LFGPU_P256_GRID_MAX": "65536", "LFGPU_P256_PER_WG": "128"}),
     ("sig", {"LFGPU_P256_GRID_MAX": "300", "LFGPU_P256_PER_WG": "2048"}),
+    # the per-device CU budget of the resident kernels (csrc/ctx.h): none at all (every round-hand on per-launch kernels), and
+    # far less than the grid asks for at its hand-off point (it starts some round-hands later, when it fits)
+    ("32", {"LFGPU_CU_BUDGET": "0"}),
+    ("32", {"LFGPU_CU_BUDGET": "5"}),
+    ("1 fp128", {"LFGPU_CU_BUDGET": "1"}),
+    ("sig", {"LFGPU_CU_BUDGET": "0"}),
+    ("sig", {"LFGPU_CU_BUDGET": "2", "LFGPU_P256_GRID_MAX": "65536", "LFGPU_P256_PER_WG": "128"}),
+    # a grid that is not placed whole (test hook: its last workgroup never shows up): the first barrier times out, the kernel
+    # reports it, and the layer continues on per-launch kernels with identical bytes; after two strikes the context stops
+    # launching grids
+    ("1", {"LFGPU_SC_TEST_DROP": "1", "LFGPU_SC_PLACE_MS": "20"}),
+    ("32", {"LFGPU_SC_TEST_DROP": "5", "LFGPU_SC_PLACE_MS": "20"}),
+    ("1 fp128", {"LFGPU_SC_TEST_DROP": "1", "LFGPU_SC_PLACE_MS": "20"}),
+    ("sig", {"LFGPU_P256_TEST_DROP": "1", "LFGPU_SC_PLACE_MS": "20", "LFGPU_P256_GRID_MAX": "65536", "LFGPU_P256_PER_WG": "128"}),
 ]
 
 
@@ -42,7 +56,7 @@ CASES = [
 def test_proof_bytes_under_every_driver(args, env):
     e = dict(os.environ)
     for k in list(e):
-        if k.startswith("LFGPU_SC_") or k.startswith("LFGPU_P256_"):
+        if k.startswith("LFGPU_SC_") or k.startswith("LFGPU_P256_") or k.startswith("LFGPU_CU_"):
             del e[k]
     e.update(env)
     r = subprocess.run([sys.executable, CHILD] + args.split(), env=e, capture_output=True, text=True, timeout=300)
