@@ -31,6 +31,28 @@ int lf_scratch2(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scr
 int lf_scratch3(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch3, &c->scratch3_bytes, bytes, out); }
 int lf_scratch4(lfgpu_ctx* c, size_t bytes, void** out) { return grow(c, &c->scratch4, &c->scratch4_bytes, bytes, out); }
 
+int lf_pool_get(lfgpu_ctx* c, size_t bytes, void** out) {
+  for (size_t i = 0; i < c->pool.size(); ++i)
+    if (c->pool[i].bytes == bytes) {
+      *out = c->pool[i].p;
+      c->pool.erase(c->pool.begin() + i);
+      return LFGPU_OK;
+    }
+  if (hipMalloc(out, bytes ? bytes : 16) != hipSuccess) {
+    (void)hipGetLastError();
+    return lf_fail(c, LFGPU_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+  }
+  return LFGPU_OK;
+}
+void lf_pool_put(lfgpu_ctx* c, void* p, size_t bytes) {
+  if (!p) return;
+  if (c->pool.size() >= LF_POOL_MAX) {
+    (void)hipFree(c->pool.front().p);
+    c->pool.erase(c->pool.begin());
+  }
+  c->pool.push_back(lfgpu_ctx::PoolEntry{p, bytes});
+}
+
 int lf_stage_upload(lfgpu_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
   const unsigned slot = c->stage_next & 3;
   if (!c->stage_h || !c->stage_ev[slot] || bytes > LF_STAGE_SLOT) {  // no ring: plain copy, the source must outlive it
@@ -225,8 +247,7 @@ int lfgpu_shutdown(lfgpu_ctx* c) {
   if (c->scratch2) hipFree(c->scratch2);
   if (c->scratch3) hipFree(c->scratch3);
   if (c->scratch4) hipFree(c->scratch4);
-  if (c->lig_T) hipFree(c->lig_T);
-  if (c->lig_L) hipFree(c->lig_L);
+  for (auto& e : c->pool) hipFree(e.p);
   if (c->zk_eq) hipFree(c->zk_eq);
   if (c->mailbox_h) hipHostFree(c->mailbox_h);
   if (c->poll_h) hipHostFree((void*)c->poll_h);

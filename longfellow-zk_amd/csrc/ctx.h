@@ -44,10 +44,13 @@ struct lfgpu_ctx {
   void* mailbox_d = nullptr;
   // one-entry cache of the last freed Ligero tableau / Merkle buffers (a prover that commits repeatedly with the same
   // parameters does not pay hipMalloc + hipFree per proof)
-  void* lig_T = nullptr;
-  size_t lig_T_bytes = 0;
-  void* lig_L = nullptr;
-  size_t lig_L_bytes = 0;
+  // (a small pool keyed by size: hipFree waits for EVERY stream of the device, so in the steady state of a prover -- or of K
+  // provers sharing the device -- nothing may be freed per proof; lf_pool_get / lf_pool_put)
+  struct PoolEntry {
+    void* p;
+    size_t bytes;
+  };
+  std::vector<PoolEntry> pool;
   // EQ table over the circuit inputs of the last verifier_constraints run (the dense block of the Ligero inner-product
   // matrix is built from it on the device)
   void* zk_eq = nullptr;
@@ -100,6 +103,12 @@ int lf_fail(lfgpu_ctx* c, int code, const char* fmt, ...);
     if (rc_ != LFGPU_OK) return rc_; \
   } while (0)
 
+// device buffers that outlive one call but recur with the same size (Ligero tableaux, Merkle layers): taken from / returned
+// to the context's pool instead of hipMalloc / hipFree.  A returned buffer may still be in use by work queued on the
+// context's stream (in order: whatever a later user enqueues comes after it).  At most LF_POOL_MAX entries, oldest evicted.
+#define LF_POOL_MAX 8
+int lf_pool_get(lfgpu_ctx* c, size_t bytes, void** out);
+void lf_pool_put(lfgpu_ctx* c, void* p, size_t bytes);
 int lf_scratch(lfgpu_ctx* c, size_t bytes, void** out);
 int lf_scratch2(lfgpu_ctx* c, size_t bytes, void** out);
 int lf_scratch3(lfgpu_ctx* c, size_t bytes, void** out);

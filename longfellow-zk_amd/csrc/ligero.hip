@@ -347,18 +347,9 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
     if (rc) return fail(lf_fail(c, rc, "%s", err));
   }
   const size_t tb = p.nrow * ld * 16, lb = 2 * p.block_ext * 32;
-  if (c->lig_T && c->lig_T_bytes == tb) {  // buffers of the last freed prover with the same shape
-    pr->d_T = (elt_t*)c->lig_T;
-    c->lig_T = nullptr;
-  } else if (hipMalloc((void**)&pr->d_T, tb) != hipSuccess) {
-    return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit: tableau alloc"));
-  }
-  if (c->lig_L && c->lig_L_bytes == lb) {
-    pr->d_layers = (decltype(pr->d_layers))c->lig_L;
-    c->lig_L = nullptr;
-  } else if (hipMalloc((void**)&pr->d_layers, lb) != hipSuccess) {
-    return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit: layers alloc"));
-  }
+  // buffers of an earlier prover with the same shape where there is one (the context's pool)
+  if (lf_pool_get(c, tb, (void**)&pr->d_T) != LFGPU_OK) return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit: tableau alloc"));
+  if (lf_pool_get(c, lb, (void**)&pr->d_layers) != LFGPU_OK) return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit: layers alloc"));
   pr->T_bytes = tb;
   pr->L_bytes = lb;
   pr->row_lo = 0;
@@ -378,24 +369,19 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
 extern "C" int lfgpu_ligero_free(lfgpu_ligero_prover* pr) {
   if (!pr) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = pr->c;
-  // keep the buffers for the next commit of the same shape (one-entry cache per context); the stream is in order,
-  // so work still queued on them finishes before anything a later commit enqueues
-  auto stash = [&](void* p, size_t bytes, void** slot, size_t* slot_bytes) {
+  // keep the buffers for the next commit of the same shape (the context's pool); the stream is in order, so work still
+  // queued on them finishes before anything a later commit enqueues
+  auto stash = [&](void* p, size_t bytes) {
     if (!p) return;
     // the tableau holds the witness, the pads and the blinding rows: scrub it before it outlives its prover (enqueued on the
     // stream, in order behind the prover's last kernels)
     if (bytes) (void)hipMemsetAsync(p, 0, bytes, c ? c->stream : nullptr);
-    if (c && bytes) {
-      if (*slot) (void)hipFree(*slot);
-      *slot = p;
-      *slot_bytes = bytes;
-    } else {
-      (void)hipFree(p);
-    }
+    if (c && bytes) lf_pool_put(c, p, bytes);
+    else (void)hipFree(p);
   };
   if (pr->owns) {
-    stash(pr->d_T, pr->T_bytes, &c->lig_T, &c->lig_T_bytes);
-    stash(pr->d_layers, pr->L_bytes, &c->lig_L, &c->lig_L_bytes);
+    stash(pr->d_T, pr->T_bytes);
+    stash(pr->d_layers, pr->L_bytes);
   }
   delete pr;
   return LFGPU_OK;

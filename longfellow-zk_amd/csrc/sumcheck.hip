@@ -1316,9 +1316,17 @@ __global__ __launch_bounds__(SM_THREADS) void sc_grid_layer_kernel(ScGrid a) {
 
 // waits until the post carries `seq`; polls coherent memory and watches the stream so a dead kernel is noticed
 static int sc_wait_post(lfgpu_ctx* c, u64 seq) {
+  // The stream is only looked at after 50 ms without the post (a dead kernel must not hang the caller): in a healthy run no HIP
+  // call is made while a resident kernel waits for this thread.  It matters with several provers on one device -- another
+  // thread's hipFree / hipMalloc holds the runtime's lock while it waits for every stream of the device, hence for that kernel;
+  // a hipStreamQuery here would then wait for the lock and the kernel for its challenge, until its timeout.
   u64 spins = 0;
+  double t_first = 0;
   while (__atomic_load_n((const u64*)&c->poll_h[5], __ATOMIC_ACQUIRE) != seq) {
     if ((++spins & 0xfff) == 0) {
+      const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+      if (t_first == 0) t_first = t;
+      if (t - t_first < 50.0) continue;
       const hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) {  // the kernel is over: its post must be visible now
         if (__atomic_load_n((const u64*)&c->poll_h[5], __ATOMIC_ACQUIRE) == seq) break;
@@ -1370,8 +1378,9 @@ __global__ void sc_handshake_test_kernel(u64 seq, u64 timeout_ticks, volatile u6
   __hip_atomic_store((u64*)&post[5], seq + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 bool lf_sc_resident_ok(lfgpu_ctx* c) {
-  if (c->resident_state) return c->resident_state > 0;
-  c->resident_state = -1;
+  if (c->resident_state > 0) return true;
+  if (c->resident_state <= -3) return false;  // three failed attempts: this system does not show a running kernel's posts
+  --c->resident_state;  // (one failed attempt may be a launch held up by another thread's allocation)
   const u64 seq = c->poll_seq + 1;
   c->poll_seq += 2;
   volatile u64* cmd = c->poll_h + 64;
@@ -1381,12 +1390,15 @@ bool lf_sc_resident_ok(lfgpu_ctx* c) {
                      (const volatile u64*)cmd);
   if (hipGetLastError() != hipSuccess) return false;
   bool seen = false;  // the first post must arrive while the kernel is still waiting for us
-  for (u64 spins = 0; spins < (1ull << 34); ++spins) {
-    if (__atomic_load_n((const u64*)&c->poll_h[5], __ATOMIC_ACQUIRE) == seq) {
-      seen = true;
-      break;
+  {  // no HIP call while the kernel waits for this thread (see sc_wait_post): the clock bounds the wait (the kernel gives up after 0.2 s)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (u64 spins = 0;; ++spins) {
+      if (__atomic_load_n((const u64*)&c->poll_h[5], __ATOMIC_ACQUIRE) == seq) {
+        seen = true;
+        break;
+      }
+      if ((spins & 0xfff) == 0xfff && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 400.0) break;
     }
-    if ((spins & 0xfff) == 0xfff && hipStreamQuery(c->stream) != hipErrorNotReady) break;
   }
   if (seen) {
     cmd[0] = 0x5eed5eed5eedull;

@@ -1220,9 +1220,17 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
   u64 h_sums[16];
   E* h_out = (E*)c->mailbox_h;
   auto wait_post = [&](u64 seq) -> int {  // bounded: a kernel that is over without posting is an error
+    // The stream is only looked at after 50 ms without the post (a dead kernel must not hang the caller): in a healthy run no HIP
+    // call is made while a resident kernel waits for this thread.  It matters -- another thread's hipFree holds the runtime's
+    // lock while it waits for every stream of the device, hence for that kernel; a hipStreamQuery here would wait for the lock
+    // and the kernel for its challenge until its timeout.
     u64 spins = 0;
+    double t_first = 0;
     while (__atomic_load_n((const u64*)&post[16], __ATOMIC_ACQUIRE) != seq) {
       if ((++spins & 0xfff) == 0) {
+        const double t = now_ms();
+        if (t_first == 0) t_first = t;
+        if (t - t_first < 50.0) continue;
         const hipError_t qe = hipStreamQuery(c->stream);
         if (qe == hipSuccess) {
           if (__atomic_load_n((const u64*)&post[16], __ATOMIC_ACQUIRE) == seq) break;
@@ -1329,7 +1337,9 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
             not_placed = true;
             break;
           }
-          if (post[9] != 0) return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: the grid kernel timed out waiting for a challenge");
+          if (post[9] != 0)
+            return lf_fail(c, LFGPU_ERR_ASSERT, "sumcheck_layer256: the grid kernel timed out waiting for a challenge (status %llu at round-hand %u of [%u, %u), %u workgroups)",
+                           (unsigned long long)post[9], rh, a.rh0, a.rh1, G);
           E coef[3], ev[3], r;
           for (int k = 0; k < 4; ++k) {
             coef[0].l[k] = post[k];
@@ -1452,12 +1462,13 @@ struct Lig256 {
   std::vector<uint8_t> nonces;
   E* row(size_t i) const { return d_T + i * p.block_enc; }
   ~Lig256() {
-    if (d_T) {  // the tableau holds the witness, the pads and the blinding rows: scrub it
+    if (d_T) {  // the tableau holds the witness, the pads and the blinding rows: scrub it (enqueued in order behind the prover's
+                // last kernels), then keep the buffer for the next commit of this shape: a hipFree per proof would wait for every
+                // stream of the device (ctx.h, lf_pool_put)
       (void)hipMemsetAsync(d_T, 0, p.nrow * p.block_enc * 32, c->stream);
-      (void)hipStreamSynchronize(c->stream);
-      (void)hipFree(d_T);
+      lf_pool_put(c, d_T, p.nrow * p.block_enc * 32);
     }
-    if (d_layers) (void)hipFree(d_layers);
+    if (d_layers) lf_pool_put(c, d_layers, 2 * p.block_ext * 32);
   }
 };
 
@@ -1522,7 +1533,7 @@ int lig256_commit(lfgpu_ctx* c, const lfgpu_ligero_param& p, const E* W, const s
   const int rc = lig256_layout(p, W, lqc, rng, user, H.data(), L->nonces.data(), err);
   if (rc) return lf_fail(c, rc, "%s", err);
   const size_t ld = p.block_enc;
-  if (hipMalloc((void**)&L->d_T, p.nrow * ld * 32) != hipSuccess || hipMalloc((void**)&L->d_layers, 2 * p.block_ext * 32) != hipSuccess)
+  if (lf_pool_get(c, p.nrow * ld * 32, (void**)&L->d_T) != LFGPU_OK || lf_pool_get(c, 2 * p.block_ext * 32, (void**)&L->d_layers) != LFGPU_OK)
     return lf_fail(c, LFGPU_ERR_NOMEM, "ligero256: tableau alloc");
   LF_HIP(c, hipMemcpy2DAsync(L->d_T, ld * 32, H.data(), p.dblock * 32, p.dblock * 32, p.nrow, hipMemcpyHostToDevice, c->stream));
   // rows IDOT / IQUAD carry dblock values, every other row block (ligero_prover.h:175,184,203,210,237)

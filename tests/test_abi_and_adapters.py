@@ -63,3 +63,30 @@ def test_adapters_instantiate_reference_ligero_prover(tmp_path):
            "-Wno-ignored-attributes", "-I/root/reference/lib", "-I" + os.path.join(ROOT, "include"), "-c",
            os.path.join(ROOT, "tests", "adapters_compile_check.cc"), "-o", str(tmp_path / "acc.o")]
     subprocess.check_call(cmd)
+
+
+def test_post_publish_waits_for_payload(tmp_path):
+    """The resident kernels post {payload words ..., sequence word} to pinned host memory with relaxed system-scope stores; the
+    host acquires on the sequence word and then reads the payload, so the payload must have left the CU first.  Pins the ISA:
+    between the last payload store and the sequence store hipcc must emit `s_waitcnt vmcnt(0)` (csrc/fields.h,
+    lf_wait_stores_before_publish) -- a workgroup-scope release fence, which the code used before, emits none."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = tmp_path / "post.hip"
+    src.write_text('#include "%s"\n' % os.path.join(ROOT, "longfellow-zk_amd", "csrc", "fields.h") + r'''
+__global__ void post_kernel(u64* po, u64 a, u64 b, u64 seq) {
+  __hip_atomic_store(&po[0], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&po[9], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  lf_wait_stores_before_publish();
+  __hip_atomic_store(&po[16], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+''')
+    out = tmp_path / "post.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), str(src)])
+    body = out.read_text().split("post_kernel", 1)[1]
+    ins = [l.strip() for l in body.splitlines() if l.strip().startswith(("global_store", "flat_store", "s_waitcnt"))]
+    stores = [i for i, l in enumerate(ins) if "_store" in l]
+    assert len(stores) >= 3, ins
+    between = ins[stores[-2] + 1:stores[-1]]
+    assert any(l.startswith("s_waitcnt") and "vmcnt(0)" in l for l in between), ins
