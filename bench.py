@@ -45,14 +45,36 @@ def cpu_baseline(logn, budget_s=10.0):
         else:
             o.lfo_fp_fftb(ol.P(x), n, o.lfo_fp_omega32(), 1 << 32)
 
-    rows, t0 = 0, time.perf_counter()
-    while True:
-        one_row()
-        rows += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s * 0.5 or rows >= 64:
-            break
-    one = rows * n / dt
+    # one thread, pinned to one core of this job's share for the duration (round 2 saw this figure move 2.5x between runs with
+    # the thread free to migrate and the measurement at the end of the run, behind every GPU leg's spinning host threads): it
+    # now runs FIRST, pinned, and reports the best row next to the mean
+    aff = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    if aff:
+        os.sched_setaffinity(0, {aff[len(aff) // 2]})
+    rows, t0, best_row = 0, time.perf_counter(), None
+    try:
+        while True:
+            tr = time.perf_counter()
+            one_row()
+            tr = time.perf_counter() - tr
+            best_row = tr if best_row is None or tr < best_row else best_row
+            rows += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s * 0.5 or rows >= 64:
+                break
+    finally:
+        if aff:
+            os.sched_setaffinity(0, set(aff))
+    one = n / best_row
+    cpu_model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     # all cores: one thread per core of this job's CPU share (a 1-GPU box gives 16), every thread transforms rows until the
     # deadline -- bounded wall time whatever the core count
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -72,7 +94,8 @@ def cpu_baseline(logn, budget_s=10.0):
     nrows_all = sum(done)
     return {"value": one, "unit": "field-elems/s", "cores": 1,
             "kind": "reference" if r is not None else "port",
-            "sample": "%d rows of 2^%d Fp128 points through FFT<Fp128>::fftb, 1 thread, %.1f s" % (rows, logn, dt),
+            "sample": "%d rows of 2^%d Fp128 points through FFT<Fp128>::fftb, 1 pinned thread, %.1f s, best row (mean %.3g elem/s); host CPU: %s" % (rows, logn, dt, rows * n / dt, cpu_model),
+            "value_mean": rows * n / dt, "host_cpu": cpu_model,
             "value_all_cores": nrows_all * n / dt2, "cores_all": cores,
             "sample_all_cores": "%d independent rows on %d threads, %.1f s" % (nrows_all, cores, dt2)}
 
@@ -123,7 +146,7 @@ def ligero_commit_shape(gpu, torch, np, stream, with_cpu):
     return res
 
 
-def ligero_commit_slig(gpu, torch, np, A, rows, logn):
+def ligero_commit_slig(gpu, torch, np, A, rows, logn, pmc_all=None):
     """SURVEY 8(d) row 3, the synthetic Ligero shape large enough for an HBM roofline: LigeroParam(nw, nq = 0,
     rateinv = 4, nreq = 132, block_enc = 2^20) over GF2_128<5> (lib/ligero/ligero_param.h:185-243) => block = 174 762,
     dblock = 349 523, block_ext = 699 053 leaves; nrow = 1024 rows resident in HBM (the batch buffer A: its first
@@ -172,7 +195,16 @@ def ligero_commit_slig(gpu, torch, np, A, rows, logn):
     ok_tree = bool(hl[1].tobytes() == root)
     rs_bytes = rows * (block + be) * 16.0          # read the message, write the codeword
     hash_bytes = rows * ext * 16.0 + ext * 32.0    # read the columns, write the leaves
+    pmc_all = pmc_all or {}
+    rs_traffic = pmc_all.get("slig_rs_encode", {}).get("hbm_bytes_per_encode")      # sum over the encode's launches (PMC)
+    hash_traffic = pmc_all.get("column_leaves_kernel", {}).get("hbm_bytes_per_launch")
     return {"shape": "LigeroParam(nw, 0, 4, 132, 2^%d), GF2_128<5>: %d rows, block %d, dblock %d, %d leaves" % (logn, rows, block, dblock, ext),
+            "rs_roofline": {"bound": "hbm", "achieved": rs_bytes / rs_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rs_bytes / rs_ms / 1e6 / HBM_PEAK_GBS,
+                            "traffic": rs_traffic, "traffic_over_algorithmic": (rs_traffic / rs_bytes) if rs_traffic else None,
+                            "kernel": "bs_cin + bs_bfly2 / bs_range passes + bs_cout (tower representation)"},
+            "hash_roofline": {"bound": "hbm", "achieved": hash_bytes / hash_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hash_bytes / hash_ms / 1e6 / HBM_PEAK_GBS,
+                              "traffic": hash_traffic, "traffic_over_algorithmic": (hash_traffic / hash_bytes) if hash_traffic else None,
+                              "kernel": "column_leaves_kernel (+ merkle levels)"},
             "rs_encode_ms": rs_ms, "rs_algo_GBps": rs_bytes / rs_ms / 1e6, "rs_frac_of_hbm": rs_bytes / rs_ms / 1e6 / HBM_PEAK_GBS,
             "column_commit_ms": hash_ms, "hash_algo_GBps": hash_bytes / hash_ms / 1e6, "hash_frac_of_hbm": hash_bytes / hash_ms / 1e6 / HBM_PEAK_GBS,
             "sha256_compressions": ext * ((32 + 16 * rows + 9 + 63) // 64) + ext - 1,
@@ -215,6 +247,22 @@ def ligero_commit_sharded(pkg, gpu, torch, np, dist, rank, world):
     return {"shape": "GF2_128<4>, %d rows x 2^15, block %d, %d leaves, rows sharded x%d" % (p.nrow, p.block, p.block_ext, world),
             "commit_wall_ms": min(times), "all_ranks_same_root": same,
             "includes": "host layout replay + upload of the slab + RS encode + all_to_all + column hash + all_gather + tree"}
+
+
+PUBLISHED_M4_MS = {1: 5.30, 2: 9.60, 4: 18.73, 8: 35.39, 16: 65.62, 32: 125.23, 33: 132.71}  # docs/content/en/docs/benchmarks.md:55-61
+
+
+def zk_throughput(device, jobs, ks, seconds, timeout=600):
+    """Throughput mode (tools/zk_throughput.py): K concurrent provers on this rank's device -- K host threads, each with its own
+    lfgpu context + stream, one copy of the circuit in HBM -- in a CHILD process (the HIP runtime reads GPU_MAX_HW_QUEUES when it
+    initialises, and this process initialised it long ago).  Every worker first REQUIRES the reference's wire bytes."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "zk_throughput.py")
+    r = subprocess.run([sys.executable, tool, "--device", str(device), "--jobs", ",".join(jobs), "--k", ",".join(str(k) for k in ks),
+                        "--seconds", str(seconds)], capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def zk_prove_flatsha(pkg, gpu, np, nb, with_cpu, reps=3):
@@ -271,7 +319,7 @@ def zk_prove_flatsha(pkg, gpu, np, nb, with_cpu, reps=3):
         vbest = dt if vbest is None or dt < vbest else vbest
     res["verify_ms"] = vbest
     res["verify_accepts"] = bool(okv)
-    res["published_mac_m4_total_ms"] = 125.23 if nb == 32 else None  # reference docs/content/en/docs/benchmarks.md:60 (BM_ShaZK_fp2_128/32)
+    res["published_mac_m4_total_ms"] = PUBLISHED_M4_MS.get(nb)  # reference docs/content/en/docs/benchmarks.md:55-61 (BM_ShaZK_fp2_128/nb)
     gen = os.path.join(ROOT, "oracle", "_ref", "gen_flatsha")
     if with_cpu and os.path.exists(gen):
         with tempfile.TemporaryDirectory() as td:
@@ -285,7 +333,7 @@ def zk_prove_flatsha(pkg, gpu, np, nb, with_cpu, reps=3):
     return res
 
 
-def zk_prove_mdoc(pkg, gpu, np, reps=3):
+def zk_prove_mdoc(pkg, gpu, np, reps=3, end_to_end=True):
     """BASELINE config 5 ("End-to-end MDOC/ECDSA prove"): the two real mdoc circuits (kZkSpecs[0]) with the witnesses of a real
     proof (tests/golden/mdoc_*, made by the reference: oracle/ref_mdoc.cc) -- hash circuit over GF2_128 (7.76 M terms), signature
     circuit over Fp256Base (32-byte elements) -- each committed, proved and verified stand-alone by the library; wire bytes
@@ -343,14 +391,15 @@ def zk_prove_mdoc(pkg, gpu, np, reps=3):
                          wire_bytes_identical_to_reference=bool(identical), verify_ms=vbest, verify_accepts=bool(okv), circuit_parse_upload_ms=t_up,
                          cpu_reference={"commit_ms": info["ref_commit_ms"], "prove_ms": info["ref_prove_ms"],
                                         "total_ms": info["ref_commit_ms"] + info["ref_prove_ms"], "cores": 1, "kind": "reference",
-                                        "note": "measured in the build container when the fixture was made"})
+                                        "host": "build container, NOT this host",
+                                        "note": "cross-host: measured in the build container when the fixture was made; the same-host comparison is end_to_end below"})
         zk.close()
         circ.close()
     rng_t.close()
     # the whole run_mdoc_prover / run_mdoc_verifier bodies with the library's provers / verifiers in the reference's place, next
     # to the reference's own on this host (oracle/_ref/mdoc_gpu: built in the build container, travels with the snapshot)
     exe = os.path.join(ROOT, "oracle", "_ref", "mdoc_gpu")
-    if os.path.exists(exe):
+    if end_to_end and os.path.exists(exe):
         import subprocess
         try:
             r = subprocess.run([exe, "3"], capture_output=True, timeout=240)
@@ -434,6 +483,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the CPU baseline first (rank 0; bounded to ~10 s), before any GPU leg has host threads spinning; for N > 1 as well
+    cpu_base = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline(logn)
+    barrier()
+
     # ---- correctness guard (untimed): row 0 of one fftb against the oracle
     import oracle_lib as ol
     o = ol.oracle()
@@ -466,10 +521,13 @@ def main():
     # HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE with the gfx950 correction + WRITE_SIZE), collected
     # with the same command and committed under profiles/ -- counters cannot be read in-process
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic_fp_fft_tile.json")
-    if os.path.exists(pmc) and rows == 1024 and logn == 20:
+    pmc_all = {}
+    pmc = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")  # this round's counters (tools/pmc_traffic.sh -> tools/pmc_summary.py)
+    if os.path.exists(pmc):
         with open(pmc) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]
+            pmc_all = json.load(f)
+    if rows == 1024 and logn == 20 and "fp_fft_tile" in pmc_all:
+        traffic = pmc_all["fp_fft_tile"]["hbm_bytes_per_launch"]
     kern_ms = dev_ms / (args.steps * launches_per_step)
     algo_bytes_per_launch = 2.0 * nelem * 16 / launches_per_step
     achieved = algo_bytes_per_launch / (kern_ms * 1e-3) / 1e9
@@ -546,15 +604,59 @@ def main():
                             "roofline": {"bound": "hbm", "achieved": agb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": agb / HBM_PEAK_GBS,
                                          "note": "same two-pass plan and kernel (fp_fft_tile) as the headline, cheaper field"}}
     if rank == 0 and not args.no_secondary and logn == 20 and rows == 1024:
-        out["ligero_commit_slig"] = ligero_commit_slig(gpu, torch, np, A, rows, logn)
+        out["ligero_commit_slig"] = ligero_commit_slig(gpu, torch, np, A, rows, logn, pmc_all)
     if rank == 0 and not args.no_secondary:
         out["ligero_commit_flatsha32"] = ligero_commit_shape(gpu, torch, np, stream, not args.no_cpu_baseline)
-        del A  # the ZK path allocates its own buffers
-        out["zk_prove_flatsha256"] = zk_prove_flatsha(pkg, gpu, np, 32, not args.no_cpu_baseline)
-        try:  # BASELINE config 5; a failure here must not cost the headline line
-            out["zk_prove_mdoc"] = zk_prove_mdoc(pkg, gpu, np)
+    del A  # the ZK path allocates its own buffers
+    torch.cuda.empty_cache()
+    if not args.no_secondary:
+        # ---- BASELINE's first metric on EVERY rank (independent proofs are the N-GPU mode of the real circuits: their tableaux are
+        # 2.5 - 20 MB): latency of one proof per rank, then the throughput mode, summed over the ranks below
+        mine = {}
+        try:
+            if rank == 0:  # every block count the reference publishes (benchmarks.md:55-61); the other ranks: the 32-block one
+                by_nb = {}
+                for nb in (1, 2, 4, 8, 16, 32, 33):
+                    by_nb[str(nb)] = zk_prove_flatsha(pkg, gpu, np, nb, not args.no_cpu_baseline)
+                out["zk_prove_flatsha256"] = dict(by_nb["32"], by_sha_blocks={k: {kk: v.get(kk) for kk in ("total_ms", "commit_ms", "prove_ms", "verify_ms", "wire_bytes_identical_to_reference", "published_mac_m4_total_ms", "cpu_reference")} for k, v in by_nb.items()})
+                mine["flatsha32_ms"] = by_nb["32"]["total_ms"]
+            else:
+                mine["flatsha32_ms"] = zk_prove_flatsha(pkg, gpu, np, 32, False)["total_ms"]
+        except Exception as e:  # noqa: BLE001 -- a failure here must not cost the headline line
+            if rank == 0:
+                out["zk_prove_flatsha256"] = {"error": repr(e)[:300]}
+        try:  # BASELINE config 5
+            md = zk_prove_mdoc(pkg, gpu, np, end_to_end=(rank == 0))
+            mine["mdoc_ms"] = md["total_ms"]
+            if rank == 0:
+                out["zk_prove_mdoc"] = md
         except Exception as e:  # noqa: BLE001
-            out["zk_prove_mdoc"] = {"error": repr(e)[:300]}
+            if rank == 0:
+                out["zk_prove_mdoc"] = {"error": repr(e)[:300]}
+        barrier()
+        # throughput: rank 0 sweeps K on one GPU at N = 1; with N > 1 every rank runs K = 8 at the same time (replicas)
+        ks = [1, 2, 4, 8, 16] if world == 1 else [8]
+        thr = zk_throughput(local_rank, ["flatsha32", "mdoc"], ks, 2.0)
+        agg = {}
+        for job in ("flatsha32", "mdoc"):
+            best = max((v["proofs_per_s"] for v in thr.get(job, {}).get("k", {}).values()), default=0.0)
+            agg[job] = best
+        if dist is not None:
+            tt = torch.tensor([agg["flatsha32"], agg["mdoc"], mine.get("flatsha32_ms", 0.0), mine.get("mdoc_ms", 0.0)], dtype=torch.float64, device="cuda")
+            mx = tt.clone()
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            agg = {"flatsha32": float(tt[0]), "mdoc": float(tt[1])}
+            lat = {"flatsha32_ms_max_over_ranks": float(mx[2]), "mdoc_ms_max_over_ranks": float(mx[3])}
+        else:
+            lat = {"flatsha32_ms_max_over_ranks": mine.get("flatsha32_ms"), "mdoc_ms_max_over_ranks": mine.get("mdoc_ms")}
+        if rank == 0:
+            out["zk_throughput"] = {
+                "what": "independent proofs (replicas): K concurrent provers per GPU (host threads, own context + stream each, one copy of the circuit), summed over %d GPU(s); every worker first reproduces the reference's wire bytes" % world,
+                "proofs_per_s": {"flatsha256_32_blocks": agg["flatsha32"], "mdoc_hash_plus_signature": agg["mdoc"]},
+                "single_proof_latency": lat,
+                "rank0_sweep": thr,
+                "cpu_reference_proofs_per_s_1_thread": {"flatsha256_32_blocks": (1e3 / out["zk_prove_flatsha256"]["cpu_reference"]["total_ms"]) if isinstance(out.get("zk_prove_flatsha256"), dict) and out["zk_prove_flatsha256"].get("cpu_reference") else None}}
     if dist is not None and not args.no_secondary:
         try:  # the sharded Ligero commit over RCCL (every rank takes part); a failure here must not cost the headline line
             sh = ligero_commit_sharded(pkg, gpu, torch, np, dist, rank, world)
@@ -565,8 +667,8 @@ def main():
     if dist is not None:
         dist.barrier()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(logn)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     gpu.close()

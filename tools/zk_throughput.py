@@ -51,10 +51,10 @@ def load_stem(stem):
 class Worker:
     """one prover thread: context with its own stream, shared circuits, one ZkProver per circuit"""
 
-    def __init__(self, pkg, base_circuits, stems):
+    def __init__(self, pkg, base_circuits, stems, device=0):
         import ligero_fixture as lf
         self.pkg, self.lf = pkg, lf
-        self.gpu = pkg.LfGpu(0).own_stream()
+        self.gpu = pkg.LfGpu(device).own_stream()
         self.L = self.gpu.L
         self.items = []
         for st in stems:
@@ -115,7 +115,7 @@ class Worker:
         self.gpu.close()
 
 
-def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None):
+def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None, device=0):
     stems = [load_stem(s) for s in JOBS[job]]
     base = {st["stem"]: pkg.Circuit(base_gpu, st["raw"]) for st in stems}
     out = {}
@@ -123,7 +123,7 @@ def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None):
     try:
         for K in ks:
             while len(workers) < K:
-                w = Worker(pkg, base, stems)
+                w = Worker(pkg, base, stems, device)
                 w.check_parity()  # also the first proof of the handle: fills its per-circuit caches
                 for _ in range(warm_jobs):
                     w.one_job()
@@ -164,17 +164,18 @@ def main():
     ap.add_argument("--jobs", default="flatsha32,mdoc")
     ap.add_argument("--k", default="1,2,4,8,16")
     ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--json", action="store_true")
     a = ap.parse_args()
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
         ge.build()
     pkg = ge.load_package()
-    base_gpu = pkg.LfGpu(0).own_stream()
+    base_gpu = pkg.LfGpu(a.device).own_stream()
     res = {"hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
     log = (lambda s: print(s, file=sys.stderr, flush=True))
     for job in a.jobs.split(","):
-        res[job] = {"circuits": JOBS[job], "k": measure(pkg, base_gpu, job, [int(k) for k in a.k.split(",")], a.seconds, log=log)}
+        res[job] = {"circuits": JOBS[job], "k": measure(pkg, base_gpu, job, [int(k) for k in a.k.split(",")], a.seconds, log=log, device=a.device)}
     base_gpu.close()
     print(json.dumps(res))
 
