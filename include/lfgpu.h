@@ -66,6 +66,13 @@ int lfgpu_set_stream(lfgpu_ctx* ctx, void* hip_stream); /* NULL = default stream
  * (NULL) stream their work would serialise.  This is the throughput mode of BM_ShaZK's loop
  * (lib/circuits/sha/flatsha256_circuit_test.cc:510-536, one proof after the other) on a GPU that one proof leaves idle. */
 int lfgpu_own_stream(lfgpu_ctx* ctx);
+/* RandomEngine call pattern.  The reference draws element by element (RandomEngine::elt -> Field::sample -> bytes(kBytes),
+ * lib/random/random.h:38-48; one bytes(32) per Merkle nonce, lib/merkle/merkle_commitment.h:52-54).  By default the library
+ * merges consecutive draws into one call of the lfgpu_rng_fn hook -- the same bytes for every engine that is a byte stream
+ * (SecureRandomEngine, Transcript, the LCG test engines) and far fewer calls.  exact = 1 keeps the reference's call pattern,
+ * for engines whose output depends on the call boundaries (the TestRng of rust/runtime/zk/tests/zk.rs:283-292 returns
+ * {2, 0, 0, ...} for EVERY call).  Applies to lfgpu_ligero_commit and lfgpu_zk_commit on this context. */
+int lfgpu_set_rng_exact_calls(lfgpu_ctx* ctx, int exact);
 int lfgpu_sync(lfgpu_ctx* ctx);
 /* device-memory helpers so that C / ctypes / cgo callers need no HIP runtime */
 int lfgpu_malloc(lfgpu_ctx* ctx, size_t bytes, void** d_out);

@@ -59,6 +59,9 @@ void lfgpu_transcript_write_bytes(lfgpu_transcript* t, const uint8_t* data, size
 void lfgpu_transcript_write_elt(lfgpu_transcript* t, const uint8_t* elt16);
 void lfgpu_transcript_write_elt_array(lfgpu_transcript* t, const uint8_t* elts16, size_t n);
 void lfgpu_transcript_bytes(lfgpu_transcript* t, uint8_t* out, size_t n);
+/* ... for elements whose to_bytes_field image is nbytes long (Fp256Base: 32) */
+void lfgpu_transcript_write_elt_sized(lfgpu_transcript* t, const uint8_t* elt, size_t nbytes);
+void lfgpu_transcript_write_elt_array_sized(lfgpu_transcript* t, const uint8_t* elts, size_t n, size_t nbytes);
 /* primitives the transcript is built from (known-answer tested) */
 void lfgpu_sha256(const uint8_t* data, size_t n, uint8_t out[32]);
 void lfgpu_aes256_ecb_block(const uint8_t key[32], const uint8_t in[16], uint8_t out[16]);

@@ -26,7 +26,7 @@ F64_P = 2**64 - 2**32 + 1
 F64_OMEGA32 = 2752994695033296049
 
 ABI_SYMBOLS = [
-    "lfgpu_init", "lfgpu_shutdown", "lfgpu_last_error", "lfgpu_set_stream", "lfgpu_own_stream", "lfgpu_sync", "lfgpu_malloc",
+    "lfgpu_init", "lfgpu_shutdown", "lfgpu_last_error", "lfgpu_set_stream", "lfgpu_own_stream", "lfgpu_set_rng_exact_calls", "lfgpu_sync", "lfgpu_malloc",
     "lfgpu_free", "lfgpu_memcpy_h2d", "lfgpu_memcpy_d2h", "lfgpu_fp128_fft", "lfgpu_f64_2_fft", "lfgpu_gf2128_lch14_fft",
     "lfgpu_gf2128_rs_encode_rows", "lfgpu_gf2128_rs_encode_tableau", "lfgpu_fp128_rs_encode_rows", "lfgpu_fp256_rs_encode_rows", "lfgpu_column_commit", "lfgpu_column_leaves", "lfgpu_merkle_build_tree",
     "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g", "lfgpu_sumcheck_layer", "lfgpu_raw_eq2", "lfgpu_quad_bind_gh_all",
     # include/lfgpu_zk.h
     "lfgpu_transcript_new", "lfgpu_transcript_free", "lfgpu_transcript_get_ops", "lfgpu_transcript_write_bytes",
-    "lfgpu_transcript_write_elt", "lfgpu_transcript_write_elt_array", "lfgpu_transcript_bytes", "lfgpu_sha256",
+    "lfgpu_transcript_write_elt", "lfgpu_transcript_write_elt_array", "lfgpu_transcript_bytes", "lfgpu_transcript_write_elt_sized", "lfgpu_transcript_write_elt_array_sized", "lfgpu_sha256",
     "lfgpu_aes256_ecb_block", "lfgpu_host_gf2128_mul", "lfgpu_crypto_hw", "lfgpu_circuit_from_lfc1", "lfgpu_circuit_share", "lfgpu_circuit_get_info", "lfgpu_circuit_layer_info",
     "lfgpu_circuit_free", "lfgpu_zk_prover_new", "lfgpu_zk_prover_param", "lfgpu_zk_commit", "lfgpu_zk_prove",
     "lfgpu_zk_proof_write", "lfgpu_zk_timings", "lfgpu_zk_prover_free", "lfgpu_zk_verify", "lfgpu_zk_verify_committed",
@@ -96,7 +96,7 @@ def load_library():
     vp, sz, u64, ci = C.c_void_p, C.c_size_t, C.c_uint64, C.c_int
     pu64 = C.POINTER(C.c_uint64)
     sig = {
-        "lfgpu_init": [ci, C.POINTER(vp)], "lfgpu_shutdown": [vp], "lfgpu_set_stream": [vp, vp], "lfgpu_own_stream": [vp], "lfgpu_sync": [vp],
+        "lfgpu_init": [ci, C.POINTER(vp)], "lfgpu_shutdown": [vp], "lfgpu_set_stream": [vp, vp], "lfgpu_own_stream": [vp], "lfgpu_set_rng_exact_calls": [vp, ci], "lfgpu_sync": [vp],
         "lfgpu_malloc": [vp, sz, C.POINTER(vp)], "lfgpu_free": [vp, vp],
         "lfgpu_memcpy_h2d": [vp, vp, vp, sz], "lfgpu_memcpy_d2h": [vp, vp, vp, sz],
         "lfgpu_fp128_fft": [vp, ci, sz, sz, pu64, u64, vp, sz],
@@ -168,6 +168,7 @@ def load_library():
     for name, args in (("lfgpu_transcript_free", [vp]), ("lfgpu_transcript_get_ops", [vp, C.POINTER(TranscriptOps)]),
                        ("lfgpu_transcript_write_bytes", [vp, vp, sz]), ("lfgpu_transcript_write_elt", [vp, vp]),
                        ("lfgpu_transcript_write_elt_array", [vp, vp, sz]), ("lfgpu_transcript_bytes", [vp, vp, sz]),
+                       ("lfgpu_transcript_write_elt_sized", [vp, vp, sz]), ("lfgpu_transcript_write_elt_array_sized", [vp, vp, sz, sz]),
                        ("lfgpu_sha256", [vp, sz, vp]), ("lfgpu_aes256_ecb_block", [vp, vp, vp]),
                        ("lfgpu_host_gf2128_mul", [pu64, pu64, pu64])):
         fn = getattr(L, name)
@@ -242,6 +243,10 @@ class LfGpu:
         """a non-blocking stream of the context's own: K contexts in K host threads then run concurrently on one device"""
         self._ck(self.L.lfgpu_own_stream(self.h))
         return self
+
+    def set_rng_exact_calls(self, exact=True):
+        """one RandomEngine call per element / nonce, as the reference draws (for engines that are not byte streams)"""
+        self._ck(self.L.lfgpu_set_rng_exact_calls(self.h, 1 if exact else 0))
 
     def sync(self):
         self._ck(self.L.lfgpu_sync(self.h))
@@ -569,6 +574,13 @@ class FsTranscript:
     def write_array(self, elts):
         b = b"".join(bytes(e) for e in elts)
         self.L.lfgpu_transcript_write_elt_array(self.h, b, len(elts))
+
+    def write_elt_sized(self, e):
+        self.L.lfgpu_transcript_write_elt_sized(self.h, bytes(e), len(e))
+
+    def write_array_sized(self, elts, nbytes):
+        b = b"".join(bytes(e) for e in elts)
+        self.L.lfgpu_transcript_write_elt_array_sized(self.h, b, len(elts), nbytes)
 
     def bytes(self, n):
         buf = C.create_string_buffer(n)

@@ -274,6 +274,11 @@ int lfgpu_own_stream(lfgpu_ctx* c) {
   c->stream = c->own_stream;
   return LFGPU_OK;
 }
+int lfgpu_set_rng_exact_calls(lfgpu_ctx* c, int exact) {
+  if (!c) return LFGPU_ERR_ARG;
+  c->rng_exact = exact ? 1 : 0;
+  return LFGPU_OK;
+}
 int lfgpu_sync(lfgpu_ctx* c) {
   if (!c) return LFGPU_ERR_ARG;
   LF_HIP(c, hipStreamSynchronize(c->stream));

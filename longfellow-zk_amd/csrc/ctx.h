@@ -79,6 +79,10 @@ struct lfgpu_ctx {
   // launching resident grids
   int cu_held = 0;
   int grid_strikes = 0;
+  // lfgpu_set_rng_exact_calls: 1 = every RandomEngine draw is its own call of the caller's hook with the reference's size (16 /
+  // 32 bytes per element, kSubFieldBytes per subfield element, 32 per Merkle nonce); 0 = consecutive draws may be merged into
+  // one call, which is the same bytes for every engine that is a byte stream
+  int rng_exact = 0;
 };
 // Per-device CU budget of the kernels whose workgroups wait for each other (sc_grid_layer_kernel, grid256_layer_kernel, the
 // single-workgroup resident kernel).  Such a grid is only safe when ALL its workgroups are placed together; two grids each

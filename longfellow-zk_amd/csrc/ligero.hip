@@ -111,12 +111,13 @@ struct Sampler {
   const GfHostCtx* g;
   lfgpu_rng_fn rng;
   void* user;
+  bool exact = false;  // lfgpu_set_rng_exact_calls: one call per element, as the reference draws
   // n consecutive full-field elements.  GF2_128::sample consumes exactly 16 bytes per element
   // (gf2_128.h:182-190), so n draws of 16 bytes equal one draw of 16n bytes for every byte-stream
   // RandomEngine of the reference (LCG test engines, Transcript/FSPRF, SecureRandomEngine); Fp128 uses
   // rejection sampling and is drawn element by element.
   void elts(elt_t* out, size_t n) {
-    if (field == LFGPU_FIELD_GF2_128) {
+    if (field == LFGPU_FIELD_GF2_128 && !exact) {
       rng(user, reinterpret_cast<uint8_t*>(out), 16 * n);  // little-endian host: bytes are the Elt image
     } else {
       for (size_t i = 0; i < n; ++i) out[i] = elt();
@@ -190,8 +191,8 @@ int lf_rs_rows(lfgpu_ctx* c, int field, int k, size_t nrow, size_t n, size_t m, 
 // happens.  Returns LFGPU_OK / LFGPU_ERR_ARG / LFGPU_ERR_ASSERT with a message in err (256 bytes).
 static int ligero_layout_host(int field, int k, const GfHostCtx* g, const lfgpu_ligero_param& p, const elt_t* W, size_t subfield_boundary,
                               const size_t* h_lqc, lfgpu_rng_fn rng, void* user, size_t row_lo, size_t row_hi, elt_t* H, uint8_t* nonces,
-                              char* err) {
-  Sampler S{field, k, g, rng, user};
+                              char* err, bool exact = false) {
+  Sampler S{field, k, g, rng, user, exact};
   const elt_t zero{0, 0};
   const size_t hw = p.dblock;
   std::vector<elt_t> spare(hw);
@@ -252,7 +253,9 @@ static int ligero_layout_host(int field, int k, const GfHostCtx* g, const lfgpu_
   }
   // MerkleCommitment::commit draws one 32-byte nonce per leaf, after the layout (merkle_commitment.h:52-54): one draw of
   // 32 * block_ext bytes is the same stream for every byte-stream engine
-  if (nonces) {
+  if (nonces && exact) {
+    for (size_t j = 0; j < p.block_ext; ++j) rng(user, nonces + 32 * j, 32);
+  } else if (nonces) {
     rng(user, nonces, 32 * p.block_ext);
   } else {
     std::vector<uint8_t> drop(32 * p.block_ext);
@@ -343,7 +346,7 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
   {
     char err[256] = {0};
     const int rc = ligero_layout_host(field, k, g, p, (const elt_t*)h_W, subfield_boundary, h_lqc, rng, user, 0, p.nrow, H.data(),
-                                      pr->nonces.data(), err);
+                                      pr->nonces.data(), err, c->rng_exact != 0);
     if (rc) return fail(lf_fail(c, rc, "%s", err));
   }
   const size_t tb = p.nrow * ld * 16, lb = 2 * p.block_ext * 32;

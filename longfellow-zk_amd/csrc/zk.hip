@@ -100,6 +100,8 @@ void lfgpu_transcript_write_bytes(lfgpu_transcript* t, const uint8_t* d, size_t 
 void lfgpu_transcript_write_elt(lfgpu_transcript* t, const uint8_t* e) { t->write_elt(e); }
 void lfgpu_transcript_write_elt_array(lfgpu_transcript* t, const uint8_t* e, size_t n) { t->write_elt_array(e, n); }
 void lfgpu_transcript_bytes(lfgpu_transcript* t, uint8_t* out, size_t n) { t->bytes(out, n); }
+void lfgpu_transcript_write_elt_sized(lfgpu_transcript* t, const uint8_t* e, size_t nbytes) { t->write_elt(e, nbytes); }
+void lfgpu_transcript_write_elt_array_sized(lfgpu_transcript* t, const uint8_t* e, size_t n, size_t nbytes) { t->write_elt_array(e, n, nbytes); }
 void lfgpu_sha256(const uint8_t* data, size_t n, uint8_t out[32]) {
   Sha256 s;
   s.update(data, n);

@@ -1474,9 +1474,15 @@ struct Lig256 {
 
 // the host half of LigeroProver::commit (ligero_prover.h:171-270 + merkle_commitment.h:52-54): every RandomEngine draw in the
 // reference's order (FpGeneric::sample and sample_subfield are the same function, fp_generic.h:360-376)
-int lig256_layout(const lfgpu_ligero_param& p, const E* W, const size_t* lqc, lfgpu_rng_fn rng, void* user, E* H, uint8_t* nonces, char* err) {
+int lig256_layout(const lfgpu_ligero_param& p, const E* W, const size_t* lqc, lfgpu_rng_fn rng, void* user, E* H, uint8_t* nonces, char* err, bool exact) {
   const size_t hw = p.dblock;
-  auto elts = [&](E* out, size_t n) { h256_sample_many(out, n, [&](uint8_t* b, size_t nb) { rng(user, b, nb); }); };
+  auto elts = [&](E* out, size_t n) {
+    if (exact) {  // one call per attempt, as FpGeneric::sample draws (fp_generic.h:360-371)
+      for (size_t i = 0; i < n; ++i) h256_sample_many(out + i, 1, [&](uint8_t* b, size_t nb) { rng(user, b, nb); });
+    } else {
+      h256_sample_many(out, n, [&](uint8_t* b, size_t nb) { rng(user, b, nb); });
+    }
+  };
   auto row = [&](size_t i) { return H + i * hw; };
   std::fill(H, H + p.nrow * hw, e32_zero());
   elts(row(p.ildt), p.block);  // layout_blinding_rows (:171-205)
@@ -1518,7 +1524,8 @@ int lig256_layout(const lfgpu_ligero_param& p, const E* W, const size_t* lqc, lf
       row(iqz + i)[j + p.r] = W[l[2]];
     }
   }
-  rng(user, nonces, 32 * p.block_ext);  // MerkleCommitment::commit: one nonce per leaf, after the layout
+  if (exact) for (size_t j = 0; j < p.block_ext; ++j) rng(user, nonces + 32 * j, 32);
+  else rng(user, nonces, 32 * p.block_ext);  // MerkleCommitment::commit: one nonce per leaf, after the layout
   return LFGPU_OK;
 }
 
@@ -1530,7 +1537,7 @@ int lig256_commit(lfgpu_ctx* c, const lfgpu_ligero_param& p, const E* W, const s
   L->nonces.resize(32 * p.block_ext);
   std::vector<E> H(p.nrow * p.dblock);
   char err[256] = {0};
-  const int rc = lig256_layout(p, W, lqc, rng, user, H.data(), L->nonces.data(), err);
+  const int rc = lig256_layout(p, W, lqc, rng, user, H.data(), L->nonces.data(), err, c->rng_exact != 0);
   if (rc) return lf_fail(c, rc, "%s", err);
   const size_t ld = p.block_enc;
   if (lf_pool_get(c, p.nrow * ld * 32, (void**)&L->d_T) != LFGPU_OK || lf_pool_get(c, 2 * p.block_ext * 32, (void**)&L->d_layers) != LFGPU_OK)
@@ -1931,7 +1938,8 @@ int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, co
   const size_t nl = C->layers.size();
   LF_HIP(c, hipSetDevice(c->device));
   std::vector<E> pads(z->pad_size - nl);  // every element fill_pad draws (the product wc0 * wc1 is computed), in order
-  h256_sample_many(pads.data(), pads.size(), [&](uint8_t* b, size_t n) { rng(rng_user, b, n); });
+  if (c->rng_exact) for (size_t i = 0; i < pads.size(); ++i) h256_sample_many(&pads[i], 1, [&](uint8_t* b, size_t n) { rng(rng_user, b, n); });
+  else h256_sample_many(pads.data(), pads.size(), [&](uint8_t* b, size_t n) { rng(rng_user, b, n); });
   size_t pd = 0;
   auto draw = [&] { return pads[pd++]; };
   std::vector<E> Wv(z->param.nw);

@@ -167,6 +167,53 @@ class SumcheckBase:
         return bytes(out)
 
 
+def prove_padded(sc, ins, tst, pads):
+    """ProverLayers::prove as ZkProver::prove runs it (lib/zk/zk_prover.h:117-127): every transmitted value is poly - pad
+    (round_h / end_layer of the padded prover, prover_layers.h:320-344), on the transcript `tst` -- the clone taken after
+    initialize_sumcheck_fiat_shamir.  pads[ly] = dict(hp={(hand, round): (t0, t2)}, wc=(wc0, wc1)).  Returns the bytes of
+    ZkProof::write_sc_proof (lib/zk/zk_proof.h:115-131): per layer, per round, p(0) of both hands then p(2) of both hands; wc."""
+    c, F = sc.c, sc.F
+    for _ in range(KMAX):
+        tst.elt_gf2128()
+    g0 = [_e(tst.elt_gf2128()) for _ in range(KMAX)]
+    G = [list(g0), list(g0)]
+    logv = c["logv"]
+    WC = [(0, 0), (0, 0)]
+    out = bytearray()
+    for ly, layer in enumerate(c["layers"]):
+        alpha, beta = _e(tst.elt_gf2128()), _e(tst.elt_gf2128())
+        logw = layer["logw"]
+        G0 = np.array(G[0][:max(1, logv)], dtype=np.uint64)
+        G1 = np.array(G[1][:max(1, logv)], dtype=np.uint64)
+        sc.begin_layer(ly, ins[ly], logv, G0, G1, alpha, beta)
+        s = F.add(WC[0], F.mul(alpha, WC[1]))
+        hands = [[], []]
+        sent = {}
+        for rnd in range(logw):
+            for hand in (0, 1):
+                a0, a2 = sc.round_partials(hand)
+                c1 = F.add(F.add(F.add(s, a0), a0), a2)
+                ev = [F.eval_monomial([a0, c1, a2], F.pts[k]) for k in range(3)]
+                t0 = F.add(ev[0], pads[ly]["hp"][(hand, rnd)][0])
+                t2 = F.add(ev[2], pads[ly]["hp"][(hand, rnd)][1])
+                sent[(hand, rnd)] = (t0, t2)
+                tst.write_elt(_b16(t0))
+                tst.write_elt(_b16(t2))
+                r = _e(tst.elt_gf2128())
+                hands[hand].append(r)
+                s = F.eval_lagrange3(ev, r)
+                sc.round_bind(hand, r, first=(rnd == 0 and hand == 0))
+        WC = sc.end_layer()
+        wcp = (F.add(WC[0], pads[ly]["wc"][0]), F.add(WC[1], pads[ly]["wc"][1]))
+        tst.write_array([_b16(wcp[0]), _b16(wcp[1])])
+        for rnd in range(logw):
+            out += _b16(sent[(0, rnd)][0]) + _b16(sent[(1, rnd)][0]) + _b16(sent[(0, rnd)][1]) + _b16(sent[(1, rnd)][1])
+        out += _b16(wcp[0]) + _b16(wcp[1])
+        G = [hands[0] + [(0, 0)] * (KMAX - logw), hands[1] + [(0, 0)] * (KMAX - logw)]
+        logv = logw
+    return bytes(out)
+
+
 class OracleSumcheck(SumcheckBase):
     """CPU: every step through the oracle (pins driver + transcript against the reference fixture without a GPU)"""
 
