@@ -225,11 +225,11 @@ def ligero_commit_sharded(pkg, gpu, torch, np, dist, rank, world):
     nw = p0.w * 1021
     p = pkg.ligero_param(pkg.FIELD_GF2_128, nw, 0, 4, 132, be)
     W = np.random.default_rng(7).integers(0, 2**63, size=(nw, 2), dtype=np.int64).view(np.uint64)
-    eng = par.GpuEngine(gpu, pkg.FIELD_GF2_128, 4, torch.device("cuda", torch.cuda.current_device()))
+    comm = par.TorchComm(None, torch.device("cuda", torch.cuda.current_device()))
     rng_t = pkg.FsTranscript(b"bench-sharded-commit")
     times, roots = [], []
     for rep in range(3):
-        pr = par.ShardedLigeroProver(eng, gpu.L, pkg.FIELD_GF2_128, p, 4, None)
+        pr = par.ShardedLigeroProver(gpu, pkg.FIELD_GF2_128, p, 4, comm=comm)  # lfgpu_ligero_commit_sharded behind the C ABI
         torch.cuda.synchronize()
         dist.barrier()
         t0 = _t.perf_counter()

@@ -287,6 +287,44 @@ int lfgpu_ligero_encode_rows(lfgpu_ctx* ctx, int field, int subfield_log_bits, c
 int lfgpu_ligero_prover_from_slab(lfgpu_ctx* ctx, int field, int subfield_log_bits, const lfgpu_ligero_param* p,
                                   size_t row_lo, size_t row_hi, void* d_slab, void* d_layers, const uint8_t* h_nonces,
                                   lfgpu_ligero_prover** out);
+/* ---- LigeroProver with the tableau rows sharded over the GPUs of a node, behind this ABI -------------------------
+ * One process per GPU; every rank calls the same entry points with the same arguments (SPMD).  The library does the
+ * orchestration -- RandomEngine stream drawn once on rank 0 and replayed everywhere, row-slab RS encode (no collective),
+ * ONE all_to_all that re-partitions the encoded columns, local column hash, all_gather of the leaf digests, the tree on every
+ * rank; the prove entry points below fold the ranks' partial vectors with the FIELD's addition -- and reaches the transport
+ * through three hooks, the way the transcript and the RandomEngine are hooks: the caller binds them to RCCL (one
+ * ncclAllGather / grouped ncclSend+ncclRecv / ncclBroadcast each; longfellow-zk_amd/parallel.py binds torch.distributed).
+ * Buffers are raw bytes; on_device = 1: device memory, and the exchange must be ordered after the work already enqueued on
+ * `stream` (the context's stream) and be complete, or enqueued on that stream, when the hook returns; on_device = 0: host.
+ * Every hook returns 0 on success.  Results (root, y vectors, opened columns, Merkle path) are identical on every rank and
+ * identical to the one-GPU lfgpu_ligero_commit fed the same RandomEngine. */
+typedef struct lfgpu_comm_ops {
+  void* user;
+  int rank, world;
+  /* every rank contributes `bytes` bytes; recv gets world * bytes, in rank order */
+  int (*all_gather)(void* user, const void* send, void* recv, size_t bytes, int on_device, void* stream);
+  /* rank q receives, from every rank p, the send_bytes[q] bytes at send + send_off[q] of p, into recv + recv_off[p]
+   * (recv_bytes[p] = what p sends to this rank); the arrays have `world` entries */
+  int (*all_to_all)(void* user, const void* send, const size_t* send_off, const size_t* send_bytes, void* recv,
+                    const size_t* recv_off, const size_t* recv_bytes, int on_device, void* stream);
+  int (*broadcast)(void* user, void* buf, size_t bytes, int root, int on_device, void* stream);
+} lfgpu_comm_ops;
+/* row slab [*row_lo, *row_hi) of rank `rank`: an even split of the rows, except that the quadratic rows [iq, nrow) all go to
+ * the last rank (a triple x, y, z is multiplied element-wise) */
+int lfgpu_ligero_row_shard(const lfgpu_ligero_param* p, int rank, int world, size_t* row_lo, size_t* row_hi);
+/* The host half alone (no device): rank 0 performs every RandomEngine draw of LigeroProver::commit once (`rng` is only
+ * called there), the byte stream is broadcast, and every rank lays out its slab from it (as lfgpu_ligero_layout_rows). */
+int lfgpu_ligero_layout_rows_sharded(int field, int subfield_log_bits, const lfgpu_ligero_param* p, const void* h_W,
+                                     size_t subfield_boundary, const size_t* h_lqc, lfgpu_rng_fn rng, void* rng_user,
+                                     const lfgpu_comm_ops* comm, void* h_rows, uint8_t* h_nonces);
+/* LigeroProver::commit (lib/ligero/ligero_prover.h:58-79) over comm->world GPUs.  The prover object it returns is used with
+ * the SAME prove entry points as a one-GPU prover (low_degree_proof, dot_proof[_sparse], quadratic_proof, open): they return
+ * the complete vectors on every rank. */
+int lfgpu_ligero_commit_sharded(lfgpu_ctx* ctx, int field, int subfield_log_bits, const lfgpu_ligero_param* p,
+                                const void* h_W, size_t subfield_boundary, const size_t* h_lqc, lfgpu_rng_fn rng,
+                                void* rng_user, const lfgpu_comm_ops* comm, uint8_t root_out[32], lfgpu_ligero_prover** out);
+/* host-only self-test of a caller's hooks (each with host buffers, world > 1 or 1): 0 when all three move the right bytes */
+int lfgpu_comm_selftest(const lfgpu_comm_ops* comm);
 /* low_degree_proof (:281-291): y[block] = T[ildt] + sum_i u_ldt[i] T[iw+i] */
 int lfgpu_ligero_low_degree_proof(lfgpu_ligero_prover* pr, const void* h_u_ldt, void* h_y);
 /* dot_proof (:293-309): y[dblock] = T[idot] + sum_i RS(block->dblock)([0^r | A_i]) (.) T[iw+i] */

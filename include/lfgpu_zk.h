@@ -96,6 +96,15 @@ typedef struct lfgpu_zk_prover lfgpu_zk_prover;
 int lfgpu_zk_prover_new(lfgpu_ctx* ctx, const lfgpu_circuit* c, size_t rateinv, size_t nreq, size_t block_enc,
                         lfgpu_zk_prover** out);
 int lfgpu_zk_prover_param(const lfgpu_zk_prover* zk, lfgpu_ligero_param* p);
+/* More than one GPU behind the same prover (BASELINE config 5 names it).  Every rank constructs the prover on its
+ * own device and calls commit / prove / proof_write with the same arguments and its own copy of the transcript (SPMD); `rng`
+ * is only drawn from on rank 0 (its stream is broadcast).  A Ligero tableau of at least min_tableau_bytes is committed with
+ * its rows sharded over the communicator's GPUs (lfgpu_ligero_commit_sharded in lfgpu.h: one all_to_all + one all_gather per
+ * commit, field-sum folds of the y vectors in prove); below the threshold the proof runs replicated, which is what the
+ * real mdoc / flatsha256 circuits want (their tableaux are 2.5 - 20 MB: a second GPU only adds latency -- use independent
+ * proofs per GPU instead, lfgpu_own_stream / bench.py zk_throughput).  The sumcheck always runs replicated.  Every rank ends
+ * with the same proof bytes as a one-GPU prover fed the same RandomEngine.  comm = NULL: back to one GPU.  16-byte fields. */
+int lfgpu_zk_prover_set_comm(lfgpu_zk_prover* zk, const lfgpu_comm_ops* comm, size_t min_tableau_bytes);
 /* ZkProver::commit (zk_prover.h:72-96): fill_pad from `rng`, Ligero-commit witness||pad, root -> transcript.
  * h_W: ninputs host elements (public inputs first). */
 int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_fn rng, void* rng_user,

@@ -82,7 +82,13 @@ void rng_hook(void* user, uint8_t* buf, size_t n) {  // RandomEngine::bytes (lib
 template <class Field, class ReadBufferT>
 class GpuZkProver {
  public:
-  GpuZkProver(const Context& ctx, const uint8_t* lfc1, size_t len, const Field& F) : c_(ctx), f_(F) {
+  // comm != nullptr: one process per GPU, every rank constructs the prover on its own Context and calls commit / prove with the
+  // same arguments (SPMD; only rank 0's RandomEngine is drawn from).  Ligero tableaux of at least min_tableau_bytes are
+  // committed with their rows sharded over the communicator's GPUs (lfgpu_zk_prover_set_comm, include/lfgpu_zk.h); the hooks
+  // are the caller's binding of all_gather / all_to_all / broadcast to RCCL.  16-byte fields.
+  GpuZkProver(const Context& ctx, const uint8_t* lfc1, size_t len, const Field& F, const lfgpu_comm_ops* comm = nullptr, size_t min_tableau_bytes = 0)
+      : c_(ctx), f_(F), have_comm_(comm != nullptr), min_tableau_bytes_(min_tableau_bytes) {
+    if (comm) comm_ = *comm;
     check(c_.get(), lfgpu_circuit_from_lfc1(c_.get(), lfc1, len, &circuit_), "lfgpu_circuit_from_lfc1");
   }
   ~GpuZkProver() {
@@ -97,6 +103,7 @@ class GpuZkProver {
   void commit(ZkProofT& zkp, const DenseT& W, TranscriptT& tp, RandomEngineT& rng) {
     if (!zk_) {
       check(c_.get(), lfgpu_zk_prover_new(c_.get(), circuit_, zkp.param.rateinv, zkp.param.nreq, zkp.param.block_enc, &zk_), "lfgpu_zk_prover_new");
+      if (have_comm_) check(c_.get(), lfgpu_zk_prover_set_comm(zk_, &comm_, min_tableau_bytes_), "lfgpu_zk_prover_set_comm");
       lfgpu_ligero_param p;
       check(c_.get(), lfgpu_zk_prover_param(zk_, &p), "lfgpu_zk_prover_param");
       if (p.nrow != zkp.param.nrow || p.block != zkp.param.block || p.nw != zkp.param.nw || p.block_ext != zkp.param.block_ext)
@@ -134,6 +141,9 @@ class GpuZkProver {
   const Field& f_;
   lfgpu_circuit* circuit_ = nullptr;
   lfgpu_zk_prover* zk_ = nullptr;
+  bool have_comm_ = false;
+  lfgpu_comm_ops comm_{};
+  size_t min_tableau_bytes_ = 0;
 };
 
 // Drop-in for ZkVerifier<Field, ReedSolomonFactory> (lib/zk/zk_verifier.h:42-94; call sites lib/circuits/mdoc/mdoc_zk.cc:669-705):

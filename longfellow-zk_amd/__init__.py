@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "lfgpu_merkle_open", "lfgpu_sumcheck_partials", "lfgpu_qw_scatter", "lfgpu_dense_bind", "lfgpu_hquad_bind_h",
     "lfgpu_rows_axpy", "lfgpu_gather_columns", "lfgpu_field_binop", "lfgpu_fp128_fft_host", "lfgpu_f64_2_fft_host", "lfgpu_gf2128_lch14_fft_host",
     "lfgpu_gf2128_rs_encode_rows_host", "lfgpu_fp128_rs_encode_rows_host", "lfgpu_fp256_rs_encode_rows_host", "lfgpu_column_commit_host",
-    "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_layout_rows", "lfgpu_ligero_encode_rows", "lfgpu_ligero_prover_from_slab", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
+    "lfgpu_ligero_param_init", "lfgpu_ligero_commit", "lfgpu_ligero_commit_sharded", "lfgpu_ligero_row_shard", "lfgpu_ligero_layout_rows_sharded", "lfgpu_comm_selftest", "lfgpu_ligero_layout_rows", "lfgpu_ligero_encode_rows", "lfgpu_ligero_prover_from_slab", "lfgpu_ligero_low_degree_proof", "lfgpu_ligero_dot_proof",
     "lfgpu_ligero_inner_product_rows", "lfgpu_ligero_dot_proof_sparse",
     "lfgpu_ligero_quadratic_proof", "lfgpu_ligero_open", "lfgpu_ligero_tableau", "lfgpu_ligero_free",
     "lfgpu_quad_upload", "lfgpu_quad_free", "lfgpu_eval_quad", "lfgpu_quad_bind_g", "lfgpu_sumcheck_layer", "lfgpu_raw_eq2", "lfgpu_quad_bind_gh_all",
@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "lfgpu_transcript_new", "lfgpu_transcript_free", "lfgpu_transcript_get_ops", "lfgpu_transcript_write_bytes",
     "lfgpu_transcript_write_elt", "lfgpu_transcript_write_elt_array", "lfgpu_transcript_bytes", "lfgpu_transcript_write_elt_sized", "lfgpu_transcript_write_elt_array_sized", "lfgpu_sha256",
     "lfgpu_aes256_ecb_block", "lfgpu_host_gf2128_mul", "lfgpu_crypto_hw", "lfgpu_circuit_from_lfc1", "lfgpu_circuit_share", "lfgpu_circuit_get_info", "lfgpu_circuit_layer_info",
-    "lfgpu_circuit_free", "lfgpu_zk_prover_new", "lfgpu_zk_prover_param", "lfgpu_zk_commit", "lfgpu_zk_prove",
+    "lfgpu_circuit_free", "lfgpu_zk_prover_new", "lfgpu_zk_prover_set_comm", "lfgpu_zk_prover_param", "lfgpu_zk_commit", "lfgpu_zk_prove",
     "lfgpu_zk_proof_write", "lfgpu_zk_timings", "lfgpu_zk_prover_free", "lfgpu_zk_verify", "lfgpu_zk_verify_committed",
 ]
 
@@ -127,6 +127,11 @@ def load_library():
         "lfgpu_ligero_param_init": [C.POINTER(LigeroParam), ci, ci, sz, sz, sz, sz, sz],
         "lfgpu_ligero_commit": [vp, ci, ci, C.POINTER(LigeroParam), vp, sz, vp, RNG_FN, vp, vp, C.POINTER(vp)],
         "lfgpu_ligero_layout_rows": [ci, ci, C.POINTER(LigeroParam), vp, sz, vp, RNG_FN, vp, sz, sz, vp, vp],
+        "lfgpu_ligero_commit_sharded": [vp, ci, ci, C.POINTER(LigeroParam), vp, sz, vp, RNG_FN, vp, vp, vp, C.POINTER(vp)],
+        "lfgpu_ligero_row_shard": [C.POINTER(LigeroParam), ci, ci, C.POINTER(sz), C.POINTER(sz)],
+        "lfgpu_ligero_layout_rows_sharded": [ci, ci, C.POINTER(LigeroParam), vp, sz, vp, RNG_FN, vp, vp, vp, vp],
+        "lfgpu_comm_selftest": [vp],
+        "lfgpu_zk_prover_set_comm": [vp, vp, sz],
         "lfgpu_ligero_encode_rows": [vp, ci, ci, C.POINTER(LigeroParam), sz, sz, vp, vp],
         "lfgpu_ligero_prover_from_slab": [vp, ci, ci, C.POINTER(LigeroParam), sz, sz, vp, vp, vp, C.POINTER(vp)],
         "lfgpu_ligero_low_degree_proof": [vp, vp, vp],
@@ -651,6 +656,12 @@ class ZkProver:
         self.h = h
         self.param = LigeroParam()
         gpu._ck(gpu.L.lfgpu_zk_prover_param(self.h, C.byref(self.param)))
+
+    def set_comm(self, comm, min_tableau_bytes=0):
+        """lfgpu_zk_prover_set_comm: `comm` = parallel.TorchComm (or None); tableaux of at least min_tableau_bytes are
+        committed with their rows sharded over the communicator's GPUs, smaller ones replicated"""
+        self._comm = comm
+        self.gpu._ck(self.gpu.L.lfgpu_zk_prover_set_comm(self.h, C.byref(comm.ops) if comm is not None else None, min_tableau_bytes))
 
     def commit(self, W, rng_bytes, transcript):
         import numpy as np

@@ -203,3 +203,8 @@ static inline unsigned lf_log2(size_t n) {
   while (((size_t)1 << l) < n) ++l;
   return l;
 }
+
+// ligero.hip: helpers of the sharded (multi-GPU) paths, shared with the ZK driver
+int lf_comm_bcast_blob(const lfgpu_comm_ops* cm, std::vector<uint8_t>& blob);  // rank 0's bytes to every rank (host buffers)
+void lf_replay_rng(const std::vector<uint8_t>* data, lfgpu_rng_fn* fn, void** user, void* storage /* 32 bytes */);
+void lf_record_rng(lfgpu_rng_fn rng, void* rng_user, std::vector<uint8_t>* rec, lfgpu_rng_fn* fn, void** user, void* storage /* 32 bytes */);

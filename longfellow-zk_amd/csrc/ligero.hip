@@ -10,6 +10,7 @@
 // uploaded once; the GPU then RS-encodes every row (K3/K4) and commits the columns
 // (K5/K6).  The tableau stays in HBM for the prove-side row combinations (K12).
 #include <algorithm>
+#include <new>
 
 #include "ctx.h"
 
@@ -25,6 +26,10 @@ struct lfgpu_ligero_prover {
   // functions then return this slab's PARTIAL sums (rows it does not hold contribute zero); the caller folds the ranks.
   size_t row_lo = 0, row_hi = 0;
   bool owns = true;  // d_T / d_layers are freed (stashed) by lfgpu_ligero_free
+  // a prover made by lfgpu_ligero_commit_sharded: the prove entry points fold the ranks' partial results through these hooks
+  bool sharded = false;
+  lfgpu_comm_ops comm{};
+  std::vector<std::pair<size_t, size_t>> spans;  // row slab of every rank
   bool has(size_t i) const { return i >= row_lo && i < row_hi; }
   elt_t* row(size_t i) const { return d_T + (i - row_lo) * p.block_enc; }
 };
@@ -259,7 +264,8 @@ static int ligero_layout_host(int field, int k, const GfHostCtx* g, const lfgpu_
     rng(user, nonces, 32 * p.block_ext);
   } else {
     std::vector<uint8_t> drop(32 * p.block_ext);
-    rng(user, drop.data(), drop.size());
+    if (exact) for (size_t j = 0; j < p.block_ext; ++j) rng(user, drop.data() + 32 * j, 32);
+    else rng(user, drop.data(), drop.size());
   }
   return LFGPU_OK;
 }
@@ -369,6 +375,269 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
   return LFGPU_OK;
 }
 
+// ------------------------------------------------------------------ rows sharded over the GPUs of a node
+static void shard_split(size_t n, int rank, int world, size_t* start, size_t* count) {  // contiguous, sizes differ by at most 1
+  const size_t base = n / (size_t)world, rem = n % (size_t)world, r = (size_t)rank;
+  *start = r * base + std::min(r, rem);
+  *count = base + (r < rem ? 1 : 0);
+}
+extern "C" int lfgpu_ligero_row_shard(const lfgpu_ligero_param* p, int rank, int world, size_t* row_lo, size_t* row_hi) {
+  if (!p || !row_lo || !row_hi || world < 1 || rank < 0 || rank >= world) return LFGPU_ERR_ARG;
+  size_t lo, cnt;
+  shard_split(p->nrow, rank, world, &lo, &cnt);
+  *row_lo = std::min(lo, p->iq);
+  *row_hi = rank == world - 1 ? p->nrow : std::min(lo + cnt, p->iq);
+  return LFGPU_OK;
+}
+namespace {
+struct RecordRng {  // rank 0: the caller's engine, every byte kept
+  lfgpu_rng_fn rng;
+  void* user;
+  std::vector<uint8_t>* rec;
+};
+void record_fn(void* u, uint8_t* buf, size_t n) {
+  RecordRng* r = (RecordRng*)u;
+  r->rng(r->user, buf, n);
+  r->rec->insert(r->rec->end(), buf, buf + n);
+}
+struct ReplayRng {  // every rank: the broadcast stream (running dry yields zeros and sets `dry`)
+  const std::vector<uint8_t>* data;
+  size_t pos = 0;
+  bool dry = false;
+};
+void replay_fn(void* u, uint8_t* buf, size_t n) {
+  ReplayRng* r = (ReplayRng*)u;
+  if (r->pos + n > r->data->size()) {
+    r->dry = true;
+    memset(buf, 0, n);
+    return;
+  }
+  memcpy(buf, r->data->data() + r->pos, n);
+  r->pos += n;
+}
+bool comm_ok(const lfgpu_comm_ops* cm) { return cm && cm->world >= 1 && cm->rank >= 0 && cm->rank < cm->world && cm->all_gather && cm->all_to_all && cm->broadcast; }
+}  // namespace
+// one rank's byte string to every rank (length first); host buffers
+int lf_comm_bcast_blob(const lfgpu_comm_ops* cm, std::vector<uint8_t>& blob) {
+  if (cm->world == 1) return LFGPU_OK;
+  uint64_t n = cm->rank == 0 ? blob.size() : 0;
+  if (cm->broadcast(cm->user, &n, 8, 0, 0, nullptr)) return LFGPU_ERR_HIP;
+  if (cm->rank != 0) blob.assign(n, 0);
+  if (n && cm->broadcast(cm->user, blob.data(), n, 0, 0, nullptr)) return LFGPU_ERR_HIP;
+  return LFGPU_OK;
+}
+void lf_replay_rng(const std::vector<uint8_t>* data, lfgpu_rng_fn* fn, void** user, void* storage /* >= sizeof(ReplayRng) */) {
+  ReplayRng* r = new (storage) ReplayRng{data, 0, false};
+  *fn = replay_fn;
+  *user = r;
+}
+void lf_record_rng(lfgpu_rng_fn rng, void* rng_user, std::vector<uint8_t>* rec, lfgpu_rng_fn* fn, void** user, void* storage /* >= sizeof(RecordRng) */) {
+  RecordRng* r = new (storage) RecordRng{rng, rng_user, rec};
+  *fn = record_fn;
+  *user = r;
+}
+// field sum over the ranks of a host vector every rank holds a partial of (RCCL has no XOR / mod-p reduction: all_gather + fold)
+static int comm_fold(const lfgpu_ligero_prover* pr, elt_t* y, size_t n) {
+  const lfgpu_comm_ops& cm = pr->comm;
+  if (cm.world == 1) return LFGPU_OK;
+  std::vector<elt_t> all((size_t)cm.world * n);
+  if (cm.all_gather(cm.user, y, all.data(), n * 16, 0, nullptr)) return lf_fail(pr->c, LFGPU_ERR_HIP, "ligero (sharded): all_gather hook failed");
+  for (size_t j = 0; j < n; ++j) y[j] = all[j];
+  for (int q = 1; q < cm.world; ++q) {
+    const elt_t* v = all.data() + (size_t)q * n;
+    if (pr->field == LFGPU_FIELD_GF2_128)
+      for (size_t j = 0; j < n; ++j) y[j] = gf_add(y[j], v[j]);
+    else
+      for (size_t j = 0; j < n; ++j) y[j] = fp_add(y[j], v[j]);
+  }
+  return LFGPU_OK;
+}
+
+static int layout_sharded_host(int field, int k, const GfHostCtx* g, const lfgpu_ligero_param& p, const void* h_W, size_t subfield_boundary,
+                               const size_t* h_lqc, lfgpu_rng_fn rng, void* user, const lfgpu_comm_ops* cm, bool exact, size_t row_lo, size_t row_hi,
+                               elt_t* H, uint8_t* nonces, char* err) {
+  // the RandomEngine is ONE sequential stream (ligero_prover.h:171-270, merkle_commitment.h:52-54): rank 0 draws all of it
+  // through the layout with an empty slab, everyone replays it and keeps its rows
+  std::vector<uint8_t> stream;
+  if (cm->rank == 0) {
+    RecordRng rec{rng, user, &stream};
+    const int rc = ligero_layout_host(field, k, g, p, (const elt_t*)h_W, subfield_boundary, h_lqc, record_fn, &rec, 0, 0, nullptr, nullptr, err, exact);
+    if (rc) return rc;
+  }
+  if (lf_comm_bcast_blob(cm, stream)) {
+    snprintf(err, 256, "ligero (sharded): broadcast hook failed");
+    return LFGPU_ERR_HIP;
+  }
+  ReplayRng rep{&stream, 0, false};
+  const int rc = ligero_layout_host(field, k, g, p, (const elt_t*)h_W, subfield_boundary, h_lqc, replay_fn, &rep, row_lo, row_hi, H, nonces, err, exact);
+  if (rc) return rc;
+  if (rep.dry || rep.pos != stream.size()) {
+    snprintf(err, 256, "ligero (sharded): the replayed random stream does not match the layout (%zu of %zu bytes)", rep.pos, stream.size());
+    return LFGPU_ERR_ASSERT;
+  }
+  return LFGPU_OK;
+}
+extern "C" int lfgpu_ligero_layout_rows_sharded(int field, int k, const lfgpu_ligero_param* pp, const void* h_W, size_t subfield_boundary,
+                                                const size_t* h_lqc, lfgpu_rng_fn rng, void* user, const lfgpu_comm_ops* cm, void* h_rows,
+                                                uint8_t* h_nonces) {
+  if (!pp || !comm_ok(cm) || (cm->rank == 0 && !rng) || (pp->nw && !h_W) || (pp->nq && !h_lqc)) return LFGPU_ERR_ARG;
+  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128) return LFGPU_ERR_ARG;
+  GfHostCtx g;
+  if (field == LFGPU_FIELD_GF2_128 && !lf_gf_ctx_build(&g, k)) return LFGPU_ERR_ARG;
+  size_t lo, hi;
+  LF_TRY(lfgpu_ligero_row_shard(pp, cm->rank, cm->world, &lo, &hi));
+  if (hi > lo && !h_rows) return LFGPU_ERR_ARG;
+  char err[256] = {0};
+  return layout_sharded_host(field, k, &g, *pp, h_W, subfield_boundary, h_lqc, rng, user, cm, false, lo, hi, (elt_t*)h_rows, h_nonces, err);
+}
+
+extern "C" int lfgpu_ligero_commit_sharded(lfgpu_ctx* c, int field, int k, const lfgpu_ligero_param* pp, const void* h_W, size_t subfield_boundary,
+                                           const size_t* h_lqc, lfgpu_rng_fn rng, void* user, const lfgpu_comm_ops* cm, uint8_t root_out[32],
+                                           lfgpu_ligero_prover** out) {
+  if (!c || !pp || !root_out || !out || !comm_ok(cm) || (cm->rank == 0 && !rng) || (pp->nw && !h_W) || (pp->nq && !h_lqc))
+    return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit_sharded: null argument / incomplete communicator");
+  if (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128) return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit_sharded: field");
+  const lfgpu_ligero_param& p = *pp;
+  if (p.ildt != 0 || p.idot != 1 || p.iquad != 2 || p.iw != 3) return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit_sharded: row order");
+  LF_HIP(c, hipSetDevice(c->device));
+  const GfHostCtx* g = field == LFGPU_FIELD_GF2_128 ? lf_gf_ctx(c, k) : nullptr;
+  if (field == LFGPU_FIELD_GF2_128 && !g) return lf_fail(c, LFGPU_ERR_ARG, "ligero_commit_sharded: k");
+  const int world = cm->world, rank = cm->rank;
+  lfgpu_ligero_prover* pr = new lfgpu_ligero_prover();
+  pr->c = c;
+  pr->field = field;
+  pr->k = k;
+  pr->p = p;
+  pr->d_T = nullptr;
+  pr->d_layers = nullptr;
+  pr->nonces.resize(p.block_ext * 32);
+  pr->sharded = true;
+  pr->comm = *cm;
+  pr->spans.resize(world);
+  for (int q = 0; q < world; ++q) (void)lfgpu_ligero_row_shard(&p, q, world, &pr->spans[q].first, &pr->spans[q].second);
+  pr->row_lo = pr->spans[rank].first;
+  pr->row_hi = pr->spans[rank].second;
+  void* d_send = nullptr;
+  void* d_cols = nullptr;
+  size_t send_bytes_tot = 0, cols_bytes = 0;
+  auto fail = [&](int rc) {
+    if (d_send) lf_pool_put(c, d_send, send_bytes_tot);
+    if (d_cols) lf_pool_put(c, d_cols, cols_bytes);
+    lfgpu_ligero_free(pr);
+    return rc;
+  };
+  const size_t nr = pr->row_hi - pr->row_lo, ld = p.block_enc, ncols = p.block_ext;
+  // 1. host layout of this rank's slab from the one random stream
+  std::vector<elt_t> H(std::max<size_t>(nr, 1) * p.dblock);
+  {
+    char err[256] = {0};
+    const int rc = layout_sharded_host(field, k, g, p, h_W, subfield_boundary, h_lqc, rng, user, cm, c->rng_exact != 0, pr->row_lo, pr->row_hi, H.data(),
+                                       pr->nonces.data(), err);
+    if (rc) return fail(lf_fail(c, rc, "%s", err));
+  }
+  // 2. RS-extend the slab: rows are independent, no collective
+  const size_t tb = std::max<size_t>(nr, 1) * ld * 16, lb = 2 * ncols * 32;
+  if (lf_pool_get(c, tb, (void**)&pr->d_T) != LFGPU_OK) return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit_sharded: slab alloc"));
+  pr->T_bytes = tb;
+  if (lf_pool_get(c, lb, (void**)&pr->d_layers) != LFGPU_OK) return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit_sharded: layers alloc"));
+  pr->L_bytes = lb;
+  int rc = nr ? ligero_encode_slab(c, field, k, p, pr->row_lo, pr->row_hi, H.data(), pr->d_T) : LFGPU_OK;
+  if (rc) return fail(rc);
+  // 3. a leaf hashes ALL rows of one column: one all_to_all re-partitions the encoded columns [dblock, block_enc) so that
+  //    this rank owns columns [mc0, mc0 + mcn) of every row.  Send block for rank q: my rows x its columns, contiguous.
+  std::vector<size_t> soff(world), sbytes(world), roff(world), rbytes(world);
+  size_t mc0 = 0, mcn = 0;
+  shard_split(ncols, rank, world, &mc0, &mcn);
+  for (int q = 0; q < world; ++q) {
+    size_t c0, cn;
+    shard_split(ncols, q, world, &c0, &cn);
+    soff[q] = send_bytes_tot;
+    sbytes[q] = nr * cn * 16;
+    send_bytes_tot += sbytes[q];
+    roff[q] = pr->spans[q].first * mcn * 16;  // slabs are contiguous and ascending: the received blocks ARE the column matrix
+    rbytes[q] = (pr->spans[q].second - pr->spans[q].first) * mcn * 16;
+  }
+  cols_bytes = std::max<size_t>(p.nrow * mcn * 16, 16);
+  send_bytes_tot = std::max<size_t>(send_bytes_tot, 16);
+  if (lf_pool_get(c, send_bytes_tot, &d_send) != LFGPU_OK || lf_pool_get(c, cols_bytes, &d_cols) != LFGPU_OK)
+    return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit_sharded: exchange buffers"));
+  for (int q = 0; q < world && nr; ++q) {
+    size_t c0, cn;
+    shard_split(ncols, q, world, &c0, &cn);
+    if (cn && hipMemcpy2DAsync((uint8_t*)d_send + soff[q], cn * 16, pr->d_T + p.dblock + c0, ld * 16, cn * 16, nr, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+      return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit_sharded: pack"));
+  }
+  if (cm->all_to_all(cm->user, d_send, soff.data(), sbytes.data(), d_cols, roff.data(), rbytes.data(), 1, c->stream))
+    return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit_sharded: all_to_all hook failed"));
+  // 4. local leaves of my columns, all_gather of the digests (ragged: padded to the largest share), the tree on every rank
+  size_t maxn = 0, dummy = 0;
+  shard_split(ncols, 0, world, &dummy, &maxn);
+  void* d_non = nullptr;
+  if ((rc = lf_scratch3(c, ncols * 32 + (size_t)(world + 1) * maxn * 32 + 64, &d_non))) return fail(rc);
+  uint8_t* d_mine = (uint8_t*)d_non + ncols * 32;
+  uint8_t* d_all = d_mine + maxn * 32;
+  if (hipMemcpyAsync(d_non, pr->nonces.data(), ncols * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipMemsetAsync(d_mine, 0, maxn * 32, c->stream) != hipSuccess)
+    return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit_sharded: nonce upload"));
+  if (mcn && (rc = lfgpu_column_leaves(c, field, p.nrow, mcn, 0, mcn, d_cols, (const uint8_t*)d_non + mc0 * 32, d_mine))) return fail(rc);
+  if (cm->all_gather(cm->user, d_mine, d_all, maxn * 32, 1, c->stream)) return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit_sharded: all_gather hook failed"));
+  if (hipMemsetAsync(pr->d_layers, 0, ncols * 32, c->stream) != hipSuccess) return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit_sharded: layers"));
+  for (int q = 0; q < world; ++q) {
+    size_t c0, cn;
+    shard_split(ncols, q, world, &c0, &cn);
+    if (cn && hipMemcpyAsync(pr->d_layers + (ncols + c0) * 32, d_all + (size_t)q * maxn * 32, cn * 32, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+      return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit_sharded: leaves"));
+  }
+  if ((rc = lfgpu_merkle_build_tree(c, ncols, pr->d_layers, root_out))) return fail(rc);
+  lf_pool_put(c, d_send, send_bytes_tot);
+  lf_pool_put(c, d_cols, cols_bytes);
+  *out = pr;
+  return LFGPU_OK;
+}
+
+// host-only check of a caller's hooks
+extern "C" int lfgpu_comm_selftest(const lfgpu_comm_ops* cm) {
+  if (!comm_ok(cm)) return LFGPU_ERR_ARG;
+  const int W = cm->world, r = cm->rank;
+  {  // broadcast from every root
+    for (int root = 0; root < W; ++root) {
+      uint8_t b[37];
+      for (int i = 0; i < 37; ++i) b[i] = (uint8_t)(r == root ? 11 * root + i : 0xEE);
+      if (cm->broadcast(cm->user, b, 37, root, 0, nullptr)) return LFGPU_ERR_HIP;
+      for (int i = 0; i < 37; ++i)
+        if (b[i] != (uint8_t)(11 * root + i)) return LFGPU_ERR_ASSERT;
+    }
+  }
+  {  // all_gather
+    std::vector<uint8_t> mine(53), all((size_t)53 * W);
+    for (int i = 0; i < 53; ++i) mine[i] = (uint8_t)(7 * r + 3 * i);
+    if (cm->all_gather(cm->user, mine.data(), all.data(), 53, 0, nullptr)) return LFGPU_ERR_HIP;
+    for (int q = 0; q < W; ++q)
+      for (int i = 0; i < 53; ++i)
+        if (all[(size_t)53 * q + i] != (uint8_t)(7 * q + 3 * i)) return LFGPU_ERR_ASSERT;
+  }
+  {  // ragged all_to_all: rank p sends 5 + p + 2 q bytes to rank q (zero-length blocks included: p = q = 0 sends 5)
+    std::vector<size_t> so(W), sb(W), ro(W), rb(W);
+    size_t st = 0, rt = 0;
+    for (int q = 0; q < W; ++q) {
+      so[q] = st;
+      sb[q] = (size_t)(5 + r + 2 * q) * ((r + q) % 3 != 2);
+      st += sb[q];
+      ro[q] = rt;
+      rb[q] = (size_t)(5 + q + 2 * r) * ((q + r) % 3 != 2);
+      rt += rb[q];
+    }
+    std::vector<uint8_t> send(st + 1), recv(rt + 1, 0xEE);
+    for (int q = 0; q < W; ++q)
+      for (size_t i = 0; i < sb[q]; ++i) send[so[q] + i] = (uint8_t)(r * 31 + q * 17 + i);
+    if (cm->all_to_all(cm->user, send.data(), so.data(), sb.data(), recv.data(), ro.data(), rb.data(), 0, nullptr)) return LFGPU_ERR_HIP;
+    for (int q = 0; q < W; ++q)
+      for (size_t i = 0; i < rb[q]; ++i)
+        if (recv[ro[q] + i] != (uint8_t)(q * 31 + r * 17 + i)) return LFGPU_ERR_ASSERT;
+  }
+  return LFGPU_OK;
+}
+
 extern "C" int lfgpu_ligero_free(lfgpu_ligero_prover* pr) {
   if (!pr) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = pr->c;
@@ -469,7 +738,8 @@ extern "C" int lfgpu_ligero_low_degree_proof(lfgpu_ligero_prover* pr, const void
   owned_wq_rows(pr, &a_lo, &a_hi);
   if (a_hi > a_lo)
     LF_TRY(lfgpu_rows_axpy(c, pr->field, a_hi - a_lo, p.block, dy, (const uint64_t*)h_u + 2 * a_lo, pr->row(p.iw + a_lo), p.block_enc));
-  return lfgpu_memcpy_d2h(c, h_y, dy, p.block * 16);
+  LF_TRY(lfgpu_memcpy_d2h(c, h_y, dy, p.block * 16));
+  return pr->sharded ? comm_fold(pr, (elt_t*)h_y, p.block) : LFGPU_OK;
 }
 
 // ---- the inner-product matrix built on the device (inner_product_vector + layout_Aext, ligero_param.h:382-430)
@@ -551,7 +821,8 @@ static int dot_proof_finish(lfgpu_ligero_prover* pr, elt_t* dAext, elt_t* dy, vo
   LIG_DISPATCH(pr->field, rows_vaxpy_kernel, dim3((u32)((p.dblock + 63) / 64)), dim3(1024), (u32)(a_hi - a_lo), p.dblock, T0,
                (const elt_t*)(dAext + a_lo * lda), lda, (const elt_t*)(a_hi > a_lo ? pr->row(p.iw + a_lo) : pr->d_T), p.block_enc, dy);
   LF_HIP(c, hipGetLastError());
-  return lfgpu_memcpy_d2h(c, h_y, dy, p.dblock * 16);
+  LF_TRY(lfgpu_memcpy_d2h(c, h_y, dy, p.dblock * 16));
+  return pr->sharded ? comm_fold(pr, (elt_t*)h_y, p.dblock) : LFGPU_OK;
 }
 
 extern "C" int lfgpu_ligero_dot_proof(lfgpu_ligero_prover* pr, const void* h_A, void* h_y) {
@@ -625,7 +896,8 @@ extern "C" int lfgpu_ligero_quadratic_proof(lfgpu_ligero_prover* pr, const void*
   LF_HIP(c, hipGetLastError());
   std::vector<elt_t> y(p.dblock);
   LF_TRY(lfgpu_memcpy_d2h(c, y.data(), dy, p.dblock * 16));
-  if (pr->row_lo == 0 && pr->row_hi == p.nrow)  // sanity check of the reference (:335-337); partial sums are checked after the fold
+  if (pr->sharded) LF_TRY(comm_fold(pr, y.data(), p.dblock));
+  if (pr->sharded || (pr->row_lo == 0 && pr->row_hi == p.nrow))  // sanity check of the reference (:335-337); a bare slab's partial sums are checked by its caller after the fold
     for (size_t j = 0; j < p.w; ++j)
       if (y[p.r + j].lo | y[p.r + j].hi) return lf_fail(c, LFGPU_ERR_ASSERT, "quadratic_proof: W part is nonzero");
   memcpy(h_y0, y.data(), p.r * 16);
@@ -663,13 +935,27 @@ extern "C" int lfgpu_ligero_open(lfgpu_ligero_prover* pr, const size_t* idx, voi
   for (size_t i = 0; i < p.nreq; ++i)
     if (idx[i] >= p.block_ext) return lf_fail(c, LFGPU_ERR_ARG, "ligero_open: index out of range");
   if (pr->nonces.size() != 32 * p.block_ext || !pr->d_layers) return lf_fail(c, LFGPU_ERR_ARG, "ligero_open: this prover holds no commitment");
-  // a slab returns its own rows of req ((row_hi - row_lo) x nreq, in row order)
+  // a slab returns its own rows of req ((row_hi - row_lo) x nreq, in row order); a sharded prover gathers every rank's rows
   const size_t nr = pr->row_hi - pr->row_lo;
+  std::vector<uint8_t> mine;
+  size_t maxr = nr;
+  if (pr->sharded) {
+    for (const auto& sp : pr->spans) maxr = std::max(maxr, sp.second - sp.first);
+    mine.assign(maxr * p.nreq * 16, 0);
+  }
+  void* h_dst = pr->sharded ? (void*)mine.data() : h_req;
   if (nr) {
     void* dreq = nullptr;
     LF_TRY(lf_scratch3(c, nr * p.nreq * 16, &dreq));
     LF_TRY(lfgpu_gather_columns(c, nr, p.block_enc, p.dblock, pr->d_T, idx, p.nreq, dreq));
-    LF_TRY(lfgpu_memcpy_d2h(c, h_req, dreq, nr * p.nreq * 16));
+    LF_TRY(lfgpu_memcpy_d2h(c, h_dst, dreq, nr * p.nreq * 16));
+  }
+  if (pr->sharded) {
+    const lfgpu_comm_ops& cm = pr->comm;
+    std::vector<uint8_t> all((size_t)cm.world * mine.size());
+    if (cm.all_gather(cm.user, mine.data(), all.data(), mine.size(), 0, nullptr)) return lf_fail(c, LFGPU_ERR_HIP, "ligero_open (sharded): all_gather hook failed");
+    for (int q = 0; q < cm.world; ++q)
+      memcpy((uint8_t*)h_req + pr->spans[q].first * p.nreq * 16, all.data() + (size_t)q * mine.size(), (pr->spans[q].second - pr->spans[q].first) * p.nreq * 16);
   }
   for (size_t i = 0; i < p.nreq; ++i) memcpy(h_nonces + 32 * i, &pr->nonces[32 * idx[i]], 32);
   return lfgpu_merkle_open(c, p.block_ext, pr->d_layers, idx, p.nreq, h_path, path_cap, npath);

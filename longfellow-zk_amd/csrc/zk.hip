@@ -374,6 +374,11 @@ struct lfgpu_zk_prover {
   void* d_V = nullptr;
   void* h_V = nullptr;  // pinned: outputs (nv elements) then the assert-zero flag, read back without blocking the host
   double ms[6] = {0, 0, 0, 0, 0, 0};
+  // lfgpu_zk_prover_set_comm: Ligero tableaux of at least comm_min_bytes are committed with their rows sharded over the
+  // communicator's GPUs (lfgpu_ligero_commit_sharded); everything else -- and the whole sumcheck -- runs replicated
+  bool have_comm = false;
+  lfgpu_comm_ops comm{};
+  size_t comm_min_bytes = 0;
   ~lfgpu_zk_prover() {
     if (z256) zk256_free(z256);
     if (lp) lfgpu_ligero_free(lp);
@@ -651,6 +656,20 @@ extern "C" int lfgpu_zk_prover_new(lfgpu_ctx* c, const lfgpu_circuit* C, size_t 
   return LFGPU_OK;
 }
 
+extern "C" int lfgpu_zk_prover_set_comm(lfgpu_zk_prover* zk, const lfgpu_comm_ops* comm, size_t min_tableau_bytes) {
+  if (!zk) return LFGPU_ERR_ARG;
+  if (zk->z256) return lf_fail(zk->c, LFGPU_ERR_UNSUPPORTED, "zk_prover_set_comm: Fp256Base provers run as replicas (their tableaux are a few MB: lfgpu_zk_throughput mode)");
+  if (!comm) {
+    zk->have_comm = false;
+    return LFGPU_OK;
+  }
+  if (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world || !comm->all_gather || !comm->all_to_all || !comm->broadcast)
+    return lf_fail(zk->c, LFGPU_ERR_ARG, "zk_prover_set_comm: incomplete communicator");
+  zk->have_comm = true;
+  zk->comm = *comm;
+  zk->comm_min_bytes = min_tableau_bytes;
+  return LFGPU_OK;
+}
 extern "C" int lfgpu_zk_prover_param(const lfgpu_zk_prover* zk, lfgpu_ligero_param* p) {
   if (!zk || !p) return LFGPU_ERR_ARG;
   if (zk->z256) return zk256_param(zk->z256, p);
@@ -668,6 +687,22 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
   const size_t nl = C->layers.size();
   const int field = C->info.field;
   const HostField F(c, field);
+  // More than one rank (lfgpu_zk_prover_set_comm): every rank runs this function with the same arguments, but there is ONE
+  // RandomEngine -- rank 0's.  Its pad draws are recorded and broadcast, the other ranks replay them (the Ligero commit does
+  // the same for its own draws), so all ranks hold the same pads, the same commitment and, with their own copies of the
+  // transcript, the same proof.
+  const bool multi = zk->have_comm && zk->comm.world > 1;
+  const bool shard_rows = multi && zk->param.nrow * zk->param.block_enc * 16 >= zk->comm_min_bytes;
+  std::vector<uint8_t> pad_stream;
+  alignas(16) unsigned char rng_store[64];
+  if (multi) {
+    if (zk->comm.rank == 0) {
+      lf_record_rng(rng, rng_user, &pad_stream, &rng, &rng_user, rng_store);
+    } else {
+      if (lf_comm_bcast_blob(&zk->comm, pad_stream)) return lf_fail(c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
+      lf_replay_rng(&pad_stream, &rng, &rng_user, rng_store);
+    }
+  }
   auto draw = [&]() {  // RandomEngine::elt = Field::sample
     return elt_sample(field, [&](uint8_t* b, size_t n) { rng(rng_user, b, n); });
   };
@@ -710,7 +745,25 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
   }
   zk->have_proof = false;
   zk->wire_valid = false;
-  LF_TRY(lfgpu_ligero_commit(c, field, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), rng, rng_user, zk->root, &zk->lp));
+  if (multi && zk->comm.rank == 0 && lf_comm_bcast_blob(&zk->comm, pad_stream)) return lf_fail(c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
+  if (shard_rows) {
+    LF_TRY(lfgpu_ligero_commit_sharded(c, field, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), rng, rng_user, &zk->comm, zk->root, &zk->lp));
+  } else if (multi) {  // a small tableau stays whole on every rank (replicas): the one random stream still comes from rank 0
+    lfgpu_comm_ops one = zk->comm;
+    std::vector<uint8_t> lig_stream;
+    alignas(16) unsigned char st2[64];
+    lfgpu_rng_fn r2 = rng;
+    void* u2 = rng_user;
+    if (zk->comm.rank == 0) lf_record_rng(rng, rng_user, &lig_stream, &r2, &u2, st2);
+    else {
+      if (lf_comm_bcast_blob(&one, lig_stream)) return lf_fail(c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
+      lf_replay_rng(&lig_stream, &r2, &u2, st2);
+    }
+    LF_TRY(lfgpu_ligero_commit(c, field, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), r2, u2, zk->root, &zk->lp));
+    if (zk->comm.rank == 0 && lf_comm_bcast_blob(&one, lig_stream)) return lf_fail(c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
+  } else {
+    LF_TRY(lfgpu_ligero_commit(c, field, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), rng, rng_user, zk->root, &zk->lp));
+  }
   ts->write_bytes(ts->user, zk->root, 32);  // LigeroTranscript::write_commitment
   if (root_out) memcpy(root_out, zk->root, 32);
   zk->ms[0] = now_ms() - t0;

@@ -1,36 +1,30 @@
-"""Multi-GPU composition of the hot path: one process per GPU, torch.distributed
-(backend "nccl" = RCCL over xGMI on the GPU node; "gloo" in the CPU tests and in the
-single-box GPU rehearsal, where tensors are staged through host memory).
+"""Multi-GPU use of the hot path from Python: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+the GPU node; "gloo" in the CPU tests and in the one-GPU rehearsal, where device buffers are staged through host memory).
+
+The orchestration itself is C++ behind the C ABI (include/lfgpu.h: lfgpu_ligero_commit_sharded and the prove entry points,
+include/lfgpu_zk.h: lfgpu_zk_prover_set_comm); what this module adds is the BINDING of the library's three transport hooks
+(lfgpu_comm_ops: all_gather, all_to_all, broadcast -- the way the transcript and the RandomEngine are hooks) to
+torch.distributed, and thin wrappers.  A C++ caller binds the same hooks to RCCL directly.
 
 What shards and what is exchanged (reference lib/ligero/ligero_prover.h:58-79,171-270,
 lib/merkle/merkle_commitment.h:50-64):
   * FFT / RS row encode: rows are independent -> contiguous row slabs per rank, no collective.
-  * RandomEngine draws: sequential by definition (one engine, fixed order).  Rank 0 draws the whole
-    stream of LigeroProver::commit once (host only) and broadcasts the bytes; every rank replays them
-    through the library's host layout (lfgpu_ligero_layout_rows) and keeps its slab.
-  * Merkle column commit: a leaf hashes ALL rows of one column in order, so the encoded slab is
-    re-partitioned by columns with one all_to_all (each rank then owns block_ext/N columns x all
-    rows), leaves are hashed locally (column_leaves_kernel), the 32-byte digests are all_gathered and
-    every rank builds the (small) tree -> identical root on every rank.  SHA-256 is not a reduction,
-    so there is no "all-reduce of roots".
-  * Ligero prove (low-degree / dot / quadratic rows): y = sum over rows -> each rank combines the
-    rows of its slab, the partial vectors are all_gathered and folded with the FIELD's addition
-    (RCCL has no XOR / mod-p reduce op); opened columns are gathered slab by slab.
-  * sumcheck round: each rank sums its index range; the (a0, a2) pairs are all_gathered and folded.
+  * RandomEngine draws: sequential by definition.  Rank 0 draws the whole stream of LigeroProver::commit once and
+    broadcasts the bytes; every rank replays them through the library's host layout and keeps its slab.
+  * Merkle column commit: a leaf hashes ALL rows of one column, so the encoded slab is re-partitioned by columns with ONE
+    all_to_all, leaves are hashed locally, the 32-byte digests are all_gathered and every rank builds the (small) tree ->
+    identical root on every rank.  SHA-256 is not a reduction: there is no "all-reduce of roots".
+  * Ligero prove: each rank combines the rows of its slab, the partial vectors are all_gathered and folded with the FIELD's
+    addition (RCCL has no XOR / mod-p reduce op); opened columns are gathered slab by slab.
+  * sumcheck: replicated (see DESIGN.md section 6 for why the index-range split is not built).
 
-Bytes per collective (nrow rows, block_enc = ld, block_ext = ld - dblock leaves, N ranks, 16-byte elements):
-  broadcast of the random stream   16 (block + 2 dblock + r nwqrow) + 32 block_ext          (host -> all, once)
-  all_to_all column re-partition   each rank sends (nrow/N) x (block_ext/N) x 16 to every peer:
-                                   total on the wire nrow block_ext 16 (N-1)/N; per xGMI link and direction
-                                   nrow block_ext 16 / N^2  (S-lig: 11.5 GB total, 179 MB per link at N = 8)
-  all_gather of leaf digests       32 block_ext per rank received (S-lig: 22 MB)
-  prove partial vectors            16 (block + 2 dblock) per rank, all_gather
-  sumcheck partials                32 bytes per rank and round-hand
-
-The orchestration below is the product path: compute goes through an *engine* whose methods are the
-C-ABI entry points (GpuEngine: HIP kernels).  The gloo CPU tests run the SAME functions with an
-engine backed by the oracle (defined in tests/, never imported here).
+Bytes per collective (nrow rows, block_ext leaves, N ranks, 16-byte elements):
+  broadcast of the random stream   16 (block + 2 dblock + r nwqrow) + 32 block_ext          (host, once)
+  all_to_all column re-partition   nrow block_ext 16 (N-1)/N on the wire; per xGMI link and direction nrow block_ext 16 / N^2
+  all_gather of leaf digests       32 block_ext received per rank
+  prove partial vectors            16 (block + 2 dblock) per rank
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -38,6 +32,17 @@ import torch
 import torch.distributed as dist
 
 FP128_P = 2**128 - 2**108 + 1
+
+_vp, _sz, _ci = C.c_void_p, C.c_size_t, C.c_int
+_psz = C.POINTER(C.c_size_t)
+AG_FN = C.CFUNCTYPE(_ci, _vp, _vp, _vp, _sz, _ci, _vp)
+A2A_FN = C.CFUNCTYPE(_ci, _vp, _vp, _psz, _psz, _vp, _psz, _psz, _ci, _vp)
+BC_FN = C.CFUNCTYPE(_ci, _vp, _vp, _sz, _ci, _ci, _vp)
+
+
+class CommOps(C.Structure):
+    """lfgpu_comm_ops (include/lfgpu.h)"""
+    _fields_ = [("user", _vp), ("rank", _ci), ("world", _ci), ("all_gather", AG_FN), ("all_to_all", A2A_FN), ("broadcast", BC_FN)]
 
 
 def row_shard(nrows, rank, world):
@@ -51,6 +56,16 @@ def col_shard(ncols, rank, world):
     return row_shard(ncols, rank, world)
 
 
+def ligero_row_shard(p, rank, world):
+    """lfgpu_ligero_row_shard: row slab [lo, hi) of a Ligero tableau for `rank` (the quadratic rows all on the last rank)"""
+    from . import load_library
+    lo, hi = C.c_size_t(), C.c_size_t()
+    rc = load_library().lfgpu_ligero_row_shard(C.byref(p), rank, world, C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise RuntimeError("lfgpu_ligero_row_shard failed with code %d" % rc)
+    return lo.value, hi.value
+
+
 def field_add(field, a, b):
     """a, b: (lo, hi) u64 pairs.  GF(2^128): XOR; Fp128 (Montgomery images are additive): mod p."""
     if field == 4:
@@ -59,59 +74,140 @@ def field_add(field, a, b):
     return (s & (2**64 - 1), s >> 64)
 
 
-# ------------------------------------------------------------------ transport
-def _is_gloo(group):
-    return dist.get_backend(group) == "gloo"
+class _DevMem:
+    """a raw device pointer as a CUDA-array-interface object (zero-copy torch view)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 3, "strides": None}
 
 
-def _all_to_all(recv, send, group):
-    """list form of all_to_all on device tensors; gloo (no all_to_all, no device tensors): pairwise send/recv on
-    host copies"""
-    if not _is_gloo(group):
-        dist.all_to_all(recv, send, group=group)
-        return
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    hs = [t.cpu() for t in send]
-    hr = [torch.empty(t.shape, dtype=t.dtype) for t in recv]
-    hr[rank].copy_(hs[rank])
-    reqs = []
-    for q in range(world):
-        if q != rank:
-            reqs.append(dist.isend(hs[q], q, group=group))
-            reqs.append(dist.irecv(hr[q], q, group=group))
-    for r in reqs:
-        r.wait()
-    for t, h in zip(recv, hr):
-        t.copy_(h)
+class TorchComm:
+    """The library's transport hooks over a torch.distributed process group.  nccl (= RCCL): device buffers go into the
+    collectives as they are, host buffers are staged through a device tensor; gloo: device buffers are staged through host
+    memory (the one-GPU rehearsal and the CPU tests)."""
 
+    def __init__(self, group=None, device=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.gloo = dist.get_backend(group) == "gloo"
+        self.device = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
+        self.error = None
+        self._ag, self._a2a, self._bc = AG_FN(self._all_gather), A2A_FN(self._all_to_all), BC_FN(self._broadcast)
+        self.ops = CommOps(None, self.rank, self.world, self._ag, self._a2a, self._bc)
 
-def _all_gather(out_list, t, group):
-    if not _is_gloo(group) or t.device.type == "cpu":
-        dist.all_gather(out_list, t, group=group)
-        return
-    ho = [torch.empty(o.shape, dtype=o.dtype) for o in out_list]
-    dist.all_gather(ho, t.cpu(), group=group)
-    for o, h in zip(out_list, ho):
-        o.copy_(h)
+    # -- views of the library's buffers
+    def _view(self, ptr, nbytes, on_device):
+        if nbytes == 0 or not ptr:
+            return torch.empty(0, dtype=torch.uint8, device=self.device if on_device else "cpu")
+        if on_device:
+            return torch.as_tensor(_DevMem(ptr, nbytes), device=self.device)
+        return torch.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=torch.uint8)
 
+    def _on(self, stream):
+        """order after the work queued on the library's stream (it is usually torch's current one already)"""
+        if stream and self.device is not None and self.device.type == "cuda":
+            return torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=self.device))
+        return contextlib.nullcontext()
 
-def _broadcast_bytes(data, src, group):
-    """bytes on `src` -> the same bytes on every rank (length first)"""
-    rank = dist.get_rank(group)
-    n = torch.tensor([len(data) if rank == src else 0], dtype=torch.int64)
-    dev = None if _is_gloo(group) else torch.device("cuda", torch.cuda.current_device())
-    if dev is not None:
-        n = n.to(dev)
-    dist.broadcast(n, src, group=group)
-    size = int(n.item())
-    if rank == src:
-        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8)
-    else:
-        buf = torch.empty(size, dtype=torch.uint8)
-    if dev is not None:
-        buf = buf.to(dev)
-    dist.broadcast(buf, src, group=group)
-    return bytes(buf.cpu().numpy().tobytes())
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as e:  # noqa: BLE001 -- a hook must not raise through the C frames above it
+            import traceback
+            self.error = "%r\n%s" % (e, traceback.format_exc())
+            return 1
+
+    # -- hooks
+    def _all_gather(self, _user, send, recv, nbytes, on_device, stream):
+        def run():
+            with self._on(stream):
+                s, r = self._view(send, nbytes, on_device), self._view(recv, nbytes * self.world, on_device)
+                if self.world == 1:
+                    r.copy_(s)
+                elif self.gloo or not on_device:
+                    if self.gloo:
+                        hs = s.cpu() if on_device else s
+                        parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+                        dist.all_gather(parts, hs.contiguous(), group=self.group)
+                        r.copy_(torch.cat(parts))
+                    else:  # nccl, host buffers: through device tensors
+                        ds = s.to(self.device)
+                        dr = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
+                        dist.all_gather_into_tensor(dr, ds, group=self.group)
+                        r.copy_(dr.cpu())
+                else:
+                    dist.all_gather_into_tensor(r, s, group=self.group)
+                if on_device and self.device is not None and self.device.type == "cuda":
+                    torch.cuda.current_stream().synchronize()
+        return self._guard(run)
+
+    def _all_to_all(self, _user, send, soff, sbytes, recv, roff, rbytes, on_device, stream):
+        def run():
+            W, me = self.world, self.rank
+            so, sb = [soff[q] for q in range(W)], [sbytes[q] for q in range(W)]
+            ro, rb = [roff[q] for q in range(W)], [rbytes[q] for q in range(W)]
+            with self._on(stream):
+                s = self._view(send, max(o + b for o, b in zip(so, sb)), on_device)
+                r = self._view(recv, max(o + b for o, b in zip(ro, rb)), on_device)
+                sl = [s[so[q]:so[q] + sb[q]] for q in range(W)]
+                rl = [r[ro[q]:ro[q] + rb[q]] for q in range(W)]
+                if W == 1:
+                    rl[0].copy_(sl[0])
+                elif self.gloo:  # no all_to_all, no device tensors: pairwise send / recv on host copies
+                    hs = [t.cpu().contiguous() for t in sl]
+                    hr = [torch.empty(rb[q], dtype=torch.uint8) for q in range(W)]
+                    hr[me].copy_(hs[me])
+                    reqs = []
+                    for q in range(W):
+                        if q != me:
+                            if sb[q]:
+                                reqs.append(dist.isend(hs[q], q, group=self.group))
+                            if rb[q]:
+                                reqs.append(dist.irecv(hr[q], q, group=self.group))
+                    for w in reqs:
+                        w.wait()
+                    for t, h in zip(rl, hr):
+                        t.copy_(h)
+                else:
+                    if on_device:
+                        dist.all_to_all(rl, [t.contiguous() for t in sl], group=self.group)
+                    else:
+                        dr = [torch.empty(rb[q], dtype=torch.uint8, device=self.device) for q in range(W)]
+                        dist.all_to_all(dr, [t.to(self.device) for t in sl], group=self.group)
+                        for t, d in zip(rl, dr):
+                            t.copy_(d.cpu())
+                if on_device and self.device is not None and self.device.type == "cuda":
+                    torch.cuda.current_stream().synchronize()
+        return self._guard(run)
+
+    def _broadcast(self, _user, buf, nbytes, root, on_device, stream):
+        def run():
+            with self._on(stream):
+                b = self._view(buf, nbytes, on_device)
+                if self.world == 1:
+                    return
+                src = dist.get_global_rank(self.group, root) if self.group is not None else root
+                if self.gloo:
+                    h = b.cpu().contiguous() if on_device else b
+                    dist.broadcast(h, src, group=self.group)
+                    if on_device:
+                        b.copy_(h)
+                elif on_device:
+                    dist.broadcast(b, src, group=self.group)
+                    torch.cuda.current_stream().synchronize()
+                else:
+                    d = b.to(self.device)
+                    dist.broadcast(d, src, group=self.group)
+                    b.copy_(d.cpu())
+        return self._guard(run)
+
+    def selftest(self):
+        """lfgpu_comm_selftest: every hook with host buffers (ragged all_to_all, every broadcast root)"""
+        from . import load_library
+        rc = load_library().lfgpu_comm_selftest(C.byref(self.ops))
+        if rc != 0:
+            raise RuntimeError("lfgpu_comm_selftest failed with code %d: %s" % (rc, self.error))
 
 
 # ------------------------------------------------------------------ sumcheck partial sums
@@ -124,7 +220,12 @@ def allgather_fold_partials(field, a0, a2, group=None, device="cpu"):
 
     mine = torch.tensor([enc(a0[0]), enc(a0[1]), enc(a2[0]), enc(a2[1])], dtype=torch.int64, device=device)
     allp = [torch.empty_like(mine) for _ in range(world)]
-    _all_gather(allp, mine, group)
+    if dist.get_backend(group) == "gloo" and mine.device.type != "cpu":
+        hp = [torch.empty(4, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(hp, mine.cpu(), group=group)
+        allp = hp
+    else:
+        dist.all_gather(allp, mine, group=group)
     s0, s2 = (0, 0), (0, 0)
     for t in allp:
         v = [int(x) & (2**64 - 1) for x in t.cpu().tolist()]
@@ -133,69 +234,20 @@ def allgather_fold_partials(field, a0, a2, group=None, device="cpu"):
     return s0, s2
 
 
-# ------------------------------------------------------------------ engines
-class GpuEngine:
-    """This rank's MI355X through the C ABI (include/lfgpu.h): every method is a HIP kernel path of liblfgpu.so.
-    Tensors are flat uint8 device tensors; torch only owns the memory."""
-
-    def __init__(self, gpu, field, subfield_log_bits=4, device=None):
-        self.gpu, self.field, self.k = gpu, field, subfield_log_bits
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-
-    def encode_rows(self, p, row_lo, row_hi, h_rows):
-        """lfgpu_ligero_encode_rows: un-encoded slab image (numpy uint64 [nr][dblock][2]) -> device [nr, block_enc*16]"""
-        nr = row_hi - row_lo
-        slab = torch.empty((nr, p.block_enc * 16), dtype=torch.uint8, device=self.device)
-        if nr:
-            h_rows = np.ascontiguousarray(h_rows)
-            self.gpu._ck(self.gpu.L.lfgpu_ligero_encode_rows(self.gpu.h, self.field, self.k, C.byref(p), row_lo, row_hi,
-                                                             C.c_void_p(h_rows.ctypes.data), C.c_void_p(slab.data_ptr())))
-        return slab
-
-    def column_leaves(self, nrow, cols, nonces):
-        """lfgpu_column_leaves on a [nrow, ncols*16] column block -> [ncols, 32] digests"""
-        ncols = cols.shape[1] // 16
-        out = torch.empty((ncols, 32), dtype=torch.uint8, device=self.device)
-        if ncols:
-            nz = nonces.to(self.device).contiguous()
-            self.gpu._ck(self.gpu.L.lfgpu_column_leaves(self.gpu.h, self.field, nrow, ncols, 0, ncols, C.c_void_p(cols.data_ptr()),
-                                                        C.c_void_p(nz.data_ptr()), C.c_void_p(out.data_ptr())))
-            self.gpu.sync()  # nz may be a temporary
-        return out
-
-    def build_tree(self, leaves):
-        """lfgpu_merkle_build_tree: [n, 32] leaves -> (root bytes, heap layers tensor [2n, 32])"""
-        n = leaves.shape[0]
-        layers = torch.zeros((2 * n, 32), dtype=torch.uint8, device=self.device)
-        layers[n:] = leaves
-        return self.gpu.merkle_build_tree(n, layers.data_ptr()), layers
-
-    def merkle_open(self, n, layers, idx):
-        """lfgpu_merkle_open: compressed opening of the leaves idx -> list of 32-byte digests"""
-        return self.gpu.merkle_open(n, layers.data_ptr(), list(idx))
-
-    def slab_prover(self, p, row_lo, row_hi, slab, layers, nonces):
-        """lfgpu_ligero_prover_from_slab: the prove entry points on this rank's rows (partial sums)"""
-        from . import LigeroProver
-        pr = LigeroProver(self.gpu, self.field, p, self.k)
-        h = C.c_void_p()
-        nz = (C.c_uint8 * len(nonces)).from_buffer_copy(nonces)
-        self.gpu._ck(self.gpu.L.lfgpu_ligero_prover_from_slab(self.gpu.h, self.field, self.k, C.byref(p), row_lo, row_hi,
-                                                              C.c_void_p(slab.data_ptr()), C.c_void_p(layers.data_ptr()), nz, C.byref(h)))
-        pr.h = h
-        pr.rows = row_hi - row_lo
-        return pr
-
-
-def layout_rows(lib, field, k, p, W, subfield_boundary, lqc, rng_bytes, row_lo, row_hi, want_nonces=True):
-    """lfgpu_ligero_layout_rows (host only, no device): all RandomEngine draws of LigeroProver::commit in the reference's
-    order; returns (numpy uint64 [row_hi-row_lo][dblock][2], nonces bytes or None)"""
+# ------------------------------------------------------------------ host layout
+def _rng_cb(rng_bytes):
     from . import RNG_FN
 
     def cb(_user, buf, n):
         C.memmove(buf, rng_bytes(n), n)
 
-    fn = RNG_FN(cb)
+    return RNG_FN(cb)
+
+
+def layout_rows(lib, field, k, p, W, subfield_boundary, lqc, rng_bytes, row_lo, row_hi, want_nonces=True):
+    """lfgpu_ligero_layout_rows (host only, no device): all RandomEngine draws of LigeroProver::commit in the reference's
+    order; returns (numpy uint64 [row_hi-row_lo][dblock][2], nonces bytes or None)"""
+    fn = _rng_cb(rng_bytes)
     W = np.ascontiguousarray(W, dtype=np.uint64)
     rows = np.zeros((row_hi - row_lo, p.dblock, 2), dtype=np.uint64)
     nonces = (C.c_uint8 * (32 * p.block_ext))() if want_nonces else None
@@ -207,150 +259,64 @@ def layout_rows(lib, field, k, p, W, subfield_boundary, lqc, rng_bytes, row_lo, 
     return rows, (bytes(nonces) if want_nonces else None)
 
 
-class _Replay:
-    """a recorded RandomEngine byte stream"""
-
-    def __init__(self, data):
-        self.data, self.pos = data, 0
-
-    def bytes(self, n):
-        if self.pos + n > len(self.data):
-            raise RuntimeError("replayed random stream exhausted")
-        b = self.data[self.pos:self.pos + n]
-        self.pos += n
-        return b
-
-
-# ------------------------------------------------------------------ column commit
-def sharded_column_commit(engine, slab, spans, ld, col0, ncols, nonces, group=None):
-    """`slab`: this rank's encoded rows, uint8 tensor [my_rows, ld*16]; spans[q] = (row_lo, row_hi) of rank q
-    (contiguous, ascending; an int means an even row_shard of that many rows).
-    nonces: uint8 tensor [ncols, 32], identical on every rank.  Returns (root, layers) -- same bytes on every rank."""
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if isinstance(spans, int):
-        spans = [(lo, lo + n) for lo, n in (row_shard(spans, q, world) for q in range(world))]
-    nrow_total = spans[-1][1]
-    my_rows = slab.shape[0]
-    # 1. re-partition by columns: send to rank q the columns it owns, for my rows
-    send, recv = [], []
-    for q in range(world):
-        c0, cn = col_shard(ncols, q, world)
-        send.append(slab[:, (col0 + c0) * 16:(col0 + c0 + cn) * 16].contiguous())
-    mc0, mcn = col_shard(ncols, rank, world)
-    for q in range(world):
-        recv.append(torch.empty((spans[q][1] - spans[q][0], mcn * 16), dtype=torch.uint8, device=slab.device))
-    assert send[rank].shape == recv[rank].shape and my_rows == recv[rank].shape[0]
-    _all_to_all(recv, send, group)
-    cols = torch.cat(recv, dim=0)  # [nrow_total, mycols*16], rows in global order (slabs are contiguous)
-    # 2. local leaves
-    my_leaves = engine.column_leaves(nrow_total, cols, nonces[mc0:mc0 + mcn])
-    # 3. all_gather digests (ragged: pad to the largest shard)
-    maxn = col_shard(ncols, 0, world)[1]
-    pad = torch.zeros((maxn, 32), dtype=torch.uint8, device=slab.device)
-    pad[:mcn] = my_leaves
-    gathered = [torch.empty_like(pad) for _ in range(world)]
-    _all_gather(gathered, pad, group)
-    leaves = torch.cat([gathered[q][:col_shard(ncols, q, world)[1]] for q in range(world)], dim=0)
-    # 4. the tree, on every rank
-    return engine.build_tree(leaves)
+def layout_rows_sharded(lib, field, k, p, W, subfield_boundary, lqc, rng_bytes, comm):
+    """lfgpu_ligero_layout_rows_sharded (host only): rank 0 draws, the stream is broadcast through `comm`, every rank keeps
+    its slab -> (numpy uint64 [my rows][dblock][2], nonces bytes)"""
+    fn = _rng_cb(rng_bytes if comm.rank == 0 else (lambda n: b"\x00" * n))
+    W = np.ascontiguousarray(W, dtype=np.uint64)
+    lo, hi = ligero_row_shard(p, comm.rank, comm.world)
+    rows = np.zeros((hi - lo, p.dblock, 2), dtype=np.uint64)
+    nonces = (C.c_uint8 * (32 * p.block_ext))()
+    lq = (C.c_size_t * max(1, 3 * p.nq))(*[int(x) for x in np.asarray(lqc, dtype=np.uint64).reshape(-1)]) if p.nq else None
+    rc = lib.lfgpu_ligero_layout_rows_sharded(field, k, C.byref(p), C.c_void_p(W.ctypes.data) if W.size else None, subfield_boundary, lq, fn, None,
+                                              C.byref(comm.ops), C.c_void_p(rows.ctypes.data) if rows.size else None, nonces)
+    if rc != 0:
+        raise RuntimeError("lfgpu_ligero_layout_rows_sharded failed with code %d: %s" % (rc, comm.error))
+    return rows, bytes(nonces)
 
 
-def ligero_row_shard(p, rank, world):
-    """row slab [lo, hi) of a Ligero tableau for `rank`: an even split of the rows, except that the quadratic rows
-    [iq, nrow) all go to the last rank (x_i, y_i, z_i of a triple are multiplied element-wise; in the ZK use there are
-    3 * ceil(nl / w) of them -- a handful)"""
-    lo, cnt = row_shard(p.nrow, rank, world)
-    hi = lo + cnt
-    if rank == world - 1:
-        return min(lo, p.iq), p.nrow
-    return min(lo, p.iq), min(hi, p.iq)
-
-
+# ------------------------------------------------------------------ the sharded prover
 class ShardedLigeroProver:
-    """LigeroProver<Field, InterpolatorFactory> (reference lib/ligero/ligero_prover.h:34-359) with the tableau rows
-    sharded over the ranks of `group`.  Every rank calls every method with the same arguments (SPMD); `rng_bytes` is
-    only used on rank 0.  Results (root, y vectors, opened columns) are identical on every rank and identical to the
-    single-GPU LigeroProver fed the same RandomEngine stream."""
+    """LigeroProver<Field, InterpolatorFactory> (reference lib/ligero/ligero_prover.h:34-359) with the tableau rows sharded
+    over the ranks of `group`: lfgpu_ligero_commit_sharded, then the ordinary prove entry points (which fold the ranks'
+    partial vectors inside the library).  Every rank calls every method with the same arguments (SPMD); `rng_bytes` is only
+    used on rank 0.  Results (root, y vectors, opened columns, Merkle path) are identical on every rank and identical to the
+    one-GPU LigeroProver fed the same RandomEngine stream."""
 
-    def __init__(self, engine, lib, field, param, subfield_log_bits=4, group=None):
-        self.e, self.lib, self.field, self.p, self.k, self.group = engine, lib, field, param, subfield_log_bits, group
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+    def __init__(self, gpu, field, param, subfield_log_bits=4, group=None, comm=None):
+        from . import LigeroProver
+        self.gpu, self.field, self.p, self.k = gpu, field, param, subfield_log_bits
+        self.comm = comm if comm is not None else TorchComm(group)
+        self.world, self.rank = self.comm.world, self.comm.rank
         self.spans = [ligero_row_shard(param, q, self.world) for q in range(self.world)]
-        self.row_lo, self.row_hi = self.spans[self.rank]
-        self.pr = None
+        self.pr = LigeroProver(gpu, field, param, subfield_log_bits)
 
     def commit(self, W, subfield_boundary, lqc, rng_bytes):
         """LigeroProver::commit (:58-79) without ts.write -> 32-byte root"""
-        p = self.p
-        # the RandomEngine is one sequential stream: rank 0 draws all of it (layout with an empty slab), everyone replays
-        stream = b""
-        if self.rank == 0:
-            rec = bytearray()
-
-            def tap(n):
-                b = rng_bytes(n)
-                rec.extend(b)
-                return b
-
-            layout_rows(self.lib, self.field, self.k, p, W, subfield_boundary, lqc, tap, 0, 0, want_nonces=False)
-            stream = bytes(rec)
-        if self.world > 1:
-            stream = _broadcast_bytes(stream, 0, self.group)
-        rep = _Replay(stream)
-        h_rows, nonces = layout_rows(self.lib, self.field, self.k, p, W, subfield_boundary, lqc, rep.bytes, self.row_lo, self.row_hi)
-        self.nonces = nonces
-        self.slab = self.e.encode_rows(p, self.row_lo, self.row_hi, h_rows)
-        nz = torch.frombuffer(bytearray(nonces), dtype=torch.uint8).reshape(p.block_ext, 32)
-        self.root, self.layers = sharded_column_commit(self.e, self.slab, self.spans, p.block_enc, p.dblock, p.block_ext, nz, self.group)
-        self.pr = self.e.slab_prover(p, self.row_lo, self.row_hi, self.slab, self.layers, nonces)
-        return self.root
-
-    # -- prove side: y = T[special row] + sum over the witness / quadratic rows: partial over the slab, all_gather, fold
-    def _fold(self, part):
-        """part: numpy uint64 [n][2], this rank's partial vector -> the field sum over the ranks"""
-        if self.world == 1:
-            return part
-        dev = "cpu" if _is_gloo(self.group) else self.slab.device
-        t = torch.from_numpy(np.ascontiguousarray(part).view(np.uint8).reshape(-1).copy()).to(dev)
-        parts = [torch.empty_like(t) for _ in range(self.world)]
-        _all_gather(parts, t, self.group)
-        acc = parts[0].cpu().numpy().view(np.uint64).reshape(-1, 2).copy()
-        for t2 in parts[1:]:
-            v = t2.cpu().numpy().view(np.uint64).reshape(-1, 2)
-            if self.field == 4:
-                acc ^= v
-            else:
-                tot = [((int(x[0]) | (int(x[1]) << 64)) + (int(y[0]) | (int(y[1]) << 64))) % FP128_P for x, y in zip(acc, v)]
-                acc = np.array([[x & (2**64 - 1), x >> 64] for x in tot], dtype=np.uint64)
-        return acc
+        gpu = self.gpu
+        self._cb = _rng_cb(rng_bytes if self.rank == 0 else (lambda n: b"\x00" * n))
+        lq = np.ascontiguousarray(np.asarray(lqc, dtype=np.uint64).reshape(-1))
+        W = np.ascontiguousarray(W)
+        root = (C.c_uint8 * 32)()
+        h = C.c_void_p()
+        rc = gpu.L.lfgpu_ligero_commit_sharded(gpu.h, self.field, self.k, C.byref(self.p), C.c_void_p(W.ctypes.data), subfield_boundary,
+                                               C.c_void_p(lq.ctypes.data) if lq.size else None, self._cb, None, C.byref(self.comm.ops), root, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("lfgpu_ligero_commit_sharded: %s | hook: %s" % (gpu.L.lfgpu_last_error(gpu.h).decode(), self.comm.error))
+        self.pr.h = h
+        return bytes(root)
 
     def low_degree_proof(self, u_ldt):
-        """y[block] = T[ildt] + sum_i u_ldt[i] T[iw + i] (ligero_prover.h:281-291)"""
-        return self._fold(self.pr.low_degree_proof(u_ldt))
+        return self.pr.low_degree_proof(u_ldt)
 
     def dot_proof(self, A):
-        """y[dblock] = T[idot] + sum_i RS([0^r | A_i]) (.) T[iw + i] (:293-309); A: numpy uint64 [nwqrow * w][2]"""
-        return self._fold(self.pr.dot_proof(A))
+        return self.pr.dot_proof(A)
 
     def quadratic_proof(self, u_quad):
-        """(:311-344) -> (y_quad_0 [r], y_quad_2 [dblock - block])"""
-        y0, y2 = self.pr.quadratic_proof(u_quad)
-        return self._fold(y0), self._fold(y2)
+        return self.pr.quadratic_proof(u_quad)
 
     def open(self, idx):
-        """compute_req (:346-351) + MerkleCommitment::open (merkle_commitment.h:66-73)
-        -> (req numpy uint64 [nrow][nreq][2], nonces uint8 [nreq][32], path digests)"""
-        p = self.p
-        mine, nz, path = self.pr.open(idx, rows=self.row_hi - self.row_lo)
-        maxr = max(hi - lo for lo, hi in self.spans)
-        dev = "cpu" if _is_gloo(self.group) else self.slab.device
-        pad = torch.zeros((maxr, p.nreq * 16), dtype=torch.uint8)
-        pad[:mine.shape[0]] = torch.from_numpy(mine.view(np.uint8).reshape(mine.shape[0], -1))
-        pad = pad.to(dev)
-        got = [torch.empty_like(pad) for _ in range(self.world)]
-        _all_gather(got, pad, self.group)
-        req = torch.cat([got[q][:hi - lo] for q, (lo, hi) in enumerate(self.spans)], dim=0)
-        return req.cpu().numpy().view(np.uint64).reshape(p.nrow, p.nreq, 2), nz, path
+        return self.pr.open(idx)
 
     def close(self):
         if self.pr is not None:

@@ -150,6 +150,30 @@ def statement(pkg, field):
     return p, W, 0, lqc, 5, None
 
 
+def run_rank_c(pkg, par, gpu, field, group_world):
+    """the PRODUCT path: lfgpu_ligero_commit_sharded + the prove entry points through parallel.ShardedLigeroProver (hooks bound
+    to torch.distributed by parallel.TorchComm) on the same statement / vectors as run_rank"""
+    import ligero_fixture as lf
+    p, W, sfb, lqc, seed, want_root = statement(pkg, field)
+    rng = np.random.default_rng(9)
+    u = ol.rand_elts(rng, p.nwqrow, field)
+    A = ol.rand_elts(rng, p.nwqrow * p.w, field)
+    uq = ol.rand_elts(rng, max(1, p.nqtriples), field)
+    idx = [int(t) for t in rng.choice(p.block_ext, size=p.nreq, replace=False)]
+    pr = par.ShardedLigeroProver(gpu, field, p, 4, group_world)
+    pr.comm.selftest()
+    out = {"root": pr.commit(W, sfb, lqc, lf.LcgRng(seed).bytes)}
+    out["y_ldt"] = pr.low_degree_proof(u)
+    out["y_dot"] = pr.dot_proof(A)
+    out["y_q0"], out["y_q2"] = pr.quadratic_proof(uq)
+    out["req"], out["nonces"], out["path"] = pr.open(idx)
+    out["spans"] = pr.spans
+    pr.close()
+    if want_root is not None:
+        assert out["root"] == want_root, "sharded root (C entry point) differs from the reference's C++ fixture root"
+    return out
+
+
 def run_rank(pkg, par, engine, field, group_world, group_solo):
     """every rank: sharded commit + prove over `group_world`, the same over a one-rank group, compare.  Returns a dict
     of the sharded results (root, y vectors, req) for further checks by the caller."""
@@ -163,7 +187,8 @@ def run_rank(pkg, par, engine, field, group_world, group_solo):
     idx = [int(t) for t in rng.choice(p.block_ext, size=p.nreq, replace=False)]
     res = []
     for grp in (group_world, group_solo):
-        pr = par.ShardedLigeroProver(engine, lib, field, p, 4, grp)
+        import sharded_reference as sref
+        pr = sref.ShardedLigeroProver(engine, lib, field, p, 4, grp)
         out = {"root": pr.commit(W, sfb, lqc, lf.LcgRng(seed).bytes)}
         out["y_ldt"] = pr.low_degree_proof(u)
         out["y_dot"] = pr.dot_proof(A)

@@ -95,3 +95,18 @@ def test_mdoc_end_to_end_with_gpu_provers_in_run_mdoc_prover(which, reps):
     # the body of run_mdoc_verifier (mdoc_zk.cc:548-712) with lfgpu::GpuZkVerifier in the place of both ZkVerifiers
     v = res["verify"]
     assert v["gpu_verifiers_accept"] is True and v["gpu_verifiers_reject_flipped_bit"] is True and v["reference_verifiers_accept"] is True
+
+
+@pytest.mark.gpu
+def test_remaining_adapters_executed_against_the_reference_classes():
+    """lfgpu::GpuFFT, GpuLCH14, GpuMerkleCommitment (commit + open) and GpuSumcheckRound (partials, Dense::bind, HQuad::bind_h)
+    run next to FFT<Fp128>, LCH14<GF2_128<4>>, MerkleCommitment with LigeroCommon::column_hash, and ProverLayers::evaluations /
+    Dense::bind / HQuad::bind_h of the reference, in one program (oracle/ref_adapters_exec.cc), on Bogorng inputs: bit-exact."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "adapters_exec")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/adapters_exec not built (needs the reference sources: make -C oracle ref in the build container)")
+    out = subprocess.run([exe], capture_output=True, timeout=600)
+    res = json.loads(out.stdout.decode().strip().splitlines()[-1]) if out.stdout.strip() else {}
+    assert out.returncode == 0 and res.get("all_ok") is True, (res, out.stderr.decode()[-2000:])
+    for k in ("fft", "lch14", "merkle_commitment", "sumcheck_round_gf2128", "sumcheck_round_fp128"):
+        assert res[k][0] == res[k][1] and res[k][1] > 0, (k, res)
