@@ -1,4 +1,6 @@
 // core.hip -- context, memory helpers, host-side field constants.
+#include <algorithm>
+
 #include "ctx.h"
 
 int lf_fail(lfgpu_ctx* c, int code, const char* fmt, ...) {
@@ -177,6 +179,11 @@ bool lf_cu_acquire(lfgpu_ctx* c, int n) {
   g_cu.used[c->device] += n;
   c->cu_held += n;
   return true;
+}
+int lf_cu_available(const lfgpu_ctx* c) {
+  if (c->device < 0 || c->device >= 64) return 0;
+  std::lock_guard<std::mutex> lk(g_cu.m);
+  return std::max(0, cu_limit(c) - g_cu.used[c->device]);
 }
 void lf_cu_release(lfgpu_ctx* c, int n) {
   if (n < 0 || n > c->cu_held) n = c->cu_held;

@@ -1468,6 +1468,14 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   // ... and the device's budget has G CUs left for them (ctx.h: the sum over every live grid of the process stays within the
   // CU count, so each gets placed).  Short of that the caller runs this round-hand with per-launch kernels and asks again at
   // the next one, when the arrays -- and the grid -- are half the size.
+  // With other provers on the device (throughput mode) a grid takes at most half of what is free, but not less than 8
+  // workgroups while the arrays are large: K provers then share the CUs instead of the first few taking 64 each and the rest
+  // falling back to per-launch kernels.  Alone on the device nothing changes (half of 256 is more than the cap of 64).
+  {
+    const u32 avail = (u32)lf_cu_available(c);
+    const u32 share = std::max<u32>(8u, avail / 2);
+    if (G > share) G = share;
+  }
   if (!lf_cu_acquire(c, (int)G)) return LFGPU_ERR_BUSY;
   if (G_out) *G_out = G;
   if (per_wg_out) *per_wg_out = per_wg;

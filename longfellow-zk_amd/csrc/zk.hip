@@ -382,10 +382,25 @@ struct lfgpu_zk_prover {
   ~lfgpu_zk_prover() {
     if (z256) zk256_free(z256);
     if (lp) lfgpu_ligero_free(lp);
+    // the layers' wire values are functions of the witness: scrubbed before the memory goes back to the allocator (as the
+    // Ligero tableau is, lfgpu_ligero_free), and so are the host copies of the pads
+    if (c && C && !d_in.empty()) {
+      for (size_t l = 0; l < d_in.size(); ++l)
+        if (d_in[l]) (void)hipMemsetAsync(d_in[l], 0, C->layers[l].nw * 16, c->stream);
+      if (d_V) (void)hipMemsetAsync(d_V, 0, C->info.nv * 16, c->stream);
+      (void)hipStreamSynchronize(c->stream);
+    }
     for (void* p : d_in)
       if (p) (void)hipFree(p);
     if (d_V) (void)hipFree(d_V);
-    if (h_V) (void)hipHostFree(h_V);
+    if (h_V) {
+      if (C) memset(h_V, 0, C->info.nv * 16 + 16);
+      (void)hipHostFree(h_V);
+    }
+    for (auto& P : pad) {
+      for (auto& v : P.hp) std::fill(v.begin(), v.end(), elt_t{0, 0});
+      P.wc[0] = P.wc[1] = elt_t{0, 0};
+    }
   }
 };
 

@@ -1672,11 +1672,25 @@ struct Zk256 {
   double ms[6] = {0, 0, 0, 0, 0, 0};
   ~Zk256() {
     delete lp;
+    // the layers' wire values are functions of the witness: scrubbed before the memory goes back to the allocator (as the
+    // tableau is, Lig256), and so are the host copies of the pads
+    for (size_t l = 0; l < d_in.size(); ++l)
+      if (d_in[l]) (void)hipMemsetAsync(d_in[l], 0, C->layers[l].nw * 32, c->stream);
+    if (d_V) (void)hipMemsetAsync(d_V, 0, C->info.nv * 32, c->stream);
+    if (d_eq) (void)hipMemsetAsync(d_eq, 0, C->info.ninputs * 32, c->stream);
+    (void)hipStreamSynchronize(c->stream);
     for (void* p : d_in)
       if (p) (void)hipFree(p);
     if (d_V) (void)hipFree(d_V);
     if (d_eq) (void)hipFree(d_eq);
-    if (h_V) (void)hipHostFree(h_V);
+    if (h_V) {
+      memset(h_V, 0, C->info.nv * 32 + 16);
+      (void)hipHostFree(h_V);
+    }
+    for (auto& P : pad) {
+      for (auto& v : P.hp) std::fill(v.begin(), v.end(), E{});
+      P.wc[0] = P.wc[1] = E{};
+    }
   }
 };
 
