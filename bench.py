@@ -657,6 +657,25 @@ def main():
                 "single_proof_latency": lat,
                 "rank0_sweep": thr,
                 "cpu_reference_proofs_per_s_1_thread": {"flatsha256_32_blocks": (1e3 / out["zk_prove_flatsha256"]["cpu_reference"]["total_ms"]) if isinstance(out.get("zk_prove_flatsha256"), dict) and out["zk_prove_flatsha256"].get("cpu_reference") else None}}
+    if dist is not None:
+        # RCCL small-message latency (what a sharded sumcheck round-hand would pay per collective: all_gather of one (a0, a2)
+        # pair = 32 bytes per rank; DESIGN.md section 6 weighs it against the 15 - 35 us round-hand)
+        try:
+            t32 = torch.zeros(4, dtype=torch.int64, device="cuda")
+            g32 = torch.zeros(4 * world, dtype=torch.int64, device="cuda")
+            for _ in range(20):
+                dist.all_gather_into_tensor(g32, t32)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                dist.all_gather_into_tensor(g32, t32)
+                torch.cuda.synchronize()  # a round-hand needs the result on the host before it can go on
+            lat_us = (time.perf_counter() - t0) / 200 * 1e6
+            if rank == 0:
+                out["rccl_small_message"] = {"all_gather_32B_per_rank_us": lat_us, "ranks": world, "includes": "launch + collective + stream synchronisation, as a host-driven round-hand would see it"}
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                out["rccl_small_message"] = {"error": repr(e)[:200]}
     if dist is not None and not args.no_secondary:
         try:  # the sharded Ligero commit over RCCL (every rank takes part); a failure here must not cost the headline line
             sh = ligero_commit_sharded(pkg, gpu, torch, np, dist, rank, world)

@@ -673,7 +673,6 @@ extern "C" int lfgpu_zk_prover_new(lfgpu_ctx* c, const lfgpu_circuit* C, size_t 
 
 extern "C" int lfgpu_zk_prover_set_comm(lfgpu_zk_prover* zk, const lfgpu_comm_ops* comm, size_t min_tableau_bytes) {
   if (!zk) return LFGPU_ERR_ARG;
-  if (zk->z256) return lf_fail(zk->c, LFGPU_ERR_UNSUPPORTED, "zk_prover_set_comm: Fp256Base provers run as replicas (their tableaux are a few MB: lfgpu_zk_throughput mode)");
   if (!comm) {
     zk->have_comm = false;
     return LFGPU_OK;
@@ -695,7 +694,24 @@ extern "C" int lfgpu_zk_prover_param(const lfgpu_zk_prover* zk, lfgpu_ligero_par
 extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_fn rng, void* rng_user,
                                const lfgpu_transcript_ops* ts, uint8_t root_out[32]) {
   if (!zk || !h_W || !rng || !ts) return LFGPU_ERR_ARG;
-  if (zk->z256) return zk256_commit(zk->z256, h_W, rng, rng_user, ts, root_out);
+  if (zk->z256) {
+    // Fp256Base (the mdoc signature circuit: a 2.5 MB tableau) always runs replicated; with a communicator the ranks still
+    // share ONE RandomEngine -- rank 0's draws of the whole commit are recorded and broadcast, the other ranks replay them
+    if (!(zk->have_comm && zk->comm.world > 1)) return zk256_commit(zk->z256, h_W, rng, rng_user, ts, root_out);
+    std::vector<uint8_t> stream;
+    alignas(16) unsigned char store[64];
+    lfgpu_rng_fn r2 = rng;
+    void* u2 = rng_user;
+    if (zk->comm.rank == 0) {
+      lf_record_rng(rng, rng_user, &stream, &r2, &u2, store);
+    } else {
+      if (lf_comm_bcast_blob(&zk->comm, stream)) return lf_fail(zk->c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
+      lf_replay_rng(&stream, &r2, &u2, store);
+    }
+    const int rc = zk256_commit(zk->z256, h_W, r2, u2, ts, root_out);
+    if (zk->comm.rank == 0 && lf_comm_bcast_blob(&zk->comm, stream)) return lf_fail(zk->c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
+    return rc;
+  }
   const double t0 = now_ms();
   lfgpu_ctx* c = zk->c;
   const lfgpu_circuit* C = zk->C;

@@ -16,15 +16,16 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 EXE = os.path.join(ROOT, "examples", "zk_flatsha")
 
 
-def _build():
+def _build(name="zk_flatsha"):
     if not os.path.exists(ge.LIB):
         ge.build()
-    src = os.path.join(ROOT, "examples", "zk_flatsha.cc")
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(ge.LIB)):
+    src = os.path.join(ROOT, "examples", name + ".cc")
+    exe = os.path.join(ROOT, "examples", name)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(ge.LIB)):
         libdir = os.path.dirname(ge.LIB)
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-L" + libdir,
-                               "-llfgpu", "-Wl,-rpath," + libdir, "-o", EXE])
-    return EXE
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"), src, "-L" + libdir,
+                               "-llfgpu", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
 
 
 def test_cxx_example_compiles_and_fails_loudly_without_gpu(tmp_path):
@@ -53,3 +54,20 @@ def test_cxx_example_proves_and_verifies(tmp_path, stem):
     # same shape as the reference's proof; the compressed Merkle path depends on which columns the (different) randomness opens
     assert abs(res["proof_bytes"] - info["zk_wire_bytes"]) < 0.03 * info["zk_wire_bytes"]
     assert res["commit_prove_ms"] > 0 and res["verify_ms"] > 0
+
+
+def test_cxx_throughput_example_compiles():
+    _build("zk_throughput")
+
+
+@pytest.mark.gpu
+def test_cxx_throughput_example_eight_threads(tmp_path):
+    """examples/zk_throughput.cc: 8 host threads x (own context + stream, shared circuit), every eighth proof of each verified"""
+    exe = _build("zk_throughput")
+    c, w = tmp_path / "c.lfc1", tmp_path / "w.bin"
+    c.write_bytes(lzma.decompress(open(os.path.join(GOLD, "flatsha_nb1.lfc1.xz"), "rb").read()))
+    w.write_bytes(lzma.decompress(open(os.path.join(GOLD, "flatsha_nb1.w.xz"), "rb").read()))
+    out = subprocess.run([exe, str(c), str(w), "8", "1.0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["K"] == 8 and res["proofs"] >= 8 and res["all_verified_samples_accepted"] is True
