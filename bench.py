@@ -241,6 +241,8 @@ def ligero_commit_sharded(pkg, gpu, torch, np, dist, rank, world):
         pr.close()
     rng_t.close()
     mine = torch.tensor(list(roots[-1]), dtype=torch.uint8, device="cuda")
+    if dist.get_backend() == "gloo":
+        mine = mine.cpu()
     allr = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
     same = all(bool((t == allr[0]).all()) for t in allr)
@@ -252,7 +254,7 @@ def ligero_commit_sharded(pkg, gpu, torch, np, dist, rank, world):
 PUBLISHED_M4_MS = {1: 5.30, 2: 9.60, 4: 18.73, 8: 35.39, 16: 65.62, 32: 125.23, 33: 132.71}  # docs/content/en/docs/benchmarks.md:55-61
 
 
-def zk_throughput(device, jobs, ks, seconds, timeout=600):
+def zk_throughput(device, jobs, ks, seconds, timeout=420):
     """Throughput mode (tools/zk_throughput.py): K concurrent provers on this rank's device -- K host threads, each with its own
     lfgpu context + stream, one copy of the circuit in HBM -- in a CHILD process (the HIP runtime reads GPU_MAX_HW_QUEUES when it
     initialises, and this process initialised it long ago).  Every worker first REQUIRES the reference's wire bytes."""
@@ -425,6 +427,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: rehearses the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--rehearse-gloo", action="store_true", help="rehearsal of the N > 1 control flow on a ONE-GPU box: backend gloo (host-staged), every rank on device 0 (RCCL cannot put two ranks on one device); not a measurement")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -458,9 +461,21 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            local_rank = 0
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+
+    def allreduce(t, op):  # gloo rehearsal: through the host
+        if args.rehearse_gloo:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
 
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -514,7 +529,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        allreduce(tt, dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     launches_per_step = 1 if logn <= 12 else 2  # fp_fft_tile passes (fft.hip: tiles of 2^12 elements)
@@ -636,16 +651,19 @@ def main():
         barrier()
         # throughput: rank 0 sweeps K on one GPU at N = 1; with N > 1 every rank runs K = 8 at the same time (replicas)
         ks = [1, 2, 4, 8, 16] if world == 1 else [8]
-        thr = zk_throughput(local_rank, ["flatsha32", "mdoc"], ks, 2.0)
+        try:  # whatever happens here, every rank reaches the collectives below
+            thr = zk_throughput(local_rank, ["flatsha32", "mdoc"], ks, 2.0)
+        except Exception as e:  # noqa: BLE001
+            thr = {"error": repr(e)[:300]}
         agg = {}
         for job in ("flatsha32", "mdoc"):
             best = max((v["proofs_per_s"] for v in thr.get(job, {}).get("k", {}).values()), default=0.0)
-            agg[job] = best
+            agg[job] = float(best)
         if dist is not None:
             tt = torch.tensor([agg["flatsha32"], agg["mdoc"], mine.get("flatsha32_ms", 0.0), mine.get("mdoc_ms", 0.0)], dtype=torch.float64, device="cuda")
             mx = tt.clone()
-            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            allreduce(tt, dist.ReduceOp.SUM)
+            allreduce(mx, dist.ReduceOp.MAX)
             agg = {"flatsha32": float(tt[0]), "mdoc": float(tt[1])}
             lat = {"flatsha32_ms_max_over_ranks": float(mx[2]), "mdoc_ms_max_over_ranks": float(mx[3])}
         else:
@@ -657,10 +675,29 @@ def main():
                 "single_proof_latency": lat,
                 "rank0_sweep": thr,
                 "cpu_reference_proofs_per_s_1_thread": {"flatsha256_32_blocks": (1e3 / out["zk_prove_flatsha256"]["cpu_reference"]["total_ms"]) if isinstance(out.get("zk_prove_flatsha256"), dict) and out["zk_prove_flatsha256"].get("cpu_reference") else None}}
+    watchdog = None
+    if dist is not None:
+        # the legs below are collectives that have never run on more than one GPU in the build container: should one hang, the
+        # line measured so far still goes out (rank 0) and every rank leaves, instead of the whole run being killed without a line
+        import threading
+
+        def _bail():
+            if rank == 0:
+                out["multi_rank_legs"] = {"error": "a collective leg did not finish within 240 s; the line above it is complete"}
+                if cpu_base is not None:
+                    out["cpu_baseline"] = cpu_base
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+
+        watchdog = threading.Timer(240.0, _bail)
+        watchdog.daemon = True
+        watchdog.start()
     if dist is not None:
         # RCCL small-message latency (what a sharded sumcheck round-hand would pay per collective: all_gather of one (a0, a2)
         # pair = 32 bytes per rank; DESIGN.md section 6 weighs it against the 15 - 35 us round-hand)
         try:
+            if args.rehearse_gloo:
+                raise RuntimeError("gloo rehearsal: no RCCL latency to measure")
             t32 = torch.zeros(4, dtype=torch.int64, device="cuda")
             g32 = torch.zeros(4 * world, dtype=torch.int64, device="cuda")
             for _ in range(20):
@@ -685,6 +722,8 @@ def main():
             out["ligero_commit_sharded"] = sh
     if dist is not None:
         dist.barrier()
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base

@@ -10,6 +10,8 @@
 // elements through a pinned mailbox and receives one challenge.
 #include "ctx.h"
 #include "runfold.h"
+#include <sched.h>
+
 #include <atomic>
 #include <chrono>
 #include <utility>
@@ -1323,6 +1325,9 @@ static int sc_wait_post(lfgpu_ctx* c, u64 seq) {
   u64 spins = 0;
   double t_first = 0;
   while (__atomic_load_n((const u64*)&c->poll_h[5], __ATOMIC_ACQUIRE) != seq) {
+    // far longer than a round-hand without a post: this thread's device is busy with other provers' work (throughput mode with more
+    // provers than host cores, or a large kernel ahead in the queue) -- let another thread have the core between polls
+    if (spins > 0x8000 && (spins & 0xff) == 0) sched_yield();
     if ((++spins & 0xfff) == 0) {
       const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
       if (t_first == 0) t_first = t;

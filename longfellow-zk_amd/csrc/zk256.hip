@@ -14,6 +14,8 @@
 // accumulators with atomics and reduce once (fp256_reduce_limbs): exact and independent of arrival order, as for Fp128.
 // Row extension and column hashing are csrc/p256.hip.  The verifier (ZkVerifier::verify, lib/zk/zk_verifier.h:68-94) is at
 // the end of the file.
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -1227,6 +1229,7 @@ int sumcheck_layer256(lfgpu_quad* q, const F256& F, size_t logv, const E* G0, co
     u64 spins = 0;
     double t_first = 0;
     while (__atomic_load_n((const u64*)&post[16], __ATOMIC_ACQUIRE) != seq) {
+      if (spins > 0x8000 && (spins & 0xff) == 0) sched_yield();  // see sc_wait_post (sumcheck.hip)
       if ((++spins & 0xfff) == 0) {
         const double t = now_ms();
         if (t_first == 0) t_first = t;

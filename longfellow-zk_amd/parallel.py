@@ -123,9 +123,7 @@ class TorchComm:
         def run():
             with self._on(stream):
                 s, r = self._view(send, nbytes, on_device), self._view(recv, nbytes * self.world, on_device)
-                if self.world == 1:
-                    r.copy_(s)
-                elif self.gloo or not on_device:
+                if self.gloo or not on_device:  # (a one-rank group goes through the backend too: bench.py --force-dist rehearses RCCL that way)
                     if self.gloo:
                         hs = s.cpu() if on_device else s
                         parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
@@ -152,9 +150,7 @@ class TorchComm:
                 r = self._view(recv, max(o + b for o, b in zip(ro, rb)), on_device)
                 sl = [s[so[q]:so[q] + sb[q]] for q in range(W)]
                 rl = [r[ro[q]:ro[q] + rb[q]] for q in range(W)]
-                if W == 1:
-                    rl[0].copy_(sl[0])
-                elif self.gloo:  # no all_to_all, no device tensors: pairwise send / recv on host copies
+                if self.gloo:  # no all_to_all, no device tensors: pairwise send / recv on host copies
                     hs = [t.cpu().contiguous() for t in sl]
                     hr = [torch.empty(rb[q], dtype=torch.uint8) for q in range(W)]
                     hr[me].copy_(hs[me])
@@ -185,8 +181,6 @@ class TorchComm:
         def run():
             with self._on(stream):
                 b = self._view(buf, nbytes, on_device)
-                if self.world == 1:
-                    return
                 src = dist.get_global_rank(self.group, root) if self.group is not None else root
                 if self.gloo:
                     h = b.cpu().contiguous() if on_device else b

@@ -115,7 +115,39 @@ class Worker:
         self.gpu.close()
 
 
-def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None, device=0):
+class SmiSampler:
+    """mean GPU busy % over a run (rocm-smi --showuse, ~4 samples per second); None when rocm-smi is not usable"""
+
+    def __init__(self, device):
+        self.device, self.vals, self._stop = device, [], threading.Event()
+        self.th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.device), "--showuse"], capture_output=True, text=True, timeout=5).stdout
+                m = re.search(r"GPU use \(%\):\s*(\d+)", out)
+                if m:
+                    self.vals.append(int(m.group(1)))
+            except Exception:  # noqa: BLE001
+                return
+            self._stop.wait(0.2)
+
+    def __enter__(self):
+        self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self.th.join(timeout=6)
+
+    def mean(self):
+        return round(sum(self.vals) / len(self.vals), 1) if self.vals else None
+
+
+def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None, device=0, smi=False):
     stems = [load_stem(s) for s in JOBS[job]]
     base = {st["stem"]: pkg.Circuit(base_gpu, st["raw"]) for st in stems}
     out = {}
@@ -135,12 +167,17 @@ def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None, device=0):
             th = [threading.Thread(target=w.run, args=(start, stop_at)) for w in act]
             for t in th:
                 t.start()
+            sampler = SmiSampler(device) if smi else None
+            if sampler:
+                sampler.__enter__()
             t0 = time.perf_counter()
             stop_at[0] = t0 + seconds
             start.set()
             for t in th:
                 t.join()
             wall = time.perf_counter() - t0
+            if sampler:
+                sampler.__exit__()
             for w in act:
                 if w.err:
                     raise w.err
@@ -148,6 +185,8 @@ def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None, device=0):
             lat = sorted(x for w in act for x in w.lat)
             out[str(K)] = {"proofs_per_s": round(n / wall, 2), "proofs": n, "wall_s": round(wall, 3),
                            "ms_per_proof_latency_median": round(1e3 * lat[len(lat) // 2], 3) if lat else None}
+            if sampler:
+                out[str(K)]["gpu_busy_pct_mean_rocm_smi"] = sampler.mean()
             if log:
                 log("zk_throughput %s K=%d: %.1f proofs/s (%d proofs, median latency %.2f ms)" % (job, K, n / wall, n, 1e3 * lat[len(lat) // 2]))
     finally:
@@ -166,6 +205,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--smi", action="store_true", help="sample rocm-smi --showuse during every run")
     a = ap.parse_args()
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
@@ -175,7 +215,7 @@ def main():
     res = {"hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
     log = (lambda s: print(s, file=sys.stderr, flush=True))
     for job in a.jobs.split(","):
-        res[job] = {"circuits": JOBS[job], "k": measure(pkg, base_gpu, job, [int(k) for k in a.k.split(",")], a.seconds, log=log, device=a.device)}
+        res[job] = {"circuits": JOBS[job], "k": measure(pkg, base_gpu, job, [int(k) for k in a.k.split(",")], a.seconds, log=log, device=a.device, smi=a.smi)}
     base_gpu.close()
     print(json.dumps(res))
 
