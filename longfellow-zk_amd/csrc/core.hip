@@ -166,6 +166,7 @@ namespace {
 struct CuBudget {
   std::mutex m;
   int used[64] = {0};
+  int sharers[64] = {0};  // contexts with their own stream per device
 } g_cu;
 int cu_limit(const lfgpu_ctx* c) {
   static const int env = getenv("LFGPU_CU_BUDGET") ? atoi(getenv("LFGPU_CU_BUDGET")) : -1;
@@ -179,6 +180,16 @@ bool lf_cu_acquire(lfgpu_ctx* c, int n) {
   g_cu.used[c->device] += n;
   c->cu_held += n;
   return true;
+}
+int lf_cu_sharers(const lfgpu_ctx* c) {
+  if (c->device < 0 || c->device >= 64) return 0;
+  std::lock_guard<std::mutex> lk(g_cu.m);
+  return g_cu.sharers[c->device];
+}
+static void cu_sharer_add(const lfgpu_ctx* c, int d) {
+  if (c->device < 0 || c->device >= 64) return;
+  std::lock_guard<std::mutex> lk(g_cu.m);
+  g_cu.sharers[c->device] += d;
 }
 int lf_cu_available(const lfgpu_ctx* c) {
   if (c->device < 0 || c->device >= 64) return 0;
@@ -246,6 +257,7 @@ int lfgpu_shutdown(lfgpu_ctx* c) {
   hipStreamSynchronize(c->stream);
   lf_cu_release(c, -1);
   if (c->own_stream) {
+    cu_sharer_add(c, -1);
     if (c->stream == c->own_stream) c->stream = nullptr;
     hipStreamDestroy(c->own_stream);
   }
@@ -276,7 +288,10 @@ int lfgpu_set_stream(lfgpu_ctx* c, void* s) {
 int lfgpu_own_stream(lfgpu_ctx* c) {
   if (!c) return LFGPU_ERR_ARG;
   LF_HIP(c, hipSetDevice(c->device));
-  if (!c->own_stream) LF_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  if (!c->own_stream) {
+    LF_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    cu_sharer_add(c, +1);
+  }
   LF_HIP(c, hipStreamSynchronize(c->stream));  // what was enqueued on the old stream is complete before the switch
   c->stream = c->own_stream;
   return LFGPU_OK;

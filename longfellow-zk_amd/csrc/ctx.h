@@ -91,6 +91,7 @@ struct lfgpu_ctx {
 // as the grid shrinks / ends: the sum over all live grids never exceeds the CUs, so every one of them gets placed whatever
 // else (ordinary kernels, which always finish) shares the device.  All or nothing; false = take another driver this time.
 bool lf_cu_acquire(lfgpu_ctx* c, int n);
+int lf_cu_sharers(const lfgpu_ctx* c);  // contexts with a stream of their own on this device (lfgpu_own_stream): >= 2 = throughput mode
 int lf_cu_available(const lfgpu_ctx* c);  // CUs of the device's budget nobody holds right now (a hint: it may change at once)
 void lf_cu_release(lfgpu_ctx* c, int n);  // n < 0: everything the context holds
 

@@ -650,7 +650,11 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
     const size_t v = e ? (size_t)atol(e) : (size_t)128 * 1024;
     return std::min<size_t>(std::max<size_t>(v, 1024), LF_SC_GRID_MAX);
   }();
-  const size_t resident_max = sc_mode == 3 ? grid_max : LF_SC_SMALL_MAX;  // largest array a resident kernel takes over at
+  static const bool grid_max_from_env = getenv("LFGPU_SC_GRID_MAX") != nullptr;
+  // throughput mode (several provers share the device): the per-launch path costs more there than alone (its many small
+  // launches queue behind everybody else's), so the grid takes over as early as its state allows
+  const size_t grid_max_eff = (!grid_max_from_env && lf_cu_sharers(c) >= 6) ? (size_t)LF_SC_GRID_MAX : grid_max;
+  const size_t resident_max = sc_mode == 3 ? grid_max_eff : LF_SC_SMALL_MAX;  // largest array a resident kernel takes over at
   // Quad::bind_g: enqueued on the stream, nothing read back (the HQUAD size is a circuit constant)
   const double tv0 = verbose ? clk() : 0;
   LF_TRY(lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], &nh));

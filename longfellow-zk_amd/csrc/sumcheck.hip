@@ -1450,10 +1450,16 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   // buy shorter phases until the barrier among more workgroups costs more (measured: GF(2^128) products are ~4x the
   // Fp128 ones, hence the smaller share)
   static const int per_wg_env = getenv("LFGPU_SC_PER_WG") ? std::max(64, atoi(getenv("LFGPU_SC_PER_WG"))) : 0;
-  const u32 per_wg = per_wg_env ? (u32)per_wg_env : (field == LFGPU_FIELD_GF2_128 ? 512u : 1024u);
+  // Several provers on the device (>= 6 contexts with streams of their own: throughput mode): smaller grids -- 1024 entries
+  // per workgroup, at most 24 workgroups -- give each prover a little more latency and the device 10 - 14 % more proofs per
+  // second (K = 16 on flatsha-32: 333 -> 379 proofs/s; profiles/r03/README.md); a prover that has the device to itself keeps
+  // the latency-optimal shape.  The environment overrides both.
+  const bool shared_dev = lf_cu_sharers(c) >= 6;  // measured: at K = 2 and 4 the latency-optimal shape still gives more proofs per second (128 / 237 vs 113 / 216), from K = 8 on the small one (317 vs 301)
+  const u32 per_wg = per_wg_env ? (u32)per_wg_env : (field == LFGPU_FIELD_GF2_128 && !shared_dev ? 512u : 1024u);
   u32 G = (u32)((big + per_wg - 1) / per_wg);
   G = G ? G : 1;
-  static const u32 wgs_cap = getenv("LFGPU_SC_WGS") ? (u32)std::min(LF_SC_GRID_WGS, std::max(1, atoi(getenv("LFGPU_SC_WGS")))) : 64u;
+  static const u32 wgs_cap_env = getenv("LFGPU_SC_WGS") ? (u32)std::min(LF_SC_GRID_WGS, std::max(1, atoi(getenv("LFGPU_SC_WGS")))) : 0u;
+  const u32 wgs_cap = wgs_cap_env ? wgs_cap_env : (shared_dev ? 24u : 64u);
   if (G > wgs_cap) G = wgs_cap;
   if ((int)G > c->num_cu) G = (u32)c->num_cu;
   int& tail_ok = c->sc_tail_ok;  // dynamic LDS for the tail (112 KiB) needs the attribute once per kernel and context

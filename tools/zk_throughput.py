@@ -211,7 +211,7 @@ def main():
     if not os.path.exists(ge.LIB):
         ge.build()
     pkg = ge.load_package()
-    base_gpu = pkg.LfGpu(a.device).own_stream()
+    base_gpu = pkg.LfGpu(a.device)  # uploads the circuits; proves nothing (no stream of its own: it does not count as a sharer of the device)
     res = {"hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
     log = (lambda s: print(s, file=sys.stderr, flush=True))
     for job in a.jobs.split(","):
