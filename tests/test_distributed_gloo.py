@@ -146,3 +146,35 @@ def test_layout_rows_host_slabs_match_whole():
             r1 = lf.LcgRng(seed)
             part, nz1 = par.layout_rows(lib, field, 4, p, W, sfb, lqc, r1.bytes, lo, hi)
             assert (part == whole[lo:hi]).all() and nz1 == nz and r1.state == r0.state
+
+
+def test_comm_selftest_catches_a_broken_hook():
+    """lfgpu_comm_selftest is what a C++ host runs on its RCCL binding before trusting it: a one-rank communicator whose
+    all_gather copies nothing must be rejected, a correct one accepted (no process group needed: the hooks are plain callbacks)"""
+    import ctypes as C
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    import importlib
+    par = importlib.import_module("longfellow_zk_amd.parallel")
+    lib = pkg.load_library()
+
+    def ag_ok(_u, send, recv, n, _dev, _s):
+        C.memmove(recv, send, n)
+        return 0
+
+    def ag_bad(_u, send, recv, n, _dev, _s):
+        return 0  # claims success, moves nothing
+
+    def a2a(_u, send, so, sb, recv, ro, rb, _dev, _s):
+        C.memmove(recv + ro[0], send + so[0], sb[0])
+        return 0
+
+    def bc(_u, buf, n, root, _dev, _s):
+        return 0
+
+    for ag, want in ((ag_ok, 0), (ag_bad, 5)):  # 5 = LFGPU_ERR_ASSERT
+        fns = (par.AG_FN(ag), par.A2A_FN(a2a), par.BC_FN(bc))
+        ops = par.CommOps(None, 0, 1, *fns)
+        assert lib.lfgpu_comm_selftest(C.byref(ops)) == want
+    ops = par.CommOps(None, 3, 2, *fns)  # rank outside the world
+    assert lib.lfgpu_comm_selftest(C.byref(ops)) == 1  # LFGPU_ERR_ARG
