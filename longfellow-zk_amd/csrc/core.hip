@@ -48,7 +48,14 @@ int lf_pool_get(lfgpu_ctx* c, size_t bytes, void** out) {
 }
 void lf_pool_put(lfgpu_ctx* c, void* p, size_t bytes) {
   if (!p) return;
-  if (c->pool.size() >= LF_POOL_MAX) {
+  if (bytes > LF_POOL_MAX_BYTES) {  // a one-off giant (a 16 GiB synthetic tableau): not worth holding on to
+    (void)hipFree(p);
+    return;
+  }
+  size_t held = bytes;
+  for (const auto& e : c->pool) held += e.bytes;
+  while (!c->pool.empty() && (c->pool.size() >= LF_POOL_MAX || held > LF_POOL_MAX_BYTES)) {  // oldest first
+    held -= c->pool.front().bytes;
     (void)hipFree(c->pool.front().p);
     c->pool.erase(c->pool.begin());
   }

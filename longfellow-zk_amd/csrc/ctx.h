@@ -111,8 +111,10 @@ int lf_fail(lfgpu_ctx* c, int code, const char* fmt, ...);
 
 // device buffers that outlive one call but recur with the same size (Ligero tableaux, Merkle layers): taken from / returned
 // to the context's pool instead of hipMalloc / hipFree.  A returned buffer may still be in use by work queued on the
-// context's stream (in order: whatever a later user enqueues comes after it).  At most LF_POOL_MAX entries, oldest evicted.
+// context's stream (in order: whatever a later user enqueues comes after it).  At most LF_POOL_MAX entries and LF_POOL_MAX_BYTES
+// in all, oldest evicted.
 #define LF_POOL_MAX 8
+#define LF_POOL_MAX_BYTES ((size_t)2 << 30)  // all pooled buffers of a context together; larger single buffers are freed at once
 int lf_pool_get(lfgpu_ctx* c, size_t bytes, void** out);
 void lf_pool_put(lfgpu_ctx* c, void* p, size_t bytes);
 int lf_scratch(lfgpu_ctx* c, size_t bytes, void** out);
