@@ -103,8 +103,8 @@ int lfgpu_zk_prover_param(const lfgpu_zk_prover* zk, lfgpu_ligero_param* p);
  * commit, field-sum folds of the y vectors in prove); below the threshold the proof runs replicated, which is what the
  * real mdoc / flatsha256 circuits want (their tableaux are 2.5 - 20 MB: a second GPU only adds latency -- use independent
  * proofs per GPU instead, lfgpu_own_stream / bench.py zk_throughput).  The sumcheck always runs replicated.  Every rank ends
- * with the same proof bytes as a one-GPU prover fed the same RandomEngine.  comm = NULL: back to one GPU.  Row sharding: the
- * 16-byte fields; Fp256Base provers (the mdoc signature circuit: 19 rows) always run replicated, sharing rank 0's engine. */
+ * with the same proof bytes as a one-GPU prover fed the same RandomEngine.  comm = NULL: back to one GPU.  All three
+ * fields (the mdoc signature circuit over Fp256Base has a 2.5 MB tableau: leave it replicated). */
 int lfgpu_zk_prover_set_comm(lfgpu_zk_prover* zk, const lfgpu_comm_ops* comm, size_t min_tableau_bytes);
 /* ZkProver::commit (zk_prover.h:72-96): fill_pad from `rng`, Ligero-commit witness||pad, root -> transcript.
  * h_W: ninputs host elements (public inputs first). */

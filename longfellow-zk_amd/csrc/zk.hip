@@ -675,6 +675,7 @@ extern "C" int lfgpu_zk_prover_set_comm(lfgpu_zk_prover* zk, const lfgpu_comm_op
   if (!zk) return LFGPU_ERR_ARG;
   if (!comm) {
     zk->have_comm = false;
+    if (zk->z256) zk256_set_comm(zk->z256, nullptr, 0);
     return LFGPU_OK;
   }
   if (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world || !comm->all_gather || !comm->all_to_all || !comm->broadcast)
@@ -682,6 +683,7 @@ extern "C" int lfgpu_zk_prover_set_comm(lfgpu_zk_prover* zk, const lfgpu_comm_op
   zk->have_comm = true;
   zk->comm = *comm;
   zk->comm_min_bytes = min_tableau_bytes;
+  if (zk->z256) zk256_set_comm(zk->z256, &zk->comm, min_tableau_bytes);
   return LFGPU_OK;
 }
 extern "C" int lfgpu_zk_prover_param(const lfgpu_zk_prover* zk, lfgpu_ligero_param* p) {
@@ -695,22 +697,24 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
                                const lfgpu_transcript_ops* ts, uint8_t root_out[32]) {
   if (!zk || !h_W || !rng || !ts) return LFGPU_ERR_ARG;
   if (zk->z256) {
-    // Fp256Base (the mdoc signature circuit: a 2.5 MB tableau) always runs replicated; with a communicator the ranks still
-    // share ONE RandomEngine -- rank 0's draws of the whole commit are recorded and broadcast, the other ranks replay them
+    // Fp256Base: with a communicator the ranks share ONE RandomEngine -- rank 0's draws of the whole commit (pads, then the
+    // Ligero layout) are recorded and broadcast, the other ranks replay them; zk256_commit then shards the tableau's rows when
+    // it is above the threshold (lig256_commit; the mdoc signature circuit's 2.5 MB tableau normally stays replicated)
     if (!(zk->have_comm && zk->comm.world > 1)) return zk256_commit(zk->z256, h_W, rng, rng_user, ts, root_out);
     std::vector<uint8_t> stream;
     alignas(16) unsigned char store[64];
     lfgpu_rng_fn r2 = rng;
     void* u2 = rng_user;
-    if (zk->comm.rank == 0) {
+    if (zk->comm.rank == 0) {  // all draws first (no device work, no collective), so that the stream can go out before any collective
       lf_record_rng(rng, rng_user, &stream, &r2, &u2, store);
-    } else {
+      const int rc = zk256_commit(zk->z256, h_W, r2, u2, ts, root_out, /*draws_only=*/true);
       if (lf_comm_bcast_blob(&zk->comm, stream)) return lf_fail(zk->c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
-      lf_replay_rng(&stream, &r2, &u2, store);
+      if (rc) return rc;
+    } else if (lf_comm_bcast_blob(&zk->comm, stream)) {
+      return lf_fail(zk->c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
     }
-    const int rc = zk256_commit(zk->z256, h_W, r2, u2, ts, root_out);
-    if (zk->comm.rank == 0 && lf_comm_bcast_blob(&zk->comm, stream)) return lf_fail(zk->c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
-    return rc;
+    lf_replay_rng(&stream, &r2, &u2, store);
+    return zk256_commit(zk->z256, h_W, r2, u2, ts, root_out);
   }
   const double t0 = now_ms();
   lfgpu_ctx* c = zk->c;

@@ -1463,13 +1463,21 @@ struct Lig256 {
   E* d_T = nullptr;  // [nrow][block_enc]
   uint8_t* d_layers = nullptr;
   std::vector<uint8_t> nonces;
-  E* row(size_t i) const { return d_T + i * p.block_enc; }
+  // rows [row_lo, row_hi) live in d_T: all of them on one GPU, a slab with a communicator (lfgpu_zk_prover_set_comm above the
+  // size threshold): the prove functions then fold the ranks' partial vectors with the field's addition, as ligero.hip does
+  size_t row_lo = 0, row_hi = 0;
+  bool sharded = false;
+  lfgpu_comm_ops comm{};
+  std::vector<std::pair<size_t, size_t>> spans;
+  bool has(size_t i) const { return i >= row_lo && i < row_hi; }
+  E* row(size_t i) const { return d_T + (i - row_lo) * p.block_enc; }
+  size_t slab_bytes() const { return std::max<size_t>(row_hi - row_lo, 1) * p.block_enc * 32; }
   ~Lig256() {
     if (d_T) {  // the tableau holds the witness, the pads and the blinding rows: scrub it (enqueued in order behind the prover's
                 // last kernels), then keep the buffer for the next commit of this shape: a hipFree per proof would wait for every
                 // stream of the device (ctx.h, lf_pool_put)
-      (void)hipMemsetAsync(d_T, 0, p.nrow * p.block_enc * 32, c->stream);
-      lf_pool_put(c, d_T, p.nrow * p.block_enc * 32);
+      (void)hipMemsetAsync(d_T, 0, slab_bytes(), c->stream);
+      lf_pool_put(c, d_T, slab_bytes());
     }
     if (d_layers) lf_pool_put(c, d_layers, 2 * p.block_ext * 32);
   }
@@ -1532,29 +1540,128 @@ int lig256_layout(const lfgpu_ligero_param& p, const E* W, const size_t* lqc, lf
   return LFGPU_OK;
 }
 
-int lig256_commit(lfgpu_ctx* c, const lfgpu_ligero_param& p, const E* W, const size_t* lqc, lfgpu_rng_fn rng, void* user, uint8_t root[32], Lig256** out) {
+// field sum over the ranks of a host vector every rank holds a partial of (all_gather + fold: RCCL has no mod-p reduction)
+static int comm_fold256(const Lig256* L, E* y, size_t n) {
+  const lfgpu_comm_ops& cm = L->comm;
+  if (!L->sharded || cm.world == 1) return LFGPU_OK;
+  std::vector<E> all((size_t)cm.world * n);
+  if (cm.all_gather(cm.user, y, all.data(), n * 32, 0, nullptr)) return lf_fail(L->c, LFGPU_ERR_HIP, "ligero256 (sharded): all_gather hook failed");
+  for (size_t j = 0; j < n; ++j) y[j] = all[j];
+  for (int q = 1; q < cm.world; ++q)
+    for (size_t j = 0; j < n; ++j) y[j] = fp256_add(y[j], all[(size_t)q * n + j]);
+  return LFGPU_OK;
+}
+// witness / quadratic rows [a_lo, a_hi) (relative to iw) that the slab holds
+static void owned_wq256(const Lig256* L, size_t* a_lo, size_t* a_hi) {
+  const lfgpu_ligero_param& p = L->p;
+  const size_t lo = std::min(std::max(L->row_lo, p.iw), p.iw + p.nwqrow), hi = std::min(std::max(L->row_hi, p.iw), p.iw + p.nwqrow);
+  *a_lo = lo - p.iw;
+  *a_hi = std::max(hi, lo) - p.iw;
+}
+
+// cm != nullptr (more than one rank; the caller has made every rank's `rng` yield the same bytes): every rank lays out the whole
+// host image (it is small next to the encoded tableau), keeps and encodes its row slab, and the columns are committed as in
+// lfgpu_ligero_commit_sharded (ligero.hip): one all_to_all of the encoded columns, local leaves, all_gather of the digests, the
+// tree on every rank
+int lig256_commit(lfgpu_ctx* c, const lfgpu_ligero_param& p, const E* W, const size_t* lqc, lfgpu_rng_fn rng, void* user, uint8_t root[32], Lig256** out,
+                  const lfgpu_comm_ops* cm = nullptr) {
   if (p.ildt != 0 || p.idot != 1 || p.iquad != 2 || p.iw != 3) return lf_fail(c, LFGPU_ERR_ARG, "ligero256: row order");
   std::unique_ptr<Lig256> L(new Lig256());
   L->c = c;
   L->p = p;
   L->nonces.resize(32 * p.block_ext);
+  L->row_lo = 0;
+  L->row_hi = p.nrow;
+  const int world = cm ? cm->world : 1, rank = cm ? cm->rank : 0;
+  if (cm && world > 1) {
+    L->sharded = true;
+    L->comm = *cm;
+    L->spans.resize(world);
+    for (int q = 0; q < world; ++q) (void)lfgpu_ligero_row_shard(&p, q, world, &L->spans[q].first, &L->spans[q].second);
+    L->row_lo = L->spans[rank].first;
+    L->row_hi = L->spans[rank].second;
+  }
   std::vector<E> H(p.nrow * p.dblock);
   char err[256] = {0};
   const int rc = lig256_layout(p, W, lqc, rng, user, H.data(), L->nonces.data(), err, c->rng_exact != 0);
   if (rc) return lf_fail(c, rc, "%s", err);
-  const size_t ld = p.block_enc;
-  if (lf_pool_get(c, p.nrow * ld * 32, (void**)&L->d_T) != LFGPU_OK || lf_pool_get(c, 2 * p.block_ext * 32, (void**)&L->d_layers) != LFGPU_OK)
+  const size_t ld = p.block_enc, nr = L->row_hi - L->row_lo, ncols = p.block_ext;
+  if (lf_pool_get(c, L->slab_bytes(), (void**)&L->d_T) != LFGPU_OK || lf_pool_get(c, 2 * p.block_ext * 32, (void**)&L->d_layers) != LFGPU_OK)
     return lf_fail(c, LFGPU_ERR_NOMEM, "ligero256: tableau alloc");
-  LF_HIP(c, hipMemcpy2DAsync(L->d_T, ld * 32, H.data(), p.dblock * 32, p.dblock * 32, p.nrow, hipMemcpyHostToDevice, c->stream));
-  // rows IDOT / IQUAD carry dblock values, every other row block (ligero_prover.h:175,184,203,210,237)
-  LF_TRY(lfgpu_fp256_rs_encode_rows(c, 1, p.block, p.block_enc, L->row(0), ld));
-  LF_TRY(lfgpu_fp256_rs_encode_rows(c, 2, p.dblock, p.block_enc, L->row(1), ld));
-  LF_TRY(lfgpu_fp256_rs_encode_rows(c, p.nrow - 3, p.block, p.block_enc, L->row(3), ld));
+  if (nr) LF_HIP(c, hipMemcpy2DAsync(L->d_T, ld * 32, H.data() + L->row_lo * p.dblock, p.dblock * 32, p.dblock * 32, nr, hipMemcpyHostToDevice, c->stream));
+  // rows IDOT / IQUAD carry dblock values, every other row block (ligero_prover.h:175,184,203,210,237): the slab's share of each group
+  auto encode = [&](size_t g_lo, size_t g_hi, size_t n) -> int {
+    const size_t lo = std::max(g_lo, L->row_lo), hi = std::min(g_hi, L->row_hi);
+    return hi > lo ? lfgpu_fp256_rs_encode_rows(c, hi - lo, n, p.block_enc, L->row(lo), ld) : LFGPU_OK;
+  };
+  LF_TRY(encode(0, 1, p.block));
+  LF_TRY(encode(1, 3, p.dblock));
+  LF_TRY(encode(3, p.nrow, p.block));
   void* d_non = nullptr;
-  LF_TRY(lf_scratch3(c, p.block_ext * 32, &d_non));
-  LF_HIP(c, hipMemcpyAsync(d_non, L->nonces.data(), p.block_ext * 32, hipMemcpyHostToDevice, c->stream));
-  LF_TRY(lfgpu_column_commit(c, LFGPU_FIELD_P256, p.nrow, ld, p.dblock, p.block_ext, L->d_T, d_non, L->d_layers, root));
-  LF_HIP(c, hipStreamSynchronize(c->stream));  // H is a local
+  if (!L->sharded) {
+    LF_TRY(lf_scratch3(c, p.block_ext * 32, &d_non));
+    LF_HIP(c, hipMemcpyAsync(d_non, L->nonces.data(), p.block_ext * 32, hipMemcpyHostToDevice, c->stream));
+    LF_TRY(lfgpu_column_commit(c, LFGPU_FIELD_P256, p.nrow, ld, p.dblock, p.block_ext, L->d_T, d_non, L->d_layers, root));
+    LF_HIP(c, hipStreamSynchronize(c->stream));  // H is a local
+    *out = L.release();
+    return LFGPU_OK;
+  }
+  // ---- sharded column commit
+  auto split = [&](size_t n, int q, size_t* start, size_t* count) {
+    const size_t base = n / (size_t)world, rem = n % (size_t)world, r = (size_t)q;
+    *start = r * base + std::min(r, rem);
+    *count = base + (r < rem ? 1 : 0);
+  };
+  std::vector<size_t> soff(world), sbytes(world), roff(world), rbytes(world);
+  size_t mc0 = 0, mcn = 0, send_tot = 0, maxn = 0, dummy = 0;
+  split(ncols, rank, &mc0, &mcn);
+  split(ncols, 0, &dummy, &maxn);
+  for (int q = 0; q < world; ++q) {
+    size_t c0, cn;
+    split(ncols, q, &c0, &cn);
+    soff[q] = send_tot;
+    sbytes[q] = nr * cn * 32;
+    send_tot += sbytes[q];
+    roff[q] = L->spans[q].first * mcn * 32;
+    rbytes[q] = (L->spans[q].second - L->spans[q].first) * mcn * 32;
+  }
+  const size_t send_bytes = std::max<size_t>(send_tot, 32), cols_bytes = std::max<size_t>(p.nrow * mcn * 32, 32);
+  void *d_send = nullptr, *d_cols = nullptr;
+  if (lf_pool_get(c, send_bytes, &d_send) != LFGPU_OK) return lf_fail(c, LFGPU_ERR_NOMEM, "ligero256 (sharded): exchange buffers");
+  if (lf_pool_get(c, cols_bytes, &d_cols) != LFGPU_OK) {
+    lf_pool_put(c, d_send, send_bytes);
+    return lf_fail(c, LFGPU_ERR_NOMEM, "ligero256 (sharded): exchange buffers");
+  }
+  auto done = [&](int code) {
+    lf_pool_put(c, d_send, send_bytes);
+    lf_pool_put(c, d_cols, cols_bytes);
+    return code;
+  };
+  for (int q = 0; q < world && nr; ++q) {
+    size_t c0, cn;
+    split(ncols, q, &c0, &cn);
+    if (cn && hipMemcpy2DAsync((uint8_t*)d_send + soff[q], cn * 32, L->d_T + p.dblock + c0, ld * 32, cn * 32, nr, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+      return done(lf_fail(c, LFGPU_ERR_HIP, "ligero256 (sharded): pack"));
+  }
+  if (cm->all_to_all(cm->user, d_send, soff.data(), sbytes.data(), d_cols, roff.data(), rbytes.data(), 1, c->stream))
+    return done(lf_fail(c, LFGPU_ERR_HIP, "ligero256 (sharded): all_to_all hook failed"));
+  int rc2 = lf_scratch3(c, ncols * 32 + (size_t)(world + 1) * maxn * 32 + 64, &d_non);
+  if (rc2) return done(rc2);
+  uint8_t* d_mine = (uint8_t*)d_non + ncols * 32;
+  uint8_t* d_all = d_mine + maxn * 32;
+  if (hipMemcpyAsync(d_non, L->nonces.data(), ncols * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipMemsetAsync(d_mine, 0, maxn * 32, c->stream) != hipSuccess)
+    return done(lf_fail(c, LFGPU_ERR_HIP, "ligero256 (sharded): nonce upload"));
+  if (mcn && (rc2 = lf_column_leaves32(c, p.nrow, mcn, 0, mcn, d_cols, (const uint8_t*)d_non + mc0 * 32, d_mine, 0))) return done(rc2);
+  if (cm->all_gather(cm->user, d_mine, d_all, maxn * 32, 1, c->stream)) return done(lf_fail(c, LFGPU_ERR_HIP, "ligero256 (sharded): all_gather hook failed"));
+  if (hipMemsetAsync(L->d_layers, 0, ncols * 32, c->stream) != hipSuccess) return done(lf_fail(c, LFGPU_ERR_HIP, "ligero256 (sharded): layers"));
+  for (int q = 0; q < world; ++q) {
+    size_t c0, cn;
+    split(ncols, q, &c0, &cn);
+    if (cn && hipMemcpyAsync(L->d_layers + (ncols + c0) * 32, d_all + (size_t)q * maxn * 32, cn * 32, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+      return done(lf_fail(c, LFGPU_ERR_HIP, "ligero256 (sharded): leaves"));
+  }
+  if ((rc2 = lfgpu_merkle_build_tree(c, ncols, L->d_layers, root))) return done(rc2);  // synchronises: H may go
+  done(LFGPU_OK);
   *out = L.release();
   return LFGPU_OK;
 }
@@ -1565,12 +1672,17 @@ int lig256_low_degree(Lig256* L, const E* u, E* y) {  // low_degree_proof (:281-
   void *dy = nullptr, *du = nullptr;
   LF_TRY(lf_scratch3(c, p.block * 32, &dy));
   LF_TRY(lf_scratch2(c, p.nwqrow * 32 + 64, &du));
-  LF_HIP(c, hipMemcpyAsync(dy, L->row(p.ildt), p.block * 32, hipMemcpyDeviceToDevice, c->stream));
+  if (L->has(p.ildt)) LF_HIP(c, hipMemcpyAsync(dy, L->row(p.ildt), p.block * 32, hipMemcpyDeviceToDevice, c->stream));
+  else LF_HIP(c, hipMemsetAsync(dy, 0, p.block * 32, c->stream));
   LF_HIP(c, hipMemcpyAsync(du, u, p.nwqrow * 32, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(rows_axpy256_kernel, dim3(nblk(p.block, 64)), dim3(256), 0, c->stream, (u32)p.nwqrow, p.block, (E*)dy, (const E*)du,
-                     (const E*)L->row(p.iw), p.block_enc);
+  size_t a_lo, a_hi;
+  owned_wq256(L, &a_lo, &a_hi);
+  if (a_hi > a_lo)
+    hipLaunchKernelGGL(rows_axpy256_kernel, dim3(nblk(p.block, 64)), dim3(256), 0, c->stream, (u32)(a_hi - a_lo), p.block, (E*)dy, (const E*)du + a_lo,
+                       (const E*)L->row(p.iw + a_lo), p.block_enc);
   LF_HIP(c, hipGetLastError());
-  return lfgpu_memcpy_d2h(c, y, dy, p.block * 32);
+  LF_TRY(lfgpu_memcpy_d2h(c, y, dy, p.block * 32));
+  return comm_fold256(L, y, p.block);
 }
 
 // dot_proof (:293-309) with A given as inner_product_vector builds it: a dense block scale * dense[0..ndense) over the first
@@ -1580,7 +1692,7 @@ int lig256_dot(Lig256* L, const E* d_dense, size_t ndense, const E& scale, const
   const lfgpu_ligero_param& p = L->p;
   const size_t lda = p.dblock;
   void* sc = nullptr;
-  LF_TRY(lf_scratch3(c, (p.nwqrow * lda + p.dblock) * 32 + 64, &sc));
+  LF_TRY(lf_scratch3(c, (p.nwqrow * lda + 2 * p.dblock) * 32 + 64, &sc));
   E* dA = (E*)sc;
   E* dy = dA + p.nwqrow * lda;
   LF_HIP(c, hipMemsetAsync(dA, 0, p.nwqrow * lda * 32, c->stream));
@@ -1597,30 +1709,52 @@ int lig256_dot(Lig256* L, const E* d_dense, size_t ndense, const E& scale, const
     LF_HIP(c, hipGetLastError());
     LF_HIP(c, hipStreamSynchronize(c->stream));  // the staging area is the Reed-Solomon encoder's work space next
   }
-  LF_TRY(lfgpu_fp256_rs_encode_rows(c, p.nwqrow, p.block, p.dblock, dA, lda));
-  hipLaunchKernelGGL(rows_vaxpy256_kernel, dim3(nblk(p.dblock, 64)), dim3(256), 0, c->stream, (u32)p.nwqrow, p.dblock, (const E*)L->row(p.idot), (const E*)dA, lda,
-                     (const E*)L->row(p.iw), p.block_enc, dy);
+  size_t a_lo, a_hi;
+  owned_wq256(L, &a_lo, &a_hi);
+  if (a_hi > a_lo) LF_TRY(lfgpu_fp256_rs_encode_rows(c, a_hi - a_lo, p.block, p.dblock, dA + a_lo * lda, lda));
+  const E* T0 = nullptr;
+  if (L->has(p.idot)) {
+    T0 = L->row(p.idot);
+  } else {  // a zero row behind dy
+    LF_HIP(c, hipMemsetAsync(dy + p.dblock, 0, p.dblock * 32, c->stream));
+    T0 = dy + p.dblock;
+  }
+  hipLaunchKernelGGL(rows_vaxpy256_kernel, dim3(nblk(p.dblock, 64)), dim3(256), 0, c->stream, (u32)(a_hi - a_lo), p.dblock, T0, (const E*)(dA + a_lo * lda), lda,
+                     (const E*)(a_hi > a_lo ? L->row(p.iw + a_lo) : L->d_T), p.block_enc, dy);
   LF_HIP(c, hipGetLastError());
-  return lfgpu_memcpy_d2h(c, y, dy, p.dblock * 32);
+  LF_TRY(lfgpu_memcpy_d2h(c, y, dy, p.dblock * 32));
+  return comm_fold256(L, y, p.dblock);
 }
 
 int lig256_quadratic(Lig256* L, const E* u, E* y0, E* y2) {  // quadratic_proof (:311-344)
   lfgpu_ctx* c = L->c;
   const lfgpu_ligero_param& p = L->p;
   void* sc = nullptr;
-  LF_TRY(lf_scratch3(c, (p.nqtriples + 1 + p.dblock) * 32 + 64, &sc));
+  LF_TRY(lf_scratch3(c, (p.nqtriples + 1 + 2 * p.dblock) * 32 + 64, &sc));
   E* du = (E*)sc;
   E* dy = du + p.nqtriples + 1;
   if (p.nqtriples) LF_HIP(c, hipMemcpyAsync(du, u, p.nqtriples * 32, hipMemcpyHostToDevice, c->stream));
   const size_t ld = p.block_enc;
-  const E* X = L->row(p.iq);
+  // a triple is multiplied element-wise: the slab holds all quadratic rows (the last rank) or none
+  const size_t q_lo = p.iq, q_hi = p.iq + 3 * p.nqtriples;
+  const bool all_q = p.nqtriples == 0 || (L->row_lo <= q_lo && q_hi <= L->row_hi);
+  if (!all_q && !(L->row_hi <= q_lo || L->row_lo >= q_hi)) return lf_fail(c, LFGPU_ERR_ARG, "quadratic_proof256: the slab splits the quadratic rows");
+  const size_t nt = all_q ? p.nqtriples : 0;
+  const E* Tq = nullptr;
+  if (L->has(p.iquad)) {
+    Tq = L->row(p.iquad);
+  } else {
+    LF_HIP(c, hipMemsetAsync(dy + p.dblock, 0, p.dblock * 32, c->stream));
+    Tq = dy + p.dblock;
+  }
+  const E* X = nt ? L->row(p.iq) : L->d_T;
   const E* Y = X + p.nqtriples * ld;
   const E* Zr = Y + p.nqtriples * ld;
-  hipLaunchKernelGGL(quad_combo256_kernel, dim3(nblk(p.dblock)), dim3(Z_THREADS), 0, c->stream, (u32)p.nqtriples, p.dblock, (const E*)L->row(p.iquad), (const E*)du, X,
-                     Y, Zr, ld, dy);
+  hipLaunchKernelGGL(quad_combo256_kernel, dim3(nblk(p.dblock)), dim3(Z_THREADS), 0, c->stream, (u32)nt, p.dblock, Tq, (const E*)du, X, Y, Zr, ld, dy);
   LF_HIP(c, hipGetLastError());
   std::vector<E> y(p.dblock);
   LF_TRY(lfgpu_memcpy_d2h(c, y.data(), dy, p.dblock * 32));
+  LF_TRY(comm_fold256(L, y.data(), p.dblock));
   for (size_t j = 0; j < p.w; ++j)
     if (!e32_is_zero(y[p.r + j])) return lf_fail(c, LFGPU_ERR_ASSERT, "quadratic_proof: W part is nonzero");
   memcpy(y0, y.data(), p.r * 32);
@@ -1634,14 +1768,34 @@ int lig256_open(Lig256* L, const size_t* idx, E* req, uint8_t* nonces, uint8_t* 
   for (size_t i = 0; i < p.nreq; ++i)
     if (idx[i] >= p.block_ext) return lf_fail(c, LFGPU_ERR_ARG, "ligero_open: index out of range");
   void *dreq = nullptr, *di = nullptr;
-  LF_TRY(lf_scratch3(c, p.nrow * p.nreq * 32, &dreq));
+  const size_t nr = L->row_hi - L->row_lo;
+  size_t maxr = nr;
+  for (const auto& sp : L->spans) maxr = std::max(maxr, sp.second - sp.first);
+  LF_TRY(lf_scratch3(c, std::max<size_t>(nr, 1) * p.nreq * 32, &dreq));
   LF_TRY(lf_scratch2(c, p.nreq * 8 + 64, &di));
   std::vector<u64> ix(idx, idx + p.nreq);
   LF_HIP(c, hipMemcpyAsync(di, ix.data(), p.nreq * 8, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(gather_columns256_kernel, dim3(nblk(p.nrow * p.nreq)), dim3(Z_THREADS), 0, c->stream, (u32)p.nrow, p.block_enc, p.dblock, (const E*)L->d_T,
-                     (const u64*)di, (u32)p.nreq, (E*)dreq);
-  LF_HIP(c, hipGetLastError());
-  LF_TRY(lfgpu_memcpy_d2h(c, req, dreq, p.nrow * p.nreq * 32));
+  std::vector<uint8_t> mine;  // a slab's rows of req, padded to the largest slab for the all_gather
+  void* h_dst = req;
+  if (L->sharded) {
+    mine.assign(maxr * p.nreq * 32, 0);
+    h_dst = mine.data();
+  }
+  if (nr) {
+    hipLaunchKernelGGL(gather_columns256_kernel, dim3(nblk(nr * p.nreq)), dim3(Z_THREADS), 0, c->stream, (u32)nr, p.block_enc, p.dblock, (const E*)L->d_T,
+                       (const u64*)di, (u32)p.nreq, (E*)dreq);
+    LF_HIP(c, hipGetLastError());
+    LF_TRY(lfgpu_memcpy_d2h(c, h_dst, dreq, nr * p.nreq * 32));
+  } else {
+    LF_HIP(c, hipStreamSynchronize(c->stream));  // ix is a local
+  }
+  if (L->sharded) {
+    const lfgpu_comm_ops& cm = L->comm;
+    std::vector<uint8_t> all((size_t)cm.world * mine.size());
+    if (cm.all_gather(cm.user, mine.data(), all.data(), mine.size(), 0, nullptr)) return lf_fail(c, LFGPU_ERR_HIP, "ligero256_open (sharded): all_gather hook failed");
+    for (int q = 0; q < cm.world; ++q)
+      memcpy((uint8_t*)req + L->spans[q].first * p.nreq * 32, all.data() + (size_t)q * mine.size(), (L->spans[q].second - L->spans[q].first) * p.nreq * 32);
+  }
   for (size_t i = 0; i < p.nreq; ++i) memcpy(nonces + 32 * i, &L->nonces[32 * idx[i]], 32);
   return lfgpu_merkle_open(c, p.block_ext, L->d_layers, idx, p.nreq, path, path_cap, npath);
 }
@@ -1673,6 +1827,10 @@ struct Zk256 {
   void* h_V = nullptr;  // pinned: outputs then the assert-zero flag
   void* d_eq = nullptr;  // EQ table of the input constraint
   double ms[6] = {0, 0, 0, 0, 0, 0};
+  // lfgpu_zk_prover_set_comm: a tableau of at least comm_min_bytes is committed with its rows sharded over the communicator's GPUs
+  bool have_comm = false;
+  lfgpu_comm_ops comm{};
+  size_t comm_min_bytes = 0;
   ~Zk256() {
     delete lp;
     // the layers' wire values are functions of the witness: scrubbed before the memory goes back to the allocator (as the
@@ -1934,6 +2092,11 @@ int zk256_param(const Zk256* z, lfgpu_ligero_param* p) {
   *p = z->param;
   return LFGPU_OK;
 }
+void zk256_set_comm(Zk256* z, const lfgpu_comm_ops* comm, size_t min_tableau_bytes) {
+  z->have_comm = comm != nullptr;
+  if (comm) z->comm = *comm;
+  z->comm_min_bytes = min_tableau_bytes;
+}
 void zk256_free(Zk256* z) { delete z; }
 int zk256_timings(const Zk256* z, double ms[6]) {
   memcpy(ms, z->ms, sizeof(z->ms));
@@ -1947,7 +2110,9 @@ static int ts256_ok(lfgpu_ctx* c, const lfgpu_transcript_ops* ts) {
 }
 
 // ZkProver::commit (zk_prover.h:72-96): fill_pad from rng, Ligero-commit witness || pad, root -> transcript
-int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, const lfgpu_transcript_ops* ts, uint8_t root_out[32]) {
+// draws_only: perform every RandomEngine draw of the commit (pads, then the Ligero layout) and stop -- rank 0 of a communicator
+// records its engine's stream this way before any collective runs
+int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, const lfgpu_transcript_ops* ts, uint8_t root_out[32], bool draws_only) {
   lfgpu_ctx* c = z->c;
   LF_TRY(ts256_ok(c, ts));
   const double t0 = now_ms();
@@ -1989,11 +2154,19 @@ int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, co
     pi += layer_size256(logw);
   }
   if (pi != z->param.nw) return lf_fail(c, LFGPU_ERR_ASSERT, "zk256_commit: witness layout");
+  if (draws_only) {
+    std::vector<E> H(z->param.nrow * z->param.dblock);
+    std::vector<uint8_t> nz(32 * z->param.block_ext);
+    char err[256] = {0};
+    const int rc = lig256_layout(z->param, Wv.data(), z->lqc.data(), rng, rng_user, H.data(), nz.data(), err, c->rng_exact != 0);
+    return rc ? lf_fail(c, rc, "%s", err) : LFGPU_OK;
+  }
   delete z->lp;
   z->lp = nullptr;
   z->have_proof = false;
   z->wire_valid = false;
-  LF_TRY(lig256_commit(c, z->param, Wv.data(), z->lqc.data(), rng, rng_user, z->root, &z->lp));
+  const bool shard_rows = z->have_comm && z->comm.world > 1 && z->param.nrow * z->param.block_enc * 32 >= z->comm_min_bytes;
+  LF_TRY(lig256_commit(c, z->param, Wv.data(), z->lqc.data(), rng, rng_user, z->root, &z->lp, shard_rows ? &z->comm : nullptr));
   ts->write_bytes(ts->user, z->root, 32);  // LigeroTranscript::write_commitment
   if (root_out) memcpy(root_out, z->root, 32);
   z->ms[0] = now_ms() - t0;

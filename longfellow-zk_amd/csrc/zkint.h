@@ -28,11 +28,12 @@ struct lfgpu_circuit {
 struct Zk256;
 int zk256_new(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc, Zk256** out);
 int zk256_param(const Zk256* z, lfgpu_ligero_param* p);
-int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, const lfgpu_transcript_ops* ts, uint8_t root_out[32]);
+int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, const lfgpu_transcript_ops* ts, uint8_t root_out[32], bool draws_only = false);
 int zk256_prove(Zk256* z, const void* h_W, const lfgpu_transcript_ops* ts, int* ok);
 int zk256_proof_write(const Zk256* z, uint8_t* buf, size_t cap, size_t* nbytes);
 int zk256_timings(const Zk256* z, double ms[6]);
 void zk256_free(Zk256* z);
+void zk256_set_comm(Zk256* z, const lfgpu_comm_ops* comm, size_t min_tableau_bytes);  // comm == nullptr: one GPU
 int zk256_verify(lfgpu_ctx* c, const lfgpu_circuit* C, size_t rateinv, size_t nreq, size_t block_enc, const uint8_t* proof, size_t proof_len, const void* h_pub,
                  const lfgpu_transcript_ops* ts, bool committed, int* ok, const char** why);
 // MerkleTreeVerifier::verify_compressed_proof (lib/merkle/merkle_tree.h:160-209), host (zk.hip)

@@ -111,19 +111,20 @@ def _zk_with_comm(pkg, gpu, par, rank):
         assert len(wire) == info["zk_wire_bytes"] and hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"], ("threshold", thr, comm.error)
     zk.close()
     circ.close()
-    # Fp256Base (the mdoc signature circuit): replicated, one RandomEngine (rank 0's) behind the communicator
+    # Fp256Base (the mdoc signature circuit): one RandomEngine (rank 0's) behind the communicator
     raw = lzma.decompress(open(os.path.join(gold, "mdoc_sig.lfc1.xz"), "rb").read())
     W = np.frombuffer(lzma.decompress(open(os.path.join(gold, "mdoc_sig.w.xz"), "rb").read()), dtype=np.uint64).reshape(-1, 4).copy()
     info = json.load(open(os.path.join(gold, "mdoc.json")))["sig"]
     circ = pkg.Circuit(gpu, raw)
     zk = pkg.ZkProver(gpu, circ, 7, 132, info["block_enc"])
-    zk.set_comm(comm, 0)
-    ts = pkg.FsTranscript(b"test")
-    zk.commit(W, lf.LcgRng(100 if rank == 0 else 777 + rank).bytes, ts)
-    assert zk.prove(W, ts), comm.error
-    wire = zk.wire()
-    ts.close()
-    assert len(wire) == info["zk_wire_bytes"] and hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"], comm.error
+    for thr in (0, 1 << 40):  # 19 rows of 32-byte elements sharded over the ranks (lig256_commit), then replicated
+        zk.set_comm(comm, thr)
+        ts = pkg.FsTranscript(b"test")
+        zk.commit(W, lf.LcgRng(100 if rank == 0 else 777 + rank).bytes, ts)
+        assert zk.prove(W, ts), comm.error
+        wire = zk.wire()
+        ts.close()
+        assert len(wire) == info["zk_wire_bytes"] and hashlib.sha256(wire).hexdigest() == info["zk_wire_sha256"], ("p256 threshold", thr, comm.error)
     zk.close()
     circ.close()
 
