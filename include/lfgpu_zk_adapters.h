@@ -85,7 +85,7 @@ class GpuZkProver {
   // comm != nullptr: one process per GPU, every rank constructs the prover on its own Context and calls commit / prove with the
   // same arguments (SPMD; only rank 0's RandomEngine is drawn from).  Ligero tableaux of at least min_tableau_bytes are
   // committed with their rows sharded over the communicator's GPUs (lfgpu_zk_prover_set_comm, include/lfgpu_zk.h); the hooks
-  // are the caller's binding of all_gather / all_to_all / broadcast to RCCL.  16-byte fields.
+  // are the caller's binding of all_gather / all_to_all / broadcast to RCCL.  All three fields.
   GpuZkProver(const Context& ctx, const uint8_t* lfc1, size_t len, const Field& F, const lfgpu_comm_ops* comm = nullptr, size_t min_tableau_bytes = 0)
       : c_(ctx), f_(F), have_comm_(comm != nullptr), min_tableau_bytes_(min_tableau_bytes) {
     if (comm) comm_ = *comm;
