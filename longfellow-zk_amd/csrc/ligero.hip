@@ -10,6 +10,7 @@
 // uploaded once; the GPU then RS-encodes every row (K3/K4) and commits the columns
 // (K5/K6).  The tableau stays in HBM for the prove-side row combinations (K12).
 #include <algorithm>
+#include <chrono>
 #include <new>
 
 #include "ctx.h"
@@ -457,12 +458,18 @@ static int layout_sharded_host(int field, int k, const GfHostCtx* g, const lfgpu
                                const size_t* h_lqc, lfgpu_rng_fn rng, void* user, const lfgpu_comm_ops* cm, bool exact, size_t row_lo, size_t row_hi,
                                elt_t* H, uint8_t* nonces, char* err) {
   // the RandomEngine is ONE sequential stream (ligero_prover.h:171-270, merkle_commitment.h:52-54): rank 0 draws all of it
-  // through the layout with an empty slab, everyone replays it and keeps its rows
+  // (recorded while it lays out its own slab), the other ranks replay it and keep their rows
   std::vector<uint8_t> stream;
-  if (cm->rank == 0) {
+  if (cm->rank == 0) {  // rank 0 lays out its own slab while it draws: one pass, and the others wait for nothing else
     RecordRng rec{rng, user, &stream};
-    const int rc = ligero_layout_host(field, k, g, p, (const elt_t*)h_W, subfield_boundary, h_lqc, record_fn, &rec, 0, 0, nullptr, nullptr, err, exact);
+    const int rc = ligero_layout_host(field, k, g, p, (const elt_t*)h_W, subfield_boundary, h_lqc, record_fn, &rec, row_lo, row_hi, H, nonces, err, exact);
+    const bool sent = lf_comm_bcast_blob(cm, stream) == LFGPU_OK;  // even after a failed layout: the others are waiting in the broadcast
     if (rc) return rc;
+    if (!sent) {
+      snprintf(err, 256, "ligero (sharded): broadcast hook failed");
+      return LFGPU_ERR_HIP;
+    }
+    return LFGPU_OK;
   }
   if (lf_comm_bcast_blob(cm, stream)) {
     snprintf(err, 256, "ligero (sharded): broadcast hook failed");
@@ -527,6 +534,10 @@ extern "C" int lfgpu_ligero_commit_sharded(lfgpu_ctx* c, int field, int k, const
     return rc;
   };
   const size_t nr = pr->row_hi - pr->row_lo, ld = p.block_enc, ncols = p.block_ext;
+  static const bool verbose = getenv("LFGPU_VERBOSE") != nullptr;
+  auto clk = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tv0 = clk();
+  double tv1 = tv0, tv2 = tv0, tv3 = tv0, tv4 = tv0;
   // 1. host layout of this rank's slab from the one random stream
   std::vector<elt_t> H(std::max<size_t>(nr, 1) * p.dblock);
   {
@@ -535,6 +546,7 @@ extern "C" int lfgpu_ligero_commit_sharded(lfgpu_ctx* c, int field, int k, const
                                        pr->nonces.data(), err);
     if (rc) return fail(lf_fail(c, rc, "%s", err));
   }
+  tv1 = clk();
   // 2. RS-extend the slab: rows are independent, no collective
   const size_t tb = std::max<size_t>(nr, 1) * ld * 16, lb = 2 * ncols * 32;
   if (lf_pool_get(c, tb, (void**)&pr->d_T) != LFGPU_OK) return fail(lf_fail(c, LFGPU_ERR_NOMEM, "ligero_commit_sharded: slab alloc"));
@@ -567,8 +579,13 @@ extern "C" int lfgpu_ligero_commit_sharded(lfgpu_ctx* c, int field, int k, const
     if (cn && hipMemcpy2DAsync((uint8_t*)d_send + soff[q], cn * 16, pr->d_T + p.dblock + c0, ld * 16, cn * 16, nr, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
       return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit_sharded: pack"));
   }
+  if (verbose) {
+    (void)hipStreamSynchronize(c->stream);
+    tv2 = clk();
+  }
   if (cm->all_to_all(cm->user, d_send, soff.data(), sbytes.data(), d_cols, roff.data(), rbytes.data(), 1, c->stream))
     return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit_sharded: all_to_all hook failed"));
+  tv3 = clk();
   // 4. local leaves of my columns, all_gather of the digests (ragged: padded to the largest share), the tree on every rank
   size_t maxn = 0, dummy = 0;
   shard_split(ncols, 0, world, &dummy, &maxn);
@@ -589,6 +606,10 @@ extern "C" int lfgpu_ligero_commit_sharded(lfgpu_ctx* c, int field, int k, const
       return fail(lf_fail(c, LFGPU_ERR_HIP, "ligero_commit_sharded: leaves"));
   }
   if ((rc = lfgpu_merkle_build_tree(c, ncols, pr->d_layers, root_out))) return fail(rc);
+  tv4 = clk();
+  if (verbose)
+    fprintf(stderr, "lfgpu ligero_commit_sharded rank %d/%d: rows [%zu, %zu): layout + stream %.2f ms | upload + RS encode + pack %.2f | all_to_all %.2f | leaves + all_gather + tree %.2f\n",
+            rank, world, pr->row_lo, pr->row_hi, tv1 - tv0, tv2 - tv1, tv3 - tv2, tv4 - tv3);
   lf_pool_put(c, d_send, send_bytes_tot);
   lf_pool_put(c, d_cols, cols_bytes);
   *out = pr;
