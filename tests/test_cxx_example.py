@@ -71,3 +71,34 @@ def test_cxx_throughput_example_eight_threads(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["K"] == 8 and res["proofs"] >= 8 and res["all_verified_samples_accepted"] is True
+
+
+def _build_rccl_example():
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "examples", "sharded_commit_rccl.cc")
+    exe = os.path.join(ROOT, "examples", "sharded_commit_rccl")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(ge.LIB)):
+        libdir = os.path.dirname(ge.LIB)
+        subprocess.check_call([hipcc, "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), src, "-L" + libdir, "-llfgpu", "-lrccl",
+                               "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_cxx_rccl_binding_example_compiles():
+    """examples/sharded_commit_rccl.cc: lfgpu_comm_ops bound to ncclAllGather / ncclSend+ncclRecv / ncclBroadcast from plain C++"""
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")) or not os.path.exists("/opt/rocm/include/rccl/rccl.h"):
+        pytest.skip("no hipcc / rccl.h")
+    _build_rccl_example()
+
+
+@pytest.mark.gpu
+def test_cxx_rccl_binding_example_one_rank(tmp_path):
+    """one rank (RCCL cannot put two on this box's one GPU): every hook goes through RCCL -- lfgpu_comm_selftest, then
+    lfgpu_ligero_commit_sharded + low_degree / quadratic / open == the one-GPU prover"""
+    exe = _build_rccl_example()
+    out = subprocess.run([exe, "0", "1", str(tmp_path / "id")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ranks"] == 1 and res["sharded_equals_one_gpu"] is True
