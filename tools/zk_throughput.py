@@ -66,6 +66,7 @@ class Worker:
         self.done = 0
         self.lat = []
         self.err = None
+        self.phases = None  # {stem.phase: summed ms} when the caller wants the provers' own phase timers
 
     def check_parity(self):
         """the fixtures' engine and seed: the wire bytes must be the reference's"""
@@ -95,6 +96,9 @@ class Worker:
             gpu._ck(L.lfgpu_zk_prove(zk.h, Wp, C.byref(ops), C.byref(ok)))
             assert ok.value == 1
             ts.close()
+            if self.phases is not None:
+                for k, v in zk.timings().items():
+                    self.phases[st["stem"] + "." + k] = self.phases.get(st["stem"] + "." + k, 0.0) + v
 
     def run(self, start_evt, stop_at):
         try:
@@ -147,7 +151,7 @@ class SmiSampler:
         return round(sum(self.vals) / len(self.vals), 1) if self.vals else None
 
 
-def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None, device=0, smi=False):
+def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None, device=0, smi=False, phases=False):
     stems = [load_stem(s) for s in JOBS[job]]
     base = {st["stem"]: pkg.Circuit(base_gpu, st["raw"]) for st in stems}
     out = {}
@@ -162,7 +166,7 @@ def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None, device=0, sm
                 workers.append(w)
             act = workers[:K]
             for w in act:
-                w.done, w.lat = 0, []
+                w.done, w.lat, w.phases = 0, [], ({} if phases else None)
             start, stop_at = threading.Event(), [0.0]
             th = [threading.Thread(target=w.run, args=(start, stop_at)) for w in act]
             for t in th:
@@ -187,6 +191,9 @@ def measure(pkg, base_gpu, job, ks, seconds, warm_jobs=2, log=None, device=0, sm
                            "ms_per_proof_latency_median": round(1e3 * lat[len(lat) // 2], 3) if lat else None}
             if sampler:
                 out[str(K)]["gpu_busy_pct_mean_rocm_smi"] = sampler.mean()
+            if phases and n:
+                keys = sorted({k for w in act for k in w.phases})
+                out[str(K)]["phase_ms_mean"] = {k: round(sum(w.phases.get(k, 0.0) for w in act) / n, 3) for k in keys}
             if log:
                 log("zk_throughput %s K=%d: %.1f proofs/s (%d proofs, median latency %.2f ms)" % (job, K, n / wall, n, 1e3 * lat[len(lat) // 2]))
     finally:
@@ -206,6 +213,7 @@ def main():
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--json", action="store_true")
     ap.add_argument("--smi", action="store_true", help="sample rocm-smi --showuse during every run")
+    ap.add_argument("--phases", action="store_true", help="mean of the provers' own phase timers (lfgpu_zk_timings) per proof")
     a = ap.parse_args()
     import __graft_entry__ as ge
     if not os.path.exists(ge.LIB):
@@ -215,7 +223,7 @@ def main():
     res = {"hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES")}
     log = (lambda s: print(s, file=sys.stderr, flush=True))
     for job in a.jobs.split(","):
-        res[job] = {"circuits": JOBS[job], "k": measure(pkg, base_gpu, job, [int(k) for k in a.k.split(",")], a.seconds, log=log, device=a.device, smi=a.smi)}
+        res[job] = {"circuits": JOBS[job], "k": measure(pkg, base_gpu, job, [int(k) for k in a.k.split(",")], a.seconds, log=log, device=a.device, smi=a.smi, phases=a.phases)}
     base_gpu.close()
     print(json.dumps(res))
 
