@@ -96,6 +96,19 @@ int lf_cu_available(const lfgpu_ctx* c);  // CUs of the device's budget nobody h
 void lf_cu_release(lfgpu_ctx* c, int n);  // n < 0: everything the context holds
 
 int lf_fail(lfgpu_ctx* c, int code, const char* fmt, ...);
+// Zeroes a host container when its scope ends.  The witness, the pads, the blinding rows of a Ligero layout and a recorded
+// RandomEngine stream are secrets of the prover; the allocator does not clear what it takes back.
+template <class V>
+struct LfScrubHost {
+  V& v;
+  explicit LfScrubHost(V& x) : v(x) {}
+  ~LfScrubHost() {
+    if (!v.empty()) explicit_bzero((void*)v.data(), v.size() * sizeof(v[0]));
+  }
+  LfScrubHost(const LfScrubHost&) = delete;
+  LfScrubHost& operator=(const LfScrubHost&) = delete;
+};
+#define LF_SCRUB_ON_EXIT(vec) LfScrubHost<decltype(vec)> lf_scrub_##vec(vec)
 #define LF_HIP(c, call)                                                                 \
   do {                                                                                  \
     hipError_t e_ = (call);                                                             \

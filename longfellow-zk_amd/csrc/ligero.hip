@@ -350,6 +350,7 @@ extern "C" int lfgpu_ligero_commit(lfgpu_ctx* c, int field, int k, const lfgpu_l
   // host image of the un-encoded rows (only the first dblock columns are ever non-trivial) + the nonces: the single-GPU
   // commit is the slab [0, nrow) of the sharded one
   std::vector<elt_t> H(p.nrow * p.dblock);
+  LF_SCRUB_ON_EXIT(H);
   {
     char err[256] = {0};
     const int rc = ligero_layout_host(field, k, g, p, (const elt_t*)h_W, subfield_boundary, h_lqc, rng, user, 0, p.nrow, H.data(),
@@ -460,6 +461,7 @@ static int layout_sharded_host(int field, int k, const GfHostCtx* g, const lfgpu
   // the RandomEngine is ONE sequential stream (ligero_prover.h:171-270, merkle_commitment.h:52-54): rank 0 draws all of it
   // (recorded while it lays out its own slab), the other ranks replay it and keep their rows
   std::vector<uint8_t> stream;
+  LF_SCRUB_ON_EXIT(stream);
   if (cm->rank == 0) {  // rank 0 lays out its own slab while it draws: one pass, and the others wait for nothing else
     RecordRng rec{rng, user, &stream};
     const int rc = ligero_layout_host(field, k, g, p, (const elt_t*)h_W, subfield_boundary, h_lqc, record_fn, &rec, row_lo, row_hi, H, nonces, err, exact);
@@ -527,9 +529,17 @@ extern "C" int lfgpu_ligero_commit_sharded(lfgpu_ctx* c, int field, int k, const
   void* d_send = nullptr;
   void* d_cols = nullptr;
   size_t send_bytes_tot = 0, cols_bytes = 0;
+  // the exchange buffers hold encoded rows of the tableau (witness, pads, blinding rows): scrubbed like the tableau itself
+  // (lfgpu_ligero_free) before they go back to the pool, in stream order behind their last use
+  auto retire = [&](void*& d, size_t bytes) {
+    if (!d) return;
+    (void)hipMemsetAsync(d, 0, bytes, c->stream);
+    lf_pool_put(c, d, bytes);
+    d = nullptr;
+  };
   auto fail = [&](int rc) {
-    if (d_send) lf_pool_put(c, d_send, send_bytes_tot);
-    if (d_cols) lf_pool_put(c, d_cols, cols_bytes);
+    retire(d_send, send_bytes_tot);
+    retire(d_cols, cols_bytes);
     lfgpu_ligero_free(pr);
     return rc;
   };
@@ -540,6 +550,7 @@ extern "C" int lfgpu_ligero_commit_sharded(lfgpu_ctx* c, int field, int k, const
   double tv1 = tv0, tv2 = tv0, tv3 = tv0, tv4 = tv0;
   // 1. host layout of this rank's slab from the one random stream
   std::vector<elt_t> H(std::max<size_t>(nr, 1) * p.dblock);
+  LF_SCRUB_ON_EXIT(H);
   {
     char err[256] = {0};
     const int rc = layout_sharded_host(field, k, g, p, h_W, subfield_boundary, h_lqc, rng, user, cm, c->rng_exact != 0, pr->row_lo, pr->row_hi, H.data(),
@@ -610,8 +621,8 @@ extern "C" int lfgpu_ligero_commit_sharded(lfgpu_ctx* c, int field, int k, const
   if (verbose)
     fprintf(stderr, "lfgpu ligero_commit_sharded rank %d/%d: rows [%zu, %zu): layout + stream %.2f ms | upload + RS encode + pack %.2f | all_to_all %.2f | leaves + all_gather + tree %.2f\n",
             rank, world, pr->row_lo, pr->row_hi, tv1 - tv0, tv2 - tv1, tv3 - tv2, tv4 - tv3);
-  lf_pool_put(c, d_send, send_bytes_tot);
-  lf_pool_put(c, d_cols, cols_bytes);
+  retire(d_send, send_bytes_tot);
+  retire(d_cols, cols_bytes);
   *out = pr;
   return LFGPU_OK;
 }

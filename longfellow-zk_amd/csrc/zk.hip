@@ -702,6 +702,7 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
     // it is above the threshold (lig256_commit; the mdoc signature circuit's 2.5 MB tableau normally stays replicated)
     if (!(zk->have_comm && zk->comm.world > 1)) return zk256_commit(zk->z256, h_W, rng, rng_user, ts, root_out);
     std::vector<uint8_t> stream;
+    LF_SCRUB_ON_EXIT(stream);
     alignas(16) unsigned char store[64];
     lfgpu_rng_fn r2 = rng;
     void* u2 = rng_user;
@@ -729,6 +730,7 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
   const bool multi = zk->have_comm && zk->comm.world > 1;
   const bool shard_rows = multi && zk->param.nrow * zk->param.block_enc * 16 >= zk->comm_min_bytes;
   std::vector<uint8_t> pad_stream;
+  LF_SCRUB_ON_EXIT(pad_stream);
   alignas(16) unsigned char rng_store[64];
   if (multi) {
     if (zk->comm.rank == 0) {
@@ -743,7 +745,8 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
   };
   // witness = private inputs || pad; fill_pad draws, per layer: (t0, t2) for hand 0 then hand 1 of every round,
   // then wc0, wc1 and stores wc0*wc1 (zk_prover.h:152-188, logc = 0)
-  std::vector<elt_t> Wv(zk->param.nw);
+  std::vector<elt_t> Wv(zk->param.nw);  // witness || pads
+  LF_SCRUB_ON_EXIT(Wv);
   memcpy(Wv.data(), (const elt_t*)h_W + zk->npub, zk->n_witness * 16);
   zk->pad.assign(nl, {});
   zk->lqc.assign(3 * nl, 0);
@@ -772,6 +775,8 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
     zk->lqc[3 * ly + 2] = cp + 2;
     pi += layer_size(logw);
   }
+  // (rank 0 first sends what the other ranks are waiting for, whatever went wrong here)
+  if (multi && zk->comm.rank == 0 && lf_comm_bcast_blob(&zk->comm, pad_stream)) return lf_fail(c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
   if (pi != zk->param.nw) return lf_fail(c, LFGPU_ERR_ASSERT, "zk_commit: witness layout");
   const size_t sfb = C->info.subfield_boundary >= zk->npub ? C->info.subfield_boundary - zk->npub : 0;
   if (zk->lp) {
@@ -780,12 +785,12 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
   }
   zk->have_proof = false;
   zk->wire_valid = false;
-  if (multi && zk->comm.rank == 0 && lf_comm_bcast_blob(&zk->comm, pad_stream)) return lf_fail(c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
   if (shard_rows) {
     LF_TRY(lfgpu_ligero_commit_sharded(c, field, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), rng, rng_user, &zk->comm, zk->root, &zk->lp));
   } else if (multi) {  // a small tableau stays whole on every rank (replicas): the one random stream still comes from rank 0
     lfgpu_comm_ops one = zk->comm;
     std::vector<uint8_t> lig_stream;
+    LF_SCRUB_ON_EXIT(lig_stream);
     alignas(16) unsigned char st2[64];
     lfgpu_rng_fn r2 = rng;
     void* u2 = rng_user;
@@ -794,8 +799,10 @@ extern "C" int lfgpu_zk_commit(lfgpu_zk_prover* zk, const void* h_W, lfgpu_rng_f
       if (lf_comm_bcast_blob(&one, lig_stream)) return lf_fail(c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
       lf_replay_rng(&lig_stream, &r2, &u2, st2);
     }
-    LF_TRY(lfgpu_ligero_commit(c, field, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), r2, u2, zk->root, &zk->lp));
+    const int rc = lfgpu_ligero_commit(c, field, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), r2, u2, zk->root, &zk->lp);
+    // (also after a failed commit: the other ranks are waiting in this broadcast)
     if (zk->comm.rank == 0 && lf_comm_bcast_blob(&one, lig_stream)) return lf_fail(c, LFGPU_ERR_HIP, "zk_commit: broadcast hook failed");
+    if (rc) return rc;
   } else {
     LF_TRY(lfgpu_ligero_commit(c, field, 4, &zk->param, Wv.data(), sfb, zk->lqc.data(), rng, rng_user, zk->root, &zk->lp));
   }

@@ -1582,6 +1582,7 @@ int lig256_commit(lfgpu_ctx* c, const lfgpu_ligero_param& p, const E* W, const s
     L->row_hi = L->spans[rank].second;
   }
   std::vector<E> H(p.nrow * p.dblock);
+  LF_SCRUB_ON_EXIT(H);
   char err[256] = {0};
   const int rc = lig256_layout(p, W, lqc, rng, user, H.data(), L->nonces.data(), err, c->rng_exact != 0);
   if (rc) return lf_fail(c, rc, "%s", err);
@@ -1632,7 +1633,9 @@ int lig256_commit(lfgpu_ctx* c, const lfgpu_ligero_param& p, const E* W, const s
     lf_pool_put(c, d_send, send_bytes);
     return lf_fail(c, LFGPU_ERR_NOMEM, "ligero256 (sharded): exchange buffers");
   }
-  auto done = [&](int code) {
+  auto done = [&](int code) {  // encoded rows of the tableau: scrubbed like the tableau before they go back to the pool
+    (void)hipMemsetAsync(d_send, 0, send_bytes, c->stream);
+    (void)hipMemsetAsync(d_cols, 0, cols_bytes, c->stream);
     lf_pool_put(c, d_send, send_bytes);
     lf_pool_put(c, d_cols, cols_bytes);
     return code;
@@ -2120,11 +2123,13 @@ int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, co
   const size_t nl = C->layers.size();
   LF_HIP(c, hipSetDevice(c->device));
   std::vector<E> pads(z->pad_size - nl);  // every element fill_pad draws (the product wc0 * wc1 is computed), in order
+  LF_SCRUB_ON_EXIT(pads);
   if (c->rng_exact) for (size_t i = 0; i < pads.size(); ++i) h256_sample_many(&pads[i], 1, [&](uint8_t* b, size_t n) { rng(rng_user, b, n); });
   else h256_sample_many(pads.data(), pads.size(), [&](uint8_t* b, size_t n) { rng(rng_user, b, n); });
   size_t pd = 0;
   auto draw = [&] { return pads[pd++]; };
-  std::vector<E> Wv(z->param.nw);
+  std::vector<E> Wv(z->param.nw);  // witness || pads
+  LF_SCRUB_ON_EXIT(Wv);
   memcpy(Wv.data(), (const E*)h_W + z->npub, z->n_witness * 32);
   z->pad.assign(nl, {});
   z->lqc.assign(3 * nl, 0);
@@ -2156,6 +2161,7 @@ int zk256_commit(Zk256* z, const void* h_W, lfgpu_rng_fn rng, void* rng_user, co
   if (pi != z->param.nw) return lf_fail(c, LFGPU_ERR_ASSERT, "zk256_commit: witness layout");
   if (draws_only) {
     std::vector<E> H(z->param.nrow * z->param.dblock);
+    LF_SCRUB_ON_EXIT(H);
     std::vector<uint8_t> nz(32 * z->param.block_ext);
     char err[256] = {0};
     const int rc = lig256_layout(z->param, Wv.data(), z->lqc.data(), rng, rng_user, H.data(), nz.data(), err, c->rng_exact != 0);

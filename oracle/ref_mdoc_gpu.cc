@@ -115,6 +115,158 @@ static int verify_both(HashVerifier& hash_v, SigVerifier& sig_v, const Circuit<f
   return ok && ok2 ? 1 : 0;
 }
 
+// ---- the reference's own STORED mdoc proofs (rust/applications/mdoc_zk/artifacts/proofs/<circuit hash>{.bin, _hash_witness.bin,
+// _sig_witness.bin}; loaded by rust/applications/mdoc_zk/runtime/tests/all/prior_zk.rs:131-145).  The artifact of kZkSpecs[i] is the
+// proof that run_mdoc_prover_inner (rust/applications/mdoc_zk/runtime/src/prover.rs:53-215) makes for mdoc_tests[3] and the first
+// num_attributes of {family_name, birth_date, issue_date, height} with DeterministicRng(42)
+// (rust/runtime/random/src/deterministic.rs:18-41): that engine's first 96 bytes are generate_mac_ap's six u128, the rest feeds
+// hash commit, then signature commit.  With the stored witnesses (whole input vectors, public part included) the reference's C++
+// provers reproduce the stored 360 596 bytes exactly (checked in the build container); here lfgpu::GpuZkProver must, and
+// lfgpu::GpuZkVerifier must accept the stored bytes inside run_mdoc_verifier's body.
+class RustDeterministicRng : public RandomEngine {
+ public:
+  explicit RustDeterministicRng(uint64_t seed) : s_(seed) {}
+  void bytes(uint8_t* buf, size_t n) override {
+    for (size_t i = 0; i < n; ++i) {
+      s_ = s_ * 6364136223846793005ull + 1ull;
+      buf[i] = static_cast<uint8_t>(s_ >> 56);
+    }
+  }
+
+ private:
+  uint64_t s_;
+};
+static std::vector<uint8_t> slurp(const char* path) {
+  std::vector<uint8_t> v;
+  FILE* f = fopen(path, "rb");
+  if (!f) return v;
+  v.resize(size_t(1) << 23);
+  v.resize(fread(v.data(), 1, v.size(), f));
+  fclose(f);
+  return v;
+}
+template <class HashProver, class SigProver>
+static bool prove_stored(HashProver& hash_p, SigProver& sig_p, const Circuit<f_128>& c_hash, const Circuit<Fp256Base>& c_sig, Dense<f_128>& W_hash,
+                         Dense<Fp256Base>& W_sig, const MdocTests* test, const RequestedAttribute* attrs, size_t attrs_len, const Elt& pkX, const Elt& pkY,
+                         const ZkSpecStruct* zk_spec, const std::vector<uint8_t>& stored, const f_128& Fs, std::vector<uint8_t>& buf, double ms[2]) {
+  gf2k macs[6];  // public: the head of the proof string
+  for (size_t i = 0; i < 6; ++i) macs[i] = Fs.of_bytes_field(&stored[f_128::kBytes * i]).value();
+  Transcript tp(test->transcript, test->transcript_size, zk_spec->version);
+  RustDeterministicRng rng(42);
+  uint8_t mac_ap[96];
+  rng.bytes(mac_ap, sizeof(mac_ap));  // generate_mac_ap (mac.rs:18-22)
+  const size_t r = zk_spec->version < 7 ? kLigeroRate : kLigeroRatev7;
+  const size_t req = zk_spec->version < 7 ? kLigeroNreq : kLigeroNreqv7;
+  ZkProof<f_128> h_zk(c_hash, r, req, zk_spec->block_enc_hash);
+  ZkProof<Fp256Base> sig_zk(c_sig, r, req, zk_spec->block_enc_sig);
+  const double t0 = now_ms();
+  hash_p.commit(h_zk, W_hash, tp, rng);
+  sig_p.commit(sig_zk, W_sig, tp, rng);
+  const double t1 = now_ms();
+  gf2k av = generate_mac_key(tp);
+  {  // the public inputs as the verifier builds them (the stored witnesses already hold exactly these)
+    auto pub_hash = Dense<f_128>(1, c_hash.npub_in);
+    auto pub_sig = Dense<Fp256Base>(1, c_sig.npub_in);
+    DenseFiller<f_128> hf(pub_hash);
+    DenseFiller<Fp256Base> sf(pub_sig);
+    if (!fill_public_inputs(sf, hf, pkX, pkY, test->transcript, test->transcript_size, attrs, attrs_len, (const uint8_t*)test->now, (const uint8_t*)test->doc_type,
+                            strlen(test->doc_type), macs, av, Fs, zk_spec->version))
+      return false;
+    if (hf.size() != c_hash.npub_in || sf.size() != c_sig.npub_in) return false;
+    for (size_t i = 0; i < c_hash.npub_in; ++i) W_hash.v_[i] = pub_hash.v_[i];
+    for (size_t i = 0; i < c_sig.npub_in; ++i) W_sig.v_[i] = pub_sig.v_[i];
+  }
+  const double t2 = now_ms();
+  if (!hash_p.prove(h_zk, W_hash, tp)) return false;
+  if (!sig_p.prove(sig_zk, W_sig, tp)) return false;
+  ms[0] = t1 - t0;
+  ms[1] = now_ms() - t2;
+  buf.assign(stored.begin(), stored.begin() + 6 * f_128::kBytes);
+  h_zk.write(buf, Fs);
+  sig_zk.write(buf, p256_base);
+  return true;
+}
+int mdoc_stored(int spec, const char* proof_path, const char* hash_w_path, const char* sig_w_path, bool with_ref) {
+  set_log_level(ERROR);
+  if (spec < 0 || spec >= (int)kNumZkSpecs) return 2;
+  const ZkSpecStruct* zk_spec = &kZkSpecs[spec];
+  const std::vector<uint8_t> stored = slurp(proof_path), wh = slurp(hash_w_path), wsg = slurp(sig_w_path);
+  if (stored.size() < 96 || wh.empty() || wsg.empty()) return 2;
+  uint8_t* bcp;
+  size_t bcsz;
+  if (generate_circuit(zk_spec, &bcp, &bcsz) != CIRCUIT_GENERATION_SUCCESS) return 3;
+  const MdocTests* test = &mdoc_tests[3];
+  const RequestedAttribute attrs[4] = {test::familyname_mustermann, test::birthdate_1971_09_01, test::issue_date_2024_03_15, test::height_175};
+  const size_t attrs_len = zk_spec->num_attributes;
+  Elt pkX, pkY;
+  if (!parsePk(test->pkx.as_pointer, test->pky.as_pointer, pkX, pkY)) return 4;
+  const f2_p256 p256_2(p256_base);
+  const f_128 Fs;
+  std::vector<uint8_t> bytes(kCircuitSizeMax);
+  const size_t full_size = decompress(bytes, bcp, bcsz);
+  if (full_size == 0) return 5;
+  ReadBuffer rb(bytes.data(), full_size);
+  CircuitReader<Fp256Base> cr_s(p256_base, P256_ID);
+  auto c_sig = cr_s.from_bytes(rb, false);
+  const size_t sig_len = full_size - rb.remaining();
+  CircuitReader<f_128> cr_h(Fs, GF2_128_ID);
+  auto c_hash = cr_h.from_bytes(rb, false);
+  const size_t hash_len = full_size - rb.remaining() - sig_len;
+  if (!c_sig || !c_hash) return 6;
+  if (wh.size() != f_128::kBytes * c_hash->ninputs || wsg.size() != Fp256Base::kBytes * c_sig->ninputs) return 7;
+  auto W_sig = Dense<Fp256Base>(1, c_sig->ninputs);
+  auto W_hash = Dense<f_128>(1, c_hash->ninputs);
+  for (size_t i = 0; i < c_hash->ninputs; ++i) {
+    auto e = Fs.of_bytes_field(&wh[f_128::kBytes * i]);
+    if (!e.has_value()) return 8;
+    W_hash.v_[i] = e.value();
+  }
+  for (size_t i = 0; i < c_sig->ninputs; ++i) {
+    auto e = p256_base.of_bytes_field(&wsg[Fp256Base::kBytes * i]);
+    if (!e.has_value()) return 8;
+    W_sig.v_[i] = e.value();
+  }
+  const size_t r = zk_spec->version < 7 ? kLigeroRate : kLigeroRatev7;
+  const size_t req = zk_spec->version < 7 ? kLigeroNreq : kLigeroNreqv7;
+  std::vector<uint8_t> proof_ref, proof_gpu;
+  double ms_ref[2] = {0, 0}, ms_gpu[2] = {0, 0}, ms_gpu_verify = 0, dummy;
+  if (with_ref) {  // the reference's provers (one CPU thread, ~20 s): the artifact pins the reference itself
+    const Elt2 omega = p256_2.of_string(kRootX, kRootY);
+    const FftExtConvolutionFactory fft_b(p256_base, p256_2, omega, 1ull << 31);
+    const RSFactory_b rsf_b(fft_b, p256_base);
+    const RSFactory rsf(Fs);
+    ZkProver<f_128, RSFactory> hash_p(*c_hash, Fs, rsf);
+    ZkProver<Fp256Base, RSFactory_b> sig_p(*c_sig, p256_base, rsf_b);
+    if (!prove_stored(hash_p, sig_p, *c_hash, *c_sig, W_hash, W_sig, test, attrs, attrs_len, pkX, pkY, zk_spec, stored, Fs, proof_ref, ms_ref)) return 9;
+  }
+  int verdict = -9, verdict_bad = -9;
+  {
+    lfgpu::Context ctx(0);
+    lfgpu::GpuZkProver<Fp256Base, ReadBuffer> sig_p(ctx, bytes.data(), sig_len, p256_base);
+    lfgpu::GpuZkProver<f_128, ReadBuffer> hash_p(ctx, bytes.data() + sig_len, hash_len, Fs);
+    for (int rep = 0; rep < 2; ++rep)
+      if (!prove_stored(hash_p, sig_p, *c_hash, *c_sig, W_hash, W_sig, test, attrs, attrs_len, pkX, pkY, zk_spec, stored, Fs, proof_gpu, ms_gpu)) return 10;
+    lfgpu::GpuZkVerifier<Fp256Base> sig_v(ctx, bytes.data(), sig_len, r, req, zk_spec->block_enc_sig, p256_base);
+    lfgpu::GpuZkVerifier<f_128> hash_v(ctx, bytes.data() + sig_len, hash_len, r, req, zk_spec->block_enc_hash, Fs);
+    verdict = verify_both(hash_v, sig_v, *c_hash, *c_sig, stored, test, attrs, attrs_len, pkX, pkY, zk_spec, Fs, &ms_gpu_verify);
+    std::vector<uint8_t> bad = stored;
+    bad[bad.size() / 2] ^= 1;
+    verdict_bad = verify_both(hash_v, sig_v, *c_hash, *c_sig, bad, test, attrs, attrs_len, pkX, pkY, zk_spec, Fs, &dummy);
+  }
+  printf(
+      "{\"stored_artifact\": \"%s\", \"spec\": %d, \"version\": %zu, \"attributes\": %zu, \"stored_bytes\": %zu, \"stored_sha256\": \"%s\", \"gpu_bytes\": %zu, "
+      "\"gpu_proof_identical_to_stored\": %s, \"reference_prover_ran\": %s, \"reference_proof_identical_to_stored\": %s, "
+      "\"gpu_verifiers_accept_stored\": %s, \"gpu_verifiers_reject_flipped_bit\": %s, "
+      "\"gpu_ms\": {\"commit\": %.2f, \"prove\": %.2f, \"verify\": %.2f}, \"ref_ms\": {\"commit\": %.2f, \"prove\": %.2f}}\n",
+      zk_spec->circuit_hash, spec, (size_t)zk_spec->version, attrs_len, stored.size(), sha_hex(stored).c_str(), proof_gpu.size(), proof_gpu == stored ? "true" : "false",
+      with_ref ? "true" : "false", with_ref && proof_ref == stored ? "true" : "false", verdict == 1 ? "true" : "false", verdict_bad == 0 ? "true" : "false", ms_gpu[0], ms_gpu[1],
+      ms_gpu_verify, ms_ref[0], ms_ref[1]);
+  free(bcp);
+  if (proof_gpu != stored) return 11;
+  if (with_ref && proof_ref != stored) return 12;
+  return verdict == 1 && verdict_bad == 0 ? 0 : 13;
+}
+
 // which of the reference's own examples (mdoc_zk_test.cc:118-240): 0 = kZkSpecs[0], mdoc_tests[0], age_over_18 (the BASELINE
 // config); 1 = kZkSpecs[0], mdoc_tests[3], familyname_mustermann (another document, a text attribute); 2 = kZkSpecs[1] -- the
 // TWO-attribute circuits, a different pair of circuits -- mdoc_tests[3], age_over_18 + familyname_mustermann
@@ -239,6 +391,8 @@ int mdoc_gpu(int reps, bool with_ref, int which) {
 }  // namespace proofs
 
 int main(int argc, char** argv) {
+  if (argc >= 6 && std::string(argv[1]) == "stored")  // stored <spec> <proof> <hash witness> <sig witness> [--with-ref]
+    return proofs::mdoc_stored(atoi(argv[2]), argv[3], argv[4], argv[5], argc > 6 && std::string(argv[6]) == "--with-ref");
   const int reps = argc > 1 ? atoi(argv[1]) : 2;
   const bool with_ref = !(argc > 2 && std::string(argv[2]) == "--no-ref");
   const int which = argc > 3 ? atoi(argv[3]) : 0;

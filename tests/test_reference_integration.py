@@ -98,6 +98,50 @@ def test_mdoc_end_to_end_with_gpu_provers_in_run_mdoc_prover(which, reps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("idx", [0, 1], ids=["v7_one_attribute", "v7_two_attributes"])
+def test_reference_stored_mdoc_proofs_reproduced_and_verified(tmp_path, idx):
+    """The reference's own STORED mdoc proofs (rust/applications/mdoc_zk/artifacts/proofs/<circuit hash>.bin with both witness files,
+    the fixtures of its prior_zk.rs test; committed under tests/golden/ by oracle/gen_mdoc_artifact_fixtures.py): complete proofs of
+    BASELINE config 5 -- MACs, hash circuit over GF2_128, signature circuit over Fp256Base, one shared transcript.  From the stored
+    input vectors and the reference's DeterministicRng(42), lfgpu::GpuZkProver inside run_mdoc_prover's body must write exactly the
+    stored bytes (the reference's C++ provers do: checked in the build container, oracle/ref_mdoc_gpu.cc `stored ... --with-ref`),
+    and lfgpu::GpuZkVerifier inside run_mdoc_verifier's body must accept the stored bytes and reject them with one bit flipped."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "mdoc_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/mdoc_gpu not built (needs the reference sources and zstd.h: make -C oracle ref in the build container)")
+    spec = json.load(open(os.path.join(GOLD, "mdoc_artifacts.json")))["specs"][idx]
+    stem = os.path.join(GOLD, spec["stem"])
+    hw, sw = tmp_path / "hash_w.bin", tmp_path / "sig_w.bin"
+    hw.write_bytes(lzma.decompress(open(stem + ".hash_witness.xz", "rb").read()))
+    sw.write_bytes(lzma.decompress(open(stem + ".sig_witness.xz", "rb").read()))
+    out = subprocess.run([exe, "stored", str(spec["zk_spec_index"]), stem + ".proof.bin", str(hw), str(sw)], capture_output=True, timeout=900)
+    assert out.returncode == 0, (out.returncode, out.stdout.decode()[-1000:], out.stderr.decode()[-2000:])
+    res = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    print("stored mdoc artifact:", res)
+    assert res["stored_artifact"] == spec["circuit_hash"] and res["stored_sha256"] == spec["proof_sha256"] and res["stored_bytes"] == spec["proof_bytes"]
+    assert res["gpu_proof_identical_to_stored"] is True
+    assert res["gpu_verifiers_accept_stored"] is True and res["gpu_verifiers_reject_flipped_bit"] is True
+
+
+def test_reference_stored_mdoc_fixtures_are_the_reference_files():
+    """the committed fixtures are byte copies of the reference's artifact files (manifest hashes; the witnesses decompress to them)"""
+    import hashlib
+    man = json.load(open(os.path.join(GOLD, "mdoc_artifacts.json")))
+    for spec in man["specs"]:
+        stem = os.path.join(GOLD, spec["stem"])
+        proof = open(stem + ".proof.bin", "rb").read()
+        assert len(proof) == spec["proof_bytes"] and hashlib.sha256(proof).hexdigest() == spec["proof_sha256"]
+        hw = lzma.decompress(open(stem + ".hash_witness.xz", "rb").read())
+        sw = lzma.decompress(open(stem + ".sig_witness.xz", "rb").read())
+        assert len(hw) == 16 * spec["hash_witness_elements"] and hashlib.sha256(hw).hexdigest() == spec["hash_witness_sha256"]
+        assert len(sw) == 32 * spec["sig_witness_elements"] and hashlib.sha256(sw).hexdigest() == spec["sig_witness_sha256"]
+        src = os.path.join("/root/reference/rust/applications/mdoc_zk/artifacts/proofs", spec["circuit_hash"])
+        if os.path.exists(src + ".bin"):  # the build container: compare with the reference's files where they lie
+            assert open(src + ".bin", "rb").read() == proof
+            assert open(src + "_hash_witness.bin", "rb").read() == hw and open(src + "_sig_witness.bin", "rb").read() == sw
+
+
+@pytest.mark.gpu
 def test_remaining_adapters_executed_against_the_reference_classes():
     """lfgpu::GpuFFT, GpuLCH14, GpuMerkleCommitment (commit + open) and GpuSumcheckRound (partials, Dense::bind, HQuad::bind_h)
     run next to FFT<Fp128>, LCH14<GF2_128<4>>, MerkleCommitment with LigeroCommon::column_hash, and ProverLayers::evaluations /
