@@ -186,15 +186,25 @@ static bool prove_stored(HashProver& hash_p, SigProver& sig_p, const Circuit<f_1
   sig_zk.write(buf, p256_base);
   return true;
 }
-int mdoc_stored(int spec, const char* proof_path, const char* hash_w_path, const char* sig_w_path, bool with_ref) {
+// circuit_path: the compressed circuit pair as the reference ships it (rust/applications/mdoc_zk/artifacts/circuits/<hash>) for the
+// older specs whose circuits generate_circuit no longer builds; nullptr = generate_circuit(zk_spec)
+int mdoc_stored(int spec, const char* proof_path, const char* hash_w_path, const char* sig_w_path, const char* circuit_path, bool with_ref) {
   set_log_level(ERROR);
   if (spec < 0 || spec >= (int)kNumZkSpecs) return 2;
   const ZkSpecStruct* zk_spec = &kZkSpecs[spec];
   const std::vector<uint8_t> stored = slurp(proof_path), wh = slurp(hash_w_path), wsg = slurp(sig_w_path);
   if (stored.size() < 96 || wh.empty() || wsg.empty()) return 2;
-  uint8_t* bcp;
-  size_t bcsz;
-  if (generate_circuit(zk_spec, &bcp, &bcsz) != CIRCUIT_GENERATION_SUCCESS) return 3;
+  uint8_t* bcp = nullptr;
+  size_t bcsz = 0;
+  std::vector<uint8_t> cfile;
+  if (circuit_path) {
+    cfile = slurp(circuit_path);
+    if (cfile.empty()) return 3;
+    bcp = cfile.data();
+    bcsz = cfile.size();
+  } else if (generate_circuit(zk_spec, &bcp, &bcsz) != CIRCUIT_GENERATION_SUCCESS) {
+    return 3;
+  }
   const MdocTests* test = &mdoc_tests[3];
   const RequestedAttribute attrs[4] = {test::familyname_mustermann, test::birthdate_1971_09_01, test::issue_date_2024_03_15, test::height_175};
   const size_t attrs_len = zk_spec->num_attributes;
@@ -261,7 +271,7 @@ int mdoc_stored(int spec, const char* proof_path, const char* hash_w_path, const
       zk_spec->circuit_hash, spec, (size_t)zk_spec->version, attrs_len, stored.size(), sha_hex(stored).c_str(), proof_gpu.size(), proof_gpu == stored ? "true" : "false",
       with_ref ? "true" : "false", with_ref && proof_ref == stored ? "true" : "false", verdict == 1 ? "true" : "false", verdict_bad == 0 ? "true" : "false", ms_gpu[0], ms_gpu[1],
       ms_gpu_verify, ms_ref[0], ms_ref[1]);
-  free(bcp);
+  if (!circuit_path) free(bcp);
   if (proof_gpu != stored) return 11;
   if (with_ref && proof_ref != stored) return 12;
   return verdict == 1 && verdict_bad == 0 ? 0 : 13;
@@ -391,8 +401,15 @@ int mdoc_gpu(int reps, bool with_ref, int which) {
 }  // namespace proofs
 
 int main(int argc, char** argv) {
-  if (argc >= 6 && std::string(argv[1]) == "stored")  // stored <spec> <proof> <hash witness> <sig witness> [--with-ref]
-    return proofs::mdoc_stored(atoi(argv[2]), argv[3], argv[4], argv[5], argc > 6 && std::string(argv[6]) == "--with-ref");
+  if (argc >= 6 && std::string(argv[1]) == "stored") {  // stored <spec> <proof> <hash witness> <sig witness> [--circuit <file>] [--with-ref]
+    const char* circuit = nullptr;
+    bool with_ref = false;
+    for (int i = 6; i < argc; ++i) {
+      if (std::string(argv[i]) == "--with-ref") with_ref = true;
+      if (std::string(argv[i]) == "--circuit" && i + 1 < argc) circuit = argv[++i];
+    }
+    return proofs::mdoc_stored(atoi(argv[2]), argv[3], argv[4], argv[5], circuit, with_ref);
+  }
   const int reps = argc > 1 ? atoi(argv[1]) : 2;
   const bool with_ref = !(argc > 2 && std::string(argv[2]) == "--no-ref");
   const int which = argc > 3 ? atoi(argv[3]) : 0;

@@ -98,7 +98,7 @@ def test_mdoc_end_to_end_with_gpu_provers_in_run_mdoc_prover(which, reps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("idx", [0, 1], ids=["v7_one_attribute", "v7_two_attributes"])
+@pytest.mark.parametrize("idx", [0, 1, 2], ids=["v7_one_attribute", "v7_two_attributes", "v6_one_attribute_shipped_circuit"])
 def test_reference_stored_mdoc_proofs_reproduced_and_verified(tmp_path, idx):
     """The reference's own STORED mdoc proofs (rust/applications/mdoc_zk/artifacts/proofs/<circuit hash>.bin with both witness files,
     the fixtures of its prior_zk.rs test; committed under tests/golden/ by oracle/gen_mdoc_artifact_fixtures.py): complete proofs of
@@ -114,7 +114,8 @@ def test_reference_stored_mdoc_proofs_reproduced_and_verified(tmp_path, idx):
     hw, sw = tmp_path / "hash_w.bin", tmp_path / "sig_w.bin"
     hw.write_bytes(lzma.decompress(open(stem + ".hash_witness.xz", "rb").read()))
     sw.write_bytes(lzma.decompress(open(stem + ".sig_witness.xz", "rb").read()))
-    out = subprocess.run([exe, "stored", str(spec["zk_spec_index"]), stem + ".proof.bin", str(hw), str(sw)], capture_output=True, timeout=900)
+    extra = ["--circuit", stem + ".circuit.zst"] if spec["circuit_file_bytes"] else []  # version 6: the circuit pair as the reference ships it
+    out = subprocess.run([exe, "stored", str(spec["zk_spec_index"]), stem + ".proof.bin", str(hw), str(sw)] + extra, capture_output=True, timeout=900)
     assert out.returncode == 0, (out.returncode, out.stdout.decode()[-1000:], out.stderr.decode()[-2000:])
     res = json.loads(out.stdout.decode().strip().splitlines()[-1])
     print("stored mdoc artifact:", res)
@@ -136,6 +137,9 @@ def test_reference_stored_mdoc_fixtures_are_the_reference_files():
         assert len(hw) == 16 * spec["hash_witness_elements"] and hashlib.sha256(hw).hexdigest() == spec["hash_witness_sha256"]
         assert len(sw) == 32 * spec["sig_witness_elements"] and hashlib.sha256(sw).hexdigest() == spec["sig_witness_sha256"]
         src = os.path.join("/root/reference/rust/applications/mdoc_zk/artifacts/proofs", spec["circuit_hash"])
+        if spec["circuit_file_bytes"]:
+            circ = open(stem + ".circuit.zst", "rb").read()
+            assert len(circ) == spec["circuit_file_bytes"] and hashlib.sha256(circ).hexdigest() == spec["circuit_file_sha256"]
         if os.path.exists(src + ".bin"):  # the build container: compare with the reference's files where they lie
             assert open(src + ".bin", "rb").read() == proof
             assert open(src + "_hash_witness.bin", "rb").read() == hw and open(src + "_sig_witness.bin", "rb").read() == sw
