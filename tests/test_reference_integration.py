@@ -145,6 +145,19 @@ def test_reference_stored_mdoc_fixtures_are_the_reference_files():
             assert open(src + "_hash_witness.bin", "rb").read() == hw and open(src + "_sig_witness.bin", "rb").read() == sw
 
 
+def test_reference_cpp_provers_reproduce_a_stored_mdoc_proof():
+    """CPU, build container only (reads the reference's artifact files where they lie): the reference's own C++ provers inside
+    run_mdoc_prover's flow write exactly the stored proof string -- which is what makes the stored files known-answer vectors
+    (oracle/ref_mdoc_stored_cpu.cc; all twelve specs reproduce, one is run here: version 6, circuit from the artifact file)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "mdoc_stored_cpu")
+    if not os.path.exists(exe) or not os.path.isdir("/root/reference/rust/applications/mdoc_zk/artifacts/proofs"):
+        pytest.skip("needs oracle/_ref/mdoc_stored_cpu and the reference tree (build container)")
+    out = subprocess.run([exe, "4"], capture_output=True, timeout=600)
+    assert out.returncode == 0, (out.returncode, out.stdout.decode()[-500:], out.stderr.decode()[-1000:])
+    res = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert res["identical"] is True and res["public_inputs_differing_from_stored"] == 0 and res["stored_bytes"] == 323932
+
+
 @pytest.mark.gpu
 def test_remaining_adapters_executed_against_the_reference_classes():
     """lfgpu::GpuFFT, GpuLCH14, GpuMerkleCommitment (commit + open) and GpuSumcheckRound (partials, Dense::bind, HQuad::bind_h)
