@@ -22,6 +22,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 SPECS = [  # (index in kZkSpecs, circuit hash, version, attributes, ship the circuit file too)
     (0, "8d079211715200ff06c5109639245502bfe94aa869908d31176aae4016182121", 7, 1, False),
     (1, "6a5810683e62b6d7766ebd0d7ca72518a2b8325418142adcadb10d51dbbcd5ad", 7, 2, False),
+    (3, "5aebdaaafe17296a3ef3ca6c80c6e7505e09291897c39700410a365fb278e460", 7, 4, False),  # the largest pair of circuits
     # version 6: other Ligero parameters (rate 4, 189 opened columns, block_enc_sig 2945); the C++ generate_circuit no longer builds
     # these circuits, so the compressed circuit pair the reference ships (artifacts/circuits/<hash>) travels with the fixture
     (4, "137e5a75ce72735a37c8a72da1a8a0a5df8d13365c2ae3d2c2bd6a0e7197c7c6", 6, 1, True),

@@ -259,9 +259,14 @@ int mdoc_stored(int spec, const char* proof_path, const char* hash_w_path, const
     lfgpu::GpuZkVerifier<Fp256Base> sig_v(ctx, bytes.data(), sig_len, r, req, zk_spec->block_enc_sig, p256_base);
     lfgpu::GpuZkVerifier<f_128> hash_v(ctx, bytes.data() + sig_len, hash_len, r, req, zk_spec->block_enc_hash, Fs);
     verdict = verify_both(hash_v, sig_v, *c_hash, *c_sig, stored, test, attrs, attrs_len, pkX, pkY, zk_spec, Fs, &ms_gpu_verify);
-    std::vector<uint8_t> bad = stored;
-    bad[bad.size() / 2] ^= 1;
-    verdict_bad = verify_both(hash_v, sig_v, *c_hash, *c_sig, bad, test, attrs, attrs_len, pkX, pkY, zk_spec, Fs, &dummy);
+    // one flipped bit in a MAC (a public input of both circuits), in the hash-circuit proof and in the signature-circuit proof:
+    // every one must be rejected (a parse failure counts as a rejection)
+    verdict_bad = 0;
+    for (size_t pos : {size_t(40), stored.size() / 2, stored.size() - 60000}) {
+      std::vector<uint8_t> bad = stored;
+      bad[pos] ^= 1;
+      if (verify_both(hash_v, sig_v, *c_hash, *c_sig, bad, test, attrs, attrs_len, pkX, pkY, zk_spec, Fs, &dummy) == 1) verdict_bad = 1;
+    }
   }
   printf(
       "{\"stored_artifact\": \"%s\", \"spec\": %d, \"version\": %zu, \"attributes\": %zu, \"stored_bytes\": %zu, \"stored_sha256\": \"%s\", \"gpu_bytes\": %zu, "

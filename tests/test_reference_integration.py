@@ -98,7 +98,7 @@ def test_mdoc_end_to_end_with_gpu_provers_in_run_mdoc_prover(which, reps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("idx", [0, 1, 2], ids=["v7_one_attribute", "v7_two_attributes", "v6_one_attribute_shipped_circuit"])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3], ids=["v7_one_attribute", "v7_two_attributes", "v7_four_attributes", "v6_one_attribute_shipped_circuit"])
 def test_reference_stored_mdoc_proofs_reproduced_and_verified(tmp_path, idx):
     """The reference's own STORED mdoc proofs (rust/applications/mdoc_zk/artifacts/proofs/<circuit hash>.bin with both witness files,
     the fixtures of its prior_zk.rs test; committed under tests/golden/ by oracle/gen_mdoc_artifact_fixtures.py): complete proofs of
