@@ -168,6 +168,7 @@ elt_t h_lch14_twiddle(const GfHostCtx* g, unsigned i, u64 u) {
 }
 
 // ------------------------------------------------------------------ CU budget of the resident kernels (ctx.h)
+#include <atomic>
 #include <mutex>
 namespace {
 struct CuBudget {
@@ -298,6 +299,15 @@ int lfgpu_own_stream(lfgpu_ctx* c) {
   if (!c->own_stream) {
     LF_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     cu_sharer_add(c, +1);
+    // HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the environment said otherwise BEFORE the first HIP
+    // call of the process).  Streams that share a queue run in order: one prover's kernels then wait behind another prover's
+    // resident grid, for a millisecond each time (measured: 16 provers fall from 385 to below 200 proofs/s).  Said once.
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    const int hwq = e && atoi(e) > 0 ? atoi(e) : 4;
+    static std::atomic<bool> warned{false};
+    if (lf_cu_sharers(c) > hwq && !getenv("LFGPU_QUIET") && !warned.exchange(true))
+      fprintf(stderr, "lfgpu: %d contexts with streams of their own on device %d but GPU_MAX_HW_QUEUES = %d: set GPU_MAX_HW_QUEUES >= the number of "
+                      "concurrent provers before the first HIP call (INTEGRATION.md, throughput mode)\n", lf_cu_sharers(c), c->device, hwq);
   }
   LF_HIP(c, hipStreamSynchronize(c->stream));  // what was enqueued on the old stream is complete before the switch
   c->stream = c->own_stream;
