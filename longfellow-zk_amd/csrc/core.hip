@@ -151,6 +151,13 @@ bool lf_gf_ctx_build(GfHostCtx* g, int k) {
     elt_t sc = h_gf_inv(g->w_hat[i][i]);
     for (unsigned j = 0; j < sb; ++j) g->w_hat[i][j] = gf_mul(sc, g->w_hat[i][j]);
   }
+  for (unsigned b = 0; b < 4; ++b)
+    for (unsigned v = 0; v < 256; ++v) {
+      elt_t t{0, 0};
+      for (unsigned i = 0; i < 8; ++i)
+        if (((v >> i) & 1) && 8 * b + i < sb) t = gf_add(t, g->beta[8 * b + i]);
+      g->sub_tab[b][v] = t;
+    }
   g->init = true;
   return true;
 }

@@ -19,6 +19,7 @@ struct GfHostCtx {  // GF2_128<k> constants (lib/gf2k/gf2_128.h:97-116, lch14.h:
   elt_t g{};
   elt_t beta[32];
   elt_t w_hat[32][32];
+  elt_t sub_tab[4][256];  // of_scalar by bytes: sub_tab[b][v] = sum of beta[8 b + i] over the set bits i of v (gf2_128.h:192-214)
 };
 
 struct lfgpu_ctx {
