@@ -1165,12 +1165,8 @@ bool parse_proof(const lfgpu_circuit* C, const lfgpu_ligero_param& p, const GfHo
           pr.req[i] = rd.elt();
           continue;
         }
-        const uint8_t* b = rd.next(2);
-        const u32 u = (u32)b[0] | (u32)b[1] << 8;
-        elt_t e{0, 0};
-        for (unsigned k = 0; k < g->sub_bits; ++k)
-          if ((u >> k) & 1) e = gf_add(e, g->beta[k]);
-        pr.req[i] = e;
+        const uint8_t* b = rd.next(2);  // (kSubFieldBytes = 2: the wire format is GF2_128<4>'s)
+        pr.req[i] = gf_add(g->sub_tab[0][b[0]], g->sub_tab[1][b[1]]);  // of_scalar through the byte tables (GfHostCtx)
       }
     } else {
       if (!rd.have(runlen * 16)) return false;
