@@ -47,9 +47,24 @@ __global__ __launch_bounds__(QD_THREADS) void eval_quad_kernel(u32 nv, const u32
 }
 
 // ---- K10 step 1: eq[i] = EQ(G0,i) + alpha*EQ(G1,i), EQ(G,i) = prod_l (bit_l(i) ? G[l] : 1 - G[l])
+// The binding points travel as a KERNEL ARGUMENT (4 * logn + 1 <= 161 elements = 2.6 KB of the 4 KB kernarg segment; dynamic
+// indexing compiles to loads from that segment, no scratch): no staging copy, i.e. one dispatch less per EQ table -- a layer of a
+// proof is a chain of dependent dispatches and every one costs 3 - 4 us alone and ten times that with 16 provers.
+struct EqPoints {
+  elt_t g[4 * 40 + 1];  // G0 | G1 | 1-G0 | 1-G1
+};
+// zero[0 .. nzero) (64-bit words) is cleared on the side by the kernels that span the table: the accumulators of the next kernel
+// on the stream (Quad::bind_g's emit), instead of a hipMemsetAsync of their own
+__device__ __forceinline__ void eq_side_clear(u64* __restrict__ zero, u32 nzero) {
+  if (!zero) return;
+  const u32 T = gridDim.x * QD_THREADS;
+  for (u32 k = blockIdx.x * QD_THREADS + threadIdx.x; k < nzero; k += T) zero[k] = 0;
+}
 template <int F>
-__global__ __launch_bounds__(QD_THREADS) void raw_eq2_kernel(u32 logn, u32 n, const elt_t* __restrict__ G /*G0|G1|1-G0|1-G1*/,
-                                                             elt_t alpha, elt_t one, elt_t* __restrict__ eq) {
+__global__ __launch_bounds__(QD_THREADS) void raw_eq2_kernel(u32 logn, u32 n, EqPoints gp, elt_t alpha, elt_t one, elt_t* __restrict__ eq,
+                                                             u64* __restrict__ zero, u32 nzero) {
+  const elt_t* G = gp.g;
+  eq_side_clear(zero, nzero);
   u32 i = blockIdx.x * QD_THREADS + threadIdx.x;
   if (i >= n) return;
   elt_t e0 = one, e1 = alpha;
@@ -66,8 +81,8 @@ __global__ __launch_bounds__(QD_THREADS) void raw_eq2_kernel(u32 logn, u32 n, co
 // (LO0 | HI0 | LO1 | HI1, alpha folded into HI1; at most 2^ceil(logn/2) entries each, a product of <= 20 factors per
 // entry), raw_eq2_split_kernel combines them.  Exact field arithmetic: the association does not matter.
 template <int F>
-__global__ __launch_bounds__(QD_THREADS) void eq_tables_kernel(u32 logn, u32 lb, const elt_t* __restrict__ G /*G0|G1|1-G0|1-G1*/, elt_t alpha,
-                                                               elt_t one, elt_t* __restrict__ tab) {
+__global__ __launch_bounds__(QD_THREADS) void eq_tables_kernel(u32 logn, u32 lb, EqPoints gp, elt_t alpha, elt_t one, elt_t* __restrict__ tab) {
+  const elt_t* G = gp.g;
   // four lanes per entry, each multiplies every fourth factor, two shuffle steps combine them: the kernel is a chain of
   // dependent products (its tables are tiny), so the depth -- ceil(bits / 4) + 2 instead of bits -- is its run time
   const u32 hb = logn - lb, nlo = 1u << lb, nhi = 1u << hb;
@@ -92,7 +107,9 @@ __global__ __launch_bounds__(QD_THREADS) void eq_tables_kernel(u32 logn, u32 lb,
   if (live && part == 0) st16(&tab[t], e);
 }
 template <int F>
-__global__ __launch_bounds__(QD_THREADS) void raw_eq2_split_kernel(u32 logn, u32 lb, u32 n, const elt_t* __restrict__ tab, elt_t* __restrict__ eq) {
+__global__ __launch_bounds__(QD_THREADS) void raw_eq2_split_kernel(u32 logn, u32 lb, u32 n, const elt_t* __restrict__ tab, elt_t* __restrict__ eq,
+                                                                   u64* __restrict__ zero, u32 nzero) {
+  eq_side_clear(zero, nzero);
   const u32 i = blockIdx.x * QD_THREADS + threadIdx.x;
   if (i >= n) return;
   const u32 nlo = 1u << lb, nhi = 1u << (logn - lb);
@@ -408,17 +425,24 @@ extern "C" int lfgpu_eval_quad(lfgpu_quad* q, size_t nw, const void* d_W, void* 
   return LFGPU_OK;
 }
 
-// Eqs::raw_eq2 (lib/arrays/eqs.h): eq[i] = EQ(G0, i) + alpha EQ(G1, i), i < n <= 2^logn
-extern "C" int lfgpu_raw_eq2(lfgpu_ctx* c, int field, size_t logn, size_t n, const void* h_G0, const void* h_G1,
-                             const uint64_t alpha[2], void* d_eq) {
+// d_zero / zero_bytes (a multiple of 8, < 32 GiB): device words cleared on the side (eq_side_clear), or nullptr
+static int lf_raw_eq2_clear(lfgpu_ctx* c, int field, size_t logn, size_t n, const void* h_G0, const void* h_G1, const uint64_t alpha[2], void* d_eq,
+                            void* d_zero, size_t zero_bytes) {
   if (!c || !alpha || !d_eq || (logn && (!h_G0 || !h_G1)) || (field != LFGPU_FIELD_GF2_128 && field != LFGPU_FIELD_FP128))
     return LFGPU_ERR_ARG;
   if (logn > 40 || ((size_t)1 << logn) < n || (n >> 32)) return lf_fail(c, LFGPU_ERR_ARG, "raw_eq2: n out of range");
-  if (n == 0) return LFGPU_OK;
+  if (n == 0 || (zero_bytes >> 35)) {  // nothing to launch (or an accumulator region beyond the side clear's 32-bit word count)
+    if (d_zero && zero_bytes) LF_HIP(c, hipMemsetAsync(d_zero, 0, zero_bytes, c->stream));
+    if (n == 0) return LFGPU_OK;
+    d_zero = nullptr;
+  }
+  u64* const zp = (u64*)d_zero;
+  const u32 nz = d_zero ? (u32)(zero_bytes / 8) : 0u;
   LF_HIP(c, hipSetDevice(c->device));
   const elt_t one = field == LFGPU_FIELD_GF2_128 ? elt_t{1, 0} : h_fp_of_scalar(1);
-  // table [G0 | G1 | 1-G0 | 1-G1]
-  std::vector<elt_t> Gt(4 * logn + 1);
+  // table [G0 | G1 | 1-G0 | 1-G1]: a kernel argument (EqPoints)
+  EqPoints gp;
+  elt_t* const Gt = gp.g;
   const elt_t* G0 = (const elt_t*)h_G0;
   const elt_t* G1 = (const elt_t*)h_G1;
   for (size_t l = 0; l < logn; ++l) {
@@ -429,22 +453,25 @@ extern "C" int lfgpu_raw_eq2(lfgpu_ctx* c, int field, size_t logn, size_t n, con
   }
   const u32 lb = (u32)(logn / 2), hb = (u32)logn - lb;
   const size_t ntab = 2 * (((size_t)1 << lb) + ((size_t)1 << hb));
-  void* d_G = nullptr;
-  LF_TRY(lf_scratch2(c, (Gt.size() + ntab) * 16, &d_G));
-  elt_t* d_tab = (elt_t*)d_G + Gt.size();
-  LF_TRY(lf_stage_upload(c, d_G, Gt.data(), Gt.size() * 16));  // 4*logn+1 <= 161 elements: through the pinned ring
+  void* d_tabv = nullptr;
+  LF_TRY(lf_scratch2(c, ntab * 16 + 64, &d_tabv));
+  elt_t* d_tab = (elt_t*)d_tabv;
   const elt_t al{alpha[0], alpha[1]};
   if (logn < 6) {  // tiny: the direct product per entry
-    QD_DISPATCH(field, raw_eq2_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, (u32)n,
-                (const elt_t*)d_G, al, one, (elt_t*)d_eq);
+    QD_DISPATCH(field, raw_eq2_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, (u32)n, gp, al, one, (elt_t*)d_eq,
+                zp, nz);
   } else {
-    QD_DISPATCH(field, eq_tables_kernel, dim3((u32)((4 * ntab + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, lb, (const elt_t*)d_G, al,
-                one, d_tab);
+    QD_DISPATCH(field, eq_tables_kernel, dim3((u32)((4 * ntab + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, lb, gp, al, one, d_tab);
     QD_DISPATCH(field, raw_eq2_split_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, lb, (u32)n,
-                (const elt_t*)d_tab, (elt_t*)d_eq);
+                (const elt_t*)d_tab, (elt_t*)d_eq, zp, nz);
   }
   LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
+}
+// Eqs::raw_eq2 (lib/arrays/eqs.h): eq[i] = EQ(G0, i) + alpha EQ(G1, i), i < n <= 2^logn
+extern "C" int lfgpu_raw_eq2(lfgpu_ctx* c, int field, size_t logn, size_t n, const void* h_G0, const void* h_G1,
+                             const uint64_t alpha[2], void* d_eq) {
+  return lf_raw_eq2_clear(c, field, logn, n, h_G0, h_G1, alpha, d_eq, nullptr, 0);
 }
 
 // Enqueue only: the outputs are ordered on the context's stream; the HQUAD size is a property of the circuit (nh0,
@@ -463,17 +490,17 @@ int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G
   LF_TRY(lf_scratch3(c, q->nv * 16 + 256, &sc));
   elt_t* d_eq = (elt_t*)sc;
   elt_t be{beta[0], beta[1]};
-  LF_TRY(lfgpu_raw_eq2(c, field, logv, q->nv, h_G0, h_G1, alpha, d_eq));
   if (field == LFGPU_FIELD_GF2_128) {
-    LF_HIP(c, hipMemsetAsync(d_vc_out, 0, q->nh0 * 16, c->stream));
+    // (the emit kernel XORs into d_vc_out: cleared on the side by the EQ kernel in front of it)
+    LF_TRY(lf_raw_eq2_clear(c, field, logv, q->nv, h_G0, h_G1, alpha, d_eq, d_vc_out, q->nh0 * 16));
     hipLaunchKernelGGL(bindg_emit_gf_kernel, dim3(nb), dim3(BG_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
                        (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)q->d_runoff, (uint2*)d_hc_out, (u64*)d_vc_out);
   } else {
     // Fp128 has no 128-bit atomic add: integer limb accumulators + one reduction per run
     if (n >> 32) return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_g: more than 2^32 terms");
     void* accv = nullptr;
-    LF_TRY(lf_scratch2(c, q->nh0 * 32 + 64, &accv));
-    LF_HIP(c, hipMemsetAsync(accv, 0, q->nh0 * 32, c->stream));
+    LF_TRY(lf_scratch4(c, q->nh0 * 32 + 64, &accv));  // (scratch2 holds the EQ factor tables of lf_raw_eq2_clear)
+    LF_TRY(lf_raw_eq2_clear(c, field, logv, q->nv, h_G0, h_G1, alpha, d_eq, accv, q->nh0 * 32));
     hipLaunchKernelGGL(bindg_emit_fp_kernel, dim3(nb), dim3(BG_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
                        (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)q->d_runoff, (uint2*)d_hc_out, (u64*)accv);
     hipLaunchKernelGGL(fp_limb_normalize4_kernel, dim3((u32)((q->nh0 + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), 0, c->stream,
