@@ -853,11 +853,16 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
         pr = elt_t{r[0], r[1]};
         continue;
       }
-      if (WH[hand] == d_W && hand == 0) {  // hand 0 leaves the shared input out of place (prover_layers.h:222-226,255-257)
-        LF_TRY(lfgpu_dense_bind(c, field, nW[0], r, WH[0], wtmp));
-        WH[0] = wtmp;
-      } else {
-        LF_TRY(lfgpu_dense_bind(c, field, nW[hand], r, WH[hand], WH[hand]));
+      {
+        // Dense::bind out of place, ping-pong between the hand's two half-size buffers (the ones the grid kernel binds into after
+        // the hand-off): an in-place bind needs a temporary and a device-to-device copy back -- one more dispatch in a chain where
+        // every dispatch counts.  Hand 0's first bind leaves the shared input as before (prover_layers.h:222-226,
+        // 255-257); hand 1 no longer overwrites it.
+        uint8_t* const wb = (uint8_t*)wtmp;
+        void* dst = wb + (size_t)(2 * hand) * half;
+        if (dst == WH[hand]) dst = wb + (size_t)(2 * hand + 1) * half;
+        LF_TRY(lfgpu_dense_bind(c, field, nW[hand], r, WH[hand], dst));
+        WH[hand] = dst;
       }
       nW[hand] = (nW[hand] + 1) / 2;
       {  // HQuad::bind_h: the merge structure of this round-hand is a circuit constant, kept from the first proof on
