@@ -619,6 +619,8 @@ extern "C" int lfgpu_quad_bind_gh_all(lfgpu_quad* q, size_t logv, const void* h_
 // ------------------------------------------------------------------ one sumcheck layer (host loop)
 extern "C" int lfgpu_sumcheck_partials(lfgpu_ctx*, int, size_t, const void*, const void*, uint64_t*, uint64_t*);
 extern "C" int lfgpu_qw_scatter(lfgpu_ctx*, int, size_t, const void*, const void*, int, const void*, size_t, void*);
+int lf_qw_scatter_gf_into(lfgpu_ctx* c, size_t n, const void* d_hc, const void* d_vc, int hand, const void* d_Wother, void* d_QW);
+int lf_sumcheck_partials_clean(lfgpu_ctx* c, int field, size_t n, void* d_QW, const void* d_W, uint64_t a0[2], uint64_t a2[2]);
 extern "C" int lfgpu_dense_bind(lfgpu_ctx*, int, size_t, const uint64_t*, const void*, void*);
 extern "C" int lfgpu_hquad_bind_h(lfgpu_ctx*, int, size_t, const void*, const void*, const uint64_t*, int, void*, void*, size_t*);
 
@@ -702,6 +704,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   bool resident_off = !use_resident || no_fuse || c->grid_strikes >= 2;  // no (further) hand-off to a resident kernel in this layer
   u32 grid_G = 0, grid_per_wg = 1;  // the grid's workgroups as the kernel shrinks them (mirrored here to return CUs early)
   u64 last_r[2] = {0, 0};
+  bool qw_clean = false;  // GF(2^128), per-launch path: `qw` is all zero (set by its memset, kept by the self-cleaning sums)
   bool pending = false;  // the binds of (phand, pr) ride in the next fused step
   int phand = 0;
   elt_t pr{0, 0};
@@ -771,6 +774,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
         } else {
           rc = LFGPU_ERR_BUSY;
         }
+        qw_clean = false;  // a resident kernel (even one that is not placed and leaves) uses `qw` as its own scratch
         if (rc == LFGPU_OK) {
           resident = true;
           have_r = false;
@@ -818,8 +822,18 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
           a0[0] = out[0]; a0[1] = out[1]; a2[0] = out[2]; a2[1] = out[3];
           fused = true;
         } else {
-          LF_TRY(lfgpu_qw_scatter(c, field, nh, hc[cur], vc[cur], hand, WH[1 - hand], nW[hand], qw));
-          LF_TRY(lfgpu_sumcheck_partials(c, field, nW[hand], qw, WH[hand], a0, a2));
+          if (field == LFGPU_FIELD_GF2_128) {
+            // the accumulators clean themselves (the sums' kernel zeroes what it has read): one memset per layer, not per round-hand
+            if (!qw_clean) {
+              LF_HIP(c, hipMemsetAsync(qw, 0, qw_bytes, c->stream));
+              qw_clean = true;
+            }
+            LF_TRY(lf_qw_scatter_gf_into(c, nh, hc[cur], vc[cur], hand, WH[1 - hand], qw));
+            LF_TRY(lf_sumcheck_partials_clean(c, field, nW[hand], qw, WH[hand], a0, a2));
+          } else {
+            LF_TRY(lfgpu_qw_scatter(c, field, nh, hc[cur], vc[cur], hand, WH[1 - hand], nW[hand], qw));
+            LF_TRY(lfgpu_sumcheck_partials(c, field, nW[hand], qw, WH[hand], a0, a2));
+          }
         }
       }
       // coef[0] = eq0*a0, coef[2] = eq0*a2 with eq0 = 1 (logc = 0); coef[1] from sum (prover_layers.h:390-396)

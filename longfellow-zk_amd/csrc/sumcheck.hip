@@ -40,21 +40,28 @@ __device__ __forceinline__ elt_t block_reduce(elt_t v, elt_t* sh) {
 }
 
 // partial[2*b] = a0 part, partial[2*b+1] = a2 part of block b
+// clean != nullptr (== QW): every accumulator is zeroed by the lane that has read it, so that the NEXT evaluation's scatter finds
+// its targets cleared without a memset of its own (one dispatch less per round-hand of the per-launch path)
 template <int F>
-__global__ __launch_bounds__(SC_THREADS) void sumcheck_partials_kernel(size_t n, const elt_t* __restrict__ QW,
+__global__ __launch_bounds__(SC_THREADS) void sumcheck_partials_kernel(size_t n, const elt_t* QW /* may alias `clean` */,
                                                                        const elt_t* __restrict__ W,
-                                                                       elt_t* __restrict__ partial) {
+                                                                       elt_t* __restrict__ partial, elt_t* clean) {
   __shared__ elt_t sh[SC_THREADS / 64];
   const size_t nodd = n / 2;
   elt_t a0 = elt_zero(), a2 = elt_zero();
   for (size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x; i < nodd; i += (size_t)gridDim.x * SC_THREADS) {
     elt_t q0 = ld16(&QW[2 * i]), q1 = ld16(&QW[2 * i + 1]);
     elt_t w0 = ld16(&W[2 * i]), w1 = ld16(&W[2 * i + 1]);
+    if (clean) {
+      st16(&clean[2 * i], elt_zero());
+      st16(&clean[2 * i + 1], elt_zero());
+    }
     a0 = Fld<F>::add(a0, Fld<F>::mul(q0, w0));
     a2 = Fld<F>::add(a2, Fld<F>::mul(Fld<F>::sub(q1, q0), Fld<F>::sub(w1, w0)));
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && 2 * nodd < n) {  // odd tail (prover_layers.h:381-388)
     elt_t t = Fld<F>::mul(ld16(&QW[2 * nodd]), ld16(&W[2 * nodd]));
+    if (clean) st16(&clean[2 * nodd], elt_zero());
     a0 = Fld<F>::add(a0, t);
     a2 = Fld<F>::add(a2, t);
   }
@@ -1604,8 +1611,16 @@ int lf_sc_layer_next(lfgpu_ctx* c, const u64* r, u64 out[8]) {
   return LFGPU_OK;
 }
 
+static int sc_partials(lfgpu_ctx* c, int field, size_t n, const void* d_QW, const void* d_W, uint64_t a0[2], uint64_t a2[2], bool clean);
 extern "C" int lfgpu_sumcheck_partials(lfgpu_ctx* c, int field, size_t n, const void* d_QW, const void* d_W,
                                        uint64_t a0[2], uint64_t a2[2]) {
+  return sc_partials(c, field, n, d_QW, d_W, a0, a2, false);
+}
+// the sums of one evaluation; `d_QW` is left all zero (the accumulators are spent: see sumcheck_partials_kernel)
+int lf_sumcheck_partials_clean(lfgpu_ctx* c, int field, size_t n, void* d_QW, const void* d_W, uint64_t a0[2], uint64_t a2[2]) {
+  return sc_partials(c, field, n, d_QW, d_W, a0, a2, true);
+}
+static int sc_partials(lfgpu_ctx* c, int field, size_t n, const void* d_QW, const void* d_W, uint64_t a0[2], uint64_t a2[2], bool clean) {
   if (!c || !a0 || !a2 || (n && (!d_QW || !d_W))) return lf_fail(c, LFGPU_ERR_ARG, "sumcheck_partials: null argument");
   LF_HIP(c, hipSetDevice(c->device));
   size_t nodd = n / 2;
@@ -1618,7 +1633,7 @@ extern "C" int lfgpu_sumcheck_partials(lfgpu_ctx* c, int field, size_t n, const 
   partial = (elt_t*)sc;
   elt_t* out = (elt_t*)c->mailbox_d;
   DISPATCH_FIELD(field, sumcheck_partials_kernel, dim3(nb), dim3(SC_THREADS), n, (const elt_t*)d_QW,
-                 (const elt_t*)d_W, partial);
+                 (const elt_t*)d_W, partial, clean ? (elt_t*)const_cast<void*>(d_QW) : (elt_t*)nullptr);
   if (lf_sc_resident_ok(c)) {  // a running kernel's stores to the pinned words reach the host on this system (self-test, once)
     const u64 seq = ++c->poll_seq;
     DISPATCH_FIELD(field, sumcheck_final_kernel, dim3(1), dim3(SC_THREADS), nb, (const elt_t*)partial, out, c->poll_h, seq);
@@ -1636,6 +1651,7 @@ extern "C" int lfgpu_sumcheck_partials(lfgpu_ctx* c, int field, size_t n, const 
   return LFGPU_OK;
 }
 
+int lf_qw_scatter_gf_into(lfgpu_ctx* c, size_t n, const void* d_hc, const void* d_vc, int hand, const void* d_Wother, void* d_QW);
 extern "C" int lfgpu_qw_scatter(lfgpu_ctx* c, int field, size_t n, const void* d_hc, const void* d_vc, int hand,
                                 const void* d_Wother, size_t nqw, void* d_QW) {
   if (!c || !d_QW || (n && (!d_hc || !d_vc || !d_Wother))) return lf_fail(c, LFGPU_ERR_ARG, "qw_scatter: null argument");
@@ -1658,6 +1674,10 @@ extern "C" int lfgpu_qw_scatter(lfgpu_ctx* c, int field, size_t n, const void* d
     return LFGPU_OK;
   }
   LF_HIP(c, hipMemsetAsync(d_QW, 0, nqw * 16, c->stream));
+  return lf_qw_scatter_gf_into(c, n, d_hc, d_vc, hand, d_Wother, d_QW);
+}
+// GF(2^128): QW ^= the scatter; the caller guarantees cleared targets (a memset once, lf_sumcheck_partials_clean thereafter)
+int lf_qw_scatter_gf_into(lfgpu_ctx* c, size_t n, const void* d_hc, const void* d_vc, int hand, const void* d_Wother, void* d_QW) {
   if (n) {
     u32 nb = (u32)((n + SCAT_THREADS - 1) / SCAT_THREADS);
     hipLaunchKernelGGL(qw_scatter_gf_kernel, dim3(nb), dim3(SCAT_THREADS), 0, c->stream, n, (const uint2*)d_hc,
