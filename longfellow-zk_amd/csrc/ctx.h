@@ -151,7 +151,8 @@ int lf_quad_bind_gh_all_enqueue(lfgpu_quad* q, size_t logv, const void* h_G0, co
 void lf_quad_bind_gh_all_fold(int field, const u64 w[4], uint64_t out[2]);
 // Quad::bind_g, enqueue only (nothing is read back: the HQUAD size is computed once at lfgpu_quad_upload)
 int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2], const uint64_t beta[2],
-                   void* d_hc_out, void* d_vc_out, size_t* n_out);
+                   void* d_hc_out, void* d_vc_out, size_t* n_out, void* d_zero2 = nullptr, size_t zero2_bytes = 0,
+                   void* d_zero3 = nullptr, size_t zero3_bytes = 0);
 #define LF_GH_BATCH_MAX 96  // layers whose sums fit the device mailbox (32 bytes each from offset 512)
 
 // host-side field helpers (use the LF_HD arithmetic of fields.h compiled for the host)
@@ -200,7 +201,9 @@ struct ScGridOffCache {
 };
 int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, const u32* d_nh, void* W0, size_t nW0,
                      void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
-                     size_t logw, void* d_state, ScGridOffCache* oc = nullptr, u32* G_out = nullptr, u32* per_wg_out = nullptr);
+                     size_t logw, void* d_state, ScGridOffCache* oc = nullptr, u32* G_out = nullptr, u32* per_wg_out = nullptr,
+                     bool state_clean = false);
+#define LF_SC_GRID_SYNC_CLEAR_BYTES (64 + 1024)  // head of the grid state that must be zero at launch: counters (both levels), abort flag, challenge slot
 // ^ LFGPU_ERR_BUSY (nothing launched, no message): the device's CU budget is short of the grid -- use another driver now
 #define LF_SC_GRID_WGS 128                         // most workgroups the shrinking-grid kernel starts with
 #define LF_SC_GRID_MAX (256 * 1024)             // largest HQUAD / hand array it takes

@@ -119,6 +119,46 @@ __global__ __launch_bounds__(QD_THREADS) void raw_eq2_split_kernel(u32 logn, u32
   st16(&eq[i], Fld<F>::add(e0, e1));
 }
 
+// Both steps in ONE launch for tables of up to 2^16 entries (one dispatch less per layer): the low factor covers
+// 4 index bits, so a 256-thread block needs 16 + 16 low and 16 + 16 high factor entries -- 64 entries, four lanes each as above,
+// kept in LDS -- and then combines them into its 256 entries of the vector.  The blocks repeat the 32 low entries; the work per
+// entry stays within 3.5x of the split kernel's, which is why larger tables keep the two launches.  Same products in another
+// association: exact field arithmetic, same bytes.
+template <int F>
+__global__ __launch_bounds__(QD_THREADS) void raw_eq2_fused_kernel(u32 logn, u32 n, EqPoints gp, elt_t alpha, elt_t one, elt_t* __restrict__ eq,
+                                                                   u64* __restrict__ zero, u32 nzero) {
+  static_assert(QD_THREADS == 256, "raw_eq2_fused_kernel: 64 factor entries x 4 lanes");
+  __shared__ elt_t tab[64];  // LO0[16] | LO1[16] | HI0[16] | HI1[16] (alpha folded into HI1)
+  const elt_t* G = gp.g;
+  eq_side_clear(zero, nzero);
+  constexpr u32 lb = 4;
+  const u32 t = threadIdx.x, e = t >> 2, part = t & 3;
+  const u32 which = e >> 4, j = e & 15, g = which & 1;
+  const bool high = which >= 2;
+  const u32 bits = high ? logn - lb : lb, shift = high ? lb : 0;
+  const u32 idx = high ? blockIdx.x * 16 + j : j;  // (index bits beyond `bits` are never looked at)
+  elt_t v = (which == 3 && part == 0) ? alpha : one;
+  for (u32 l = part; l < bits; l += 4) {
+    const u32 bit = (idx >> l) & 1;
+    v = Fld<F>::mul(v, ld16(&G[(bit ? g * logn : (2 + g) * logn) + shift + l]));
+  }
+#pragma unroll
+  for (int x = 1; x <= 2; x <<= 1) {
+    elt_t o;
+    o.lo = __shfl_xor(v.lo, x, 64);
+    o.hi = __shfl_xor(v.hi, x, 64);
+    v = Fld<F>::mul(v, o);
+  }
+  if (part == 0) tab[e] = v;
+  __syncthreads();
+  const u32 i = blockIdx.x * QD_THREADS + t;
+  if (i >= n) return;
+  const u32 lo = t & 15, h = t >> 4;
+  const elt_t e0 = Fld<F>::mul(tab[lo], tab[32 + h]);
+  const elt_t e1 = Fld<F>::mul(tab[16 + lo], tab[48 + h]);
+  st16(&eq[i], Fld<F>::add(e0, e1));
+}
+
 // ---- K10 step 2: run heads (first term of each distinct hand pair)
 __device__ __forceinline__ bool is_head(const corner4* t, size_t i) {
   if (i == 0) return true;
@@ -160,6 +200,17 @@ __global__ __launch_bounds__(1024) void bindg_scan_kernel(u32 nblocks, u32* __re
   }
   if (threadIdx.x == 0) *total = carry;
 }
+// zero2[0 .. nzero2) (64-bit words, a few hundred at most) is cleared by the first block of the emit kernel: the synchronisation
+// words of the resident grid that takes the layer over later (sumcheck.hip, ScGridSync) -- one hipMemsetAsync less per layer
+// zero3[0 .. nzero3): a large region cleared by the whole grid -- the QW accumulators of the layer's first per-launch round-hand
+__device__ __forceinline__ void emit_side_clear(u64* __restrict__ zero2, u32 nzero2, u64* __restrict__ zero3, u32 nzero3) {
+  if (blockIdx.x == 0 && zero2)
+    for (u32 k = threadIdx.x; k < nzero2; k += BG_THREADS) zero2[k] = 0;
+  if (zero3) {
+    const u32 T = gridDim.x * BG_THREADS;
+    for (u32 k = blockIdx.x * BG_THREADS + threadIdx.x; k < nzero3; k += T) zero3[k] = 0;
+  }
+}
 // ---- K10 step 3: every term computes v' = (v == 0 ? beta : v) * eq[g] (prep_v) and the run sums are formed in parallel.
 // GF2_128: a hand pair shared by very many gates (constant wires: the
 // 32-block flatsha256 layers hold runs of > 10^5 terms) would otherwise be summed by ONE lane.  Every
@@ -170,8 +221,10 @@ __global__ __launch_bounds__(BG_THREADS) void bindg_emit_gf_kernel(size_t n, con
                                                                    const elt_t* __restrict__ kvec,
                                                                    const elt_t* __restrict__ eq, elt_t beta,
                                                                    const u32* __restrict__ block_off,
-                                                                   uint2* __restrict__ hc_out, u64* __restrict__ vc_out) {
+                                                                   uint2* __restrict__ hc_out, u64* __restrict__ vc_out,
+                                                                   u64* __restrict__ zero2, u32 nzero2, u64* __restrict__ zero3, u32 nzero3) {
   __shared__ u32 wave_off[BG_THREADS / 64];
+  emit_side_clear(zero2, nzero2, zero3, nzero3);
   const size_t i = (size_t)blockIdx.x * BG_THREADS + threadIdx.x;
   const bool valid = i < n;
   const bool head = valid && is_head(t, i);
@@ -201,8 +254,10 @@ __global__ __launch_bounds__(BG_THREADS) void bindg_emit_fp_kernel(size_t n, con
                                                                    const elt_t* __restrict__ kvec,
                                                                    const elt_t* __restrict__ eq, elt_t beta,
                                                                    const u32* __restrict__ block_off,
-                                                                   uint2* __restrict__ hc_out, u64* __restrict__ acc) {
+                                                                   uint2* __restrict__ hc_out, u64* __restrict__ acc,
+                                                                   u64* __restrict__ zero2, u32 nzero2, u64* __restrict__ zero3, u32 nzero3) {
   __shared__ u32 wave_off[BG_THREADS / 64];
+  emit_side_clear(zero2, nzero2, zero3, nzero3);
   const size_t i = (size_t)blockIdx.x * BG_THREADS + threadIdx.x;
   const bool valid = i < n;
   const bool head = valid && is_head(t, i);
@@ -457,9 +512,16 @@ static int lf_raw_eq2_clear(lfgpu_ctx* c, int field, size_t logn, size_t n, cons
   LF_TRY(lf_scratch2(c, ntab * 16 + 64, &d_tabv));
   elt_t* d_tab = (elt_t*)d_tabv;
   const elt_t al{alpha[0], alpha[1]};
+  static const bool fuse_off = getenv("LFGPU_EQ_FUSED") && atoi(getenv("LFGPU_EQ_FUSED")) == 0;  // A/B
+  static const bool fuse_on = getenv("LFGPU_EQ_FUSED") && atoi(getenv("LFGPU_EQ_FUSED")) == 1;  // (tests: the fused kernel on a device of one's own)
   if (logn < 6) {  // tiny: the direct product per entry
     QD_DISPATCH(field, raw_eq2_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, (u32)n, gp, al, one, (elt_t*)d_eq,
                 zp, nz);
+  } else if (logn <= 16 && !fuse_off && (fuse_on || lf_cu_sharers(c) >= 6)) {
+    // factor tables and their combination in one launch -- in throughput mode only: with 16 provers on the device the dispatch
+    // saved is worth +0.4 % proofs/s, a prover alone pays one product more on its critical path (flatsha-1: +0.05 ms)
+    QD_DISPATCH(field, raw_eq2_fused_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, (u32)n, gp, al, one,
+                (elt_t*)d_eq, zp, nz);
   } else {
     QD_DISPATCH(field, eq_tables_kernel, dim3((u32)((4 * ntab + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, lb, gp, al, one, d_tab);
     QD_DISPATCH(field, raw_eq2_split_kernel, dim3((u32)((n + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), (u32)logn, lb, (u32)n,
@@ -477,7 +539,8 @@ extern "C" int lfgpu_raw_eq2(lfgpu_ctx* c, int field, size_t logn, size_t n, con
 // Enqueue only: the outputs are ordered on the context's stream; the HQUAD size is a property of the circuit (nh0,
 // computed at upload), so nothing is read back.
 int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
-                   const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out) {
+                   const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out, void* d_zero2, size_t zero2_bytes, void* d_zero3,
+                   size_t zero3_bytes) {
   if (!q || !alpha || !beta || !d_hc_out || !d_vc_out || (logv && (!h_G0 || !h_G1))) return LFGPU_ERR_ARG;
   lfgpu_ctx* c = q->c;
   if (q->field == LFGPU_FIELD_P256) return lf_fail(c, LFGPU_ERR_UNSUPPORTED, "quad_bind_g: Fp256Base layers are bound inside the ZK driver (zk256.hip)");
@@ -494,7 +557,8 @@ int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G
     // (the emit kernel XORs into d_vc_out: cleared on the side by the EQ kernel in front of it)
     LF_TRY(lf_raw_eq2_clear(c, field, logv, q->nv, h_G0, h_G1, alpha, d_eq, d_vc_out, q->nh0 * 16));
     hipLaunchKernelGGL(bindg_emit_gf_kernel, dim3(nb), dim3(BG_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
-                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)q->d_runoff, (uint2*)d_hc_out, (u64*)d_vc_out);
+                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)q->d_runoff, (uint2*)d_hc_out, (u64*)d_vc_out,
+                       (u64*)d_zero2, (u32)(zero2_bytes / 8), (u64*)d_zero3, (u32)(zero3_bytes / 8));
   } else {
     // Fp128 has no 128-bit atomic add: integer limb accumulators + one reduction per run
     if (n >> 32) return lf_fail(c, LFGPU_ERR_ARG, "quad_bind_g: more than 2^32 terms");
@@ -502,7 +566,8 @@ int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G
     LF_TRY(lf_scratch4(c, q->nh0 * 32 + 64, &accv));  // (scratch2 holds the EQ factor tables of lf_raw_eq2_clear)
     LF_TRY(lf_raw_eq2_clear(c, field, logv, q->nv, h_G0, h_G1, alpha, d_eq, accv, q->nh0 * 32));
     hipLaunchKernelGGL(bindg_emit_fp_kernel, dim3(nb), dim3(BG_THREADS), 0, c->stream, n, (const corner4*)q->d_morton,
-                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)q->d_runoff, (uint2*)d_hc_out, (u64*)accv);
+                       (const elt_t*)q->d_kvec, (const elt_t*)d_eq, be, (const u32*)q->d_runoff, (uint2*)d_hc_out, (u64*)accv,
+                       (u64*)d_zero2, (u32)(zero2_bytes / 8), (u64*)d_zero3, (u32)(zero3_bytes / 8));
     hipLaunchKernelGGL(fp_limb_normalize4_kernel, dim3((u32)((q->nh0 + QD_THREADS - 1) / QD_THREADS)), dim3(QD_THREADS), 0, c->stream,
                        (const u32*)q->d_nh, (const u64*)accv, (elt_t*)d_vc_out);
   }
@@ -513,7 +578,7 @@ int lf_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G
 extern "C" int lfgpu_quad_bind_g(lfgpu_quad* q, size_t logv, const void* h_G0, const void* h_G1, const uint64_t alpha[2],
                                  const uint64_t beta[2], void* d_hc_out, void* d_vc_out, size_t* n_out) {
   if (!n_out) return LFGPU_ERR_ARG;
-  return lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, d_hc_out, d_vc_out, n_out);
+  return lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, d_hc_out, d_vc_out, n_out, nullptr, 0, nullptr, 0);
 }
 
 
@@ -623,6 +688,8 @@ int lf_qw_scatter_gf_into(lfgpu_ctx* c, size_t n, const void* d_hc, const void* 
 int lf_sumcheck_partials_clean(lfgpu_ctx* c, int field, size_t n, void* d_QW, const void* d_W, uint64_t a0[2], uint64_t a2[2]);
 extern "C" int lfgpu_dense_bind(lfgpu_ctx*, int, size_t, const uint64_t*, const void*, void*);
 extern "C" int lfgpu_hquad_bind_h(lfgpu_ctx*, int, size_t, const void*, const void*, const uint64_t*, int, void*, void*, size_t*);
+int lf_bind_both_cached(lfgpu_ctx* c, int field, size_t n0, const uint64_t r[2], const void* d_in, void* d_out, size_t n, const void* d_hc,
+                        const void* d_vc, int hand, void* d_hc_out, void* d_vc_out, const u32* d_off_cached);
 
 #include "hostfield.h"
 
@@ -686,7 +753,12 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   const size_t resident_max = sc_mode == 3 ? grid_max_eff : LF_SC_SMALL_MAX;  // largest array a resident kernel takes over at
   // Quad::bind_g: enqueued on the stream, nothing read back (the HQUAD size is a circuit constant)
   const double tv0 = verbose ? clk() : 0;
-  LF_TRY(lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], &nh));
+  // (the emit kernel also clears the head of the grid state: the resident grid then starts without a memset of its own)
+  bool gs_clean = sc_mode == 3 && nt > 0;
+  // ... and, for a GF(2^128) layer that starts on per-launch kernels, the QW accumulators of its first round-hand
+  const bool qw_side = field == LFGPU_FIELD_GF2_128 && nt > 0 && (qw_bytes >> 35) == 0 && std::max<size_t>(q->nh0, nw) > std::max<size_t>(resident_max, LF_SC_SMALL_MAX);
+  LF_TRY(lf_quad_bind_g(q, logv, h_G0, h_G1, alpha, beta, hc[0], vc[0], &nh, gs_clean ? grid_state : nullptr, gs_clean ? LF_SC_GRID_SYNC_CLEAR_BYTES : 0,
+                        qw_side ? qw : nullptr, qw_side ? qw_bytes : 0));
   const double tv1 = verbose ? clk() : 0;
   const size_t nh0 = nh;
   bool resident = false, have_r = false;
@@ -704,7 +776,7 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
   bool resident_off = !use_resident || no_fuse || c->grid_strikes >= 2;  // no (further) hand-off to a resident kernel in this layer
   u32 grid_G = 0, grid_per_wg = 1;  // the grid's workgroups as the kernel shrinks them (mirrored here to return CUs early)
   u64 last_r[2] = {0, 0};
-  bool qw_clean = false;  // GF(2^128), per-launch path: `qw` is all zero (set by its memset, kept by the self-cleaning sums)
+  bool qw_clean = qw_side;  // GF(2^128), per-launch path: `qw` is all zero (cleared beside bind_g or by a memset, kept by the self-cleaning sums)
   bool pending = false;  // the binds of (phand, pr) ride in the next fused step
   int phand = 0;
   elt_t pr{0, 0};
@@ -755,7 +827,8 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
         if (sc_mode == 3) {  // the shrinking grid
           uint8_t* wb = (uint8_t*)wtmp;
           rc = lf_sc_grid_begin(c, field, hc[cur], vc[cur], hc[1 - cur], vc[1 - cur], nh, nullptr, WH[0], nW[0], WH[1], nW[1], wb, wb + half, wb + 2 * half,
-                                wb + 3 * half, qw, 2 * rnd + hand, logw, grid_state, &q->grid_off, &grid_G, &grid_per_wg);
+                                wb + 3 * half, qw, 2 * rnd + hand, logw, grid_state, &q->grid_off, &grid_G, &grid_per_wg, gs_clean);
+          if (rc == LFGPU_OK) gs_clean = false;  // (a refusal by the CU budget launches nothing: the state stays clean)
         } else if (lf_cu_acquire(c, 1)) {  // the resident single workgroup
           ScSmall a{};
           a.field = field;
@@ -867,6 +940,8 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
         pr = elt_t{r[0], r[1]};
         continue;
       }
+      bool both = false;
+      static const bool bind_split = getenv("LFGPU_SC_BIND_SPLIT") && atoi(getenv("LFGPU_SC_BIND_SPLIT")) != 0;  // A/B: two launches
       {
         // Dense::bind out of place, ping-pong between the hand's two half-size buffers (the ones the grid kernel binds into after
         // the hand-off): an in-place bind needs a temporary and a device-to-device copy back -- one more dispatch in a chain where
@@ -875,15 +950,21 @@ extern "C" int lfgpu_sumcheck_layer(lfgpu_quad* q, size_t logv, const void* h_G0
         uint8_t* const wb = (uint8_t*)wtmp;
         void* dst = wb + (size_t)(2 * hand) * half;
         if (dst == WH[hand]) dst = wb + (size_t)(2 * hand + 1) * half;
-        LF_TRY(lfgpu_dense_bind(c, field, nW[hand], r, WH[hand], dst));
+        const size_t rh = 2 * rnd + hand;
+        if (q->bind_shape.size() < 2 * logw) q->bind_shape.resize(2 * logw, lfgpu_quad::BindShape{nullptr, 0, 0});
+        const lfgpu_quad::BindShape& bs0 = q->bind_shape[rh];
+        both = bs0.d_off && bs0.n_in == nh && nh > 0 && !bind_split;  // recorded merge structure: both binds in one launch
+        if (both) LF_TRY(lf_bind_both_cached(c, field, nW[hand], r, WH[hand], dst, nh, hc[cur], vc[cur], hand, hc[1 - cur], vc[1 - cur], bs0.d_off));
+        else LF_TRY(lfgpu_dense_bind(c, field, nW[hand], r, WH[hand], dst));
         WH[hand] = dst;
       }
       nW[hand] = (nW[hand] + 1) / 2;
       {  // HQuad::bind_h: the merge structure of this round-hand is a circuit constant, kept from the first proof on
         const size_t rh = 2 * rnd + hand;
-        if (q->bind_shape.size() < 2 * logw) q->bind_shape.resize(2 * logw, lfgpu_quad::BindShape{nullptr, 0, 0});
         lfgpu_quad::BindShape& bs = q->bind_shape[rh];
-        if (bs.d_off && bs.n_in == nh) {
+        if (both) {
+          nh = bs.n_out;
+        } else if (bs.d_off && bs.n_in == nh) {
           LF_TRY(lf_hquad_bind_h_cached(c, field, nh, hc[cur], vc[cur], r, hand, hc[1 - cur], vc[1 - cur], bs.d_off, nullptr, nullptr));
           nh = bs.n_out;
         } else {

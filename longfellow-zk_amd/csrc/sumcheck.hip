@@ -149,9 +149,8 @@ __global__ __launch_bounds__(SC_THREADS) void fp_limb_normalize_kernel(size_t n,
 
 // out[i] = in[2i] + r*(in[2i+1]-in[2i]);  tail: in*(1-r)   (dense.h:70-87, affine.h:26-52)
 template <int F>
-__global__ __launch_bounds__(SC_THREADS) void dense_bind_kernel(size_t n0, elt_t r, const elt_t* __restrict__ in,
-                                                                elt_t* __restrict__ out) {
-  size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
+__device__ __forceinline__ void dense_bind_body(u32 bx, size_t n0, elt_t r, const elt_t* __restrict__ in, elt_t* __restrict__ out) {
+  size_t i = (size_t)bx * SC_THREADS + threadIdx.x;
   size_t nout = (n0 + 1) / 2;
   if (i >= nout) return;
   elt_t f0 = ld16(&in[2 * i]);
@@ -163,6 +162,11 @@ __global__ __launch_bounds__(SC_THREADS) void dense_bind_kernel(size_t n0, elt_t
     v = Fld<F>::sub(f0, Fld<F>::mul(f0, r));
   }
   st16(&out[i], v);
+}
+template <int F>
+__global__ __launch_bounds__(SC_THREADS) void dense_bind_kernel(size_t n0, elt_t r, const elt_t* __restrict__ in,
+                                                                elt_t* __restrict__ out) {
+  dense_bind_body<F>(blockIdx.x, n0, r, in, out);
 }
 
 // ---- HQuad::bind_h as an order-preserving compaction.
@@ -214,18 +218,16 @@ __global__ __launch_bounds__(1024) void hquad_scan_kernel(u32 nblocks, u32* __re
   if (threadIdx.x == 0) *total = carry;
 }
 template <int F>
-__global__ __launch_bounds__(SC_THREADS) void hquad_emit_kernel(size_t n, const uint2* __restrict__ hc,
-                                                                const elt_t* __restrict__ vc, elt_t r, int hand,
-                                                                const u32* __restrict__ block_off,
-                                                                uint2* __restrict__ hc_out, elt_t* __restrict__ vc_out) {
-  __shared__ u32 wave_off[SC_THREADS / 64];
-  size_t i = (size_t)blockIdx.x * SC_THREADS + threadIdx.x;
+__device__ __forceinline__ void hquad_emit_body(u32 bx, u32* wave_off /* LDS, SC_THREADS / 64 words */, size_t n, const uint2* __restrict__ hc,
+                                                const elt_t* __restrict__ vc, elt_t r, int hand, const u32* __restrict__ block_off,
+                                                uint2* __restrict__ hc_out, elt_t* __restrict__ vc_out) {
+  size_t i = (size_t)bx * SC_THREADS + threadIdx.x;
   bool head = i < n && !is_second(hc, i, hand);
   u64 mask = __ballot(head);
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) wave_off[wave] = (u32)__popcll(mask);
   __syncthreads();
-  u32 off = block_off[blockIdx.x];
+  u32 off = block_off[bx];
   for (u32 w = 0; w < wave; ++w) off += wave_off[w];
   off += (u32)__popcll(mask & ((1ull << lane) - 1));
   if (!head) return;
@@ -243,6 +245,26 @@ __global__ __launch_bounds__(SC_THREADS) void hquad_emit_kernel(size_t n, const 
   if (hand) h.y = hh >> 1; else h.x = hh >> 1;
   hc_out[off] = h;
   st16(&vc_out[off], v);
+}
+template <int F>
+__global__ __launch_bounds__(SC_THREADS) void hquad_emit_kernel(size_t n, const uint2* __restrict__ hc,
+                                                                const elt_t* __restrict__ vc, elt_t r, int hand,
+                                                                const u32* __restrict__ block_off,
+                                                                uint2* __restrict__ hc_out, elt_t* __restrict__ vc_out) {
+  __shared__ u32 wave_off[SC_THREADS / 64];
+  hquad_emit_body<F>(blockIdx.x, wave_off, n, hc, vc, r, hand, block_off, hc_out, vc_out);
+}
+// Dense::bind of the round-hand's own array and HQuad::bind_h (recorded offsets) in ONE launch: both need only the challenge,
+// touch different arrays, and a per-launch round-hand is a chain of dependent dispatches in which every dispatch counts
+// (DESIGN.md 4.9).  Blocks [0, nbD) bind the dense array, the rest emit the HQUAD.
+template <int F>
+__global__ __launch_bounds__(SC_THREADS) void bind_both_kernel(u32 nbD, size_t n0, elt_t r, const elt_t* __restrict__ in, elt_t* __restrict__ out,
+                                                               size_t n, const uint2* __restrict__ hc, const elt_t* __restrict__ vc, int hand,
+                                                               const u32* __restrict__ block_off, uint2* __restrict__ hc_out,
+                                                               elt_t* __restrict__ vc_out) {
+  __shared__ u32 wave_off[SC_THREADS / 64];
+  if (blockIdx.x < nbD) dense_bind_body<F>(blockIdx.x, n0, r, in, out);
+  else hquad_emit_body<F>(blockIdx.x - nbD, wave_off, n, hc, vc, r, hand, block_off, hc_out, vc_out);
 }
 
 // ---- fused single-workgroup steps for the small rounds of a layer.
@@ -1449,7 +1471,7 @@ int lf_sc_layer_begin(lfgpu_ctx* c, const ScSmall& a, u32 rh0, u32 rh1, void* d_
 // d_state: LF_SC_GRID_STATE_BYTES of device scratch (ScGridSync + the per-workgroup counts)
 int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* hc_oth, void* vc_oth, size_t nh, const u32* d_nh, void* W0, size_t nW0,
                      void* W1, size_t nW1, void* Wb00, void* Wb01, void* Wb10, void* Wb11, void* qw, size_t rh0,
-                     size_t logw, void* d_state, ScGridOffCache* oc, u32* G_out, u32* per_wg_out) {
+                     size_t logw, void* d_state, ScGridOffCache* oc, u32* G_out, u32* per_wg_out, bool state_clean) {
   const size_t big = std::max(nh, std::max(nW0, nW1));
   if (rh0 >= 2 * logw || big > LF_SC_GRID_MAX) return lf_fail(c, LFGPU_ERR_ARG, "sc_grid_begin: bad operands");
   static_assert(sizeof(ScGridSync) + 4 * LF_SC_GRID_WGS + 36 * LF_SC_GRID_MAX <= LF_SC_GRID_STATE_BYTES, "grid state size");
@@ -1524,7 +1546,9 @@ int lf_sc_grid_begin(lfgpu_ctx* c, int field, void* hc_cur, void* vc_cur, void* 
   a.counts = (u32*)((uint8_t*)d_state + sizeof(ScGridSync));
   a.src = (u32*)((uint8_t*)d_state + LF_SC_GRID_STATE_BYTES - 36 * LF_SC_GRID_MAX);
   a.QW2 = (u64*)((uint8_t*)d_state + LF_SC_GRID_STATE_BYTES - 32 * LF_SC_GRID_MAX);
-  LF_HIP(c, hipMemsetAsync(d_state, 0, 64 + 1024, c->stream));  // counters (both levels), abort flag, challenge slot
+  // counters (both levels), abort flag, challenge slot: zero at launch -- cleared on the side by the layer's bind_g emit kernel
+  // (state_clean), else here
+  if (!state_clean) LF_HIP(c, hipMemsetAsync(d_state, 0, LF_SC_GRID_SYNC_CLEAR_BYTES, c->stream));
   void* args[] = {&a};
   const void* fn = field == LFGPU_FIELD_GF2_128 ? (const void*)sc_grid_layer_kernel<FIELD_GF2_128> : (const void*)sc_grid_layer_kernel<FIELD_FP128>;
   a.tail_lds = (u32)tail_ok;
@@ -1755,6 +1779,19 @@ int lf_hquad_bind_h_cached(lfgpu_ctx* c, int field, size_t n, const void* d_hc, 
     LF_HIP(c, hipMemcpyAsync(keep, sc, (size_t)nb * 4, hipMemcpyDeviceToDevice, c->stream));
     *d_off_keep = keep;
   }
+  return LFGPU_OK;
+}
+
+// Dense::bind (out of place, d_out != d_in) + HQuad::bind_h with recorded offsets, one launch (bind_both_kernel)
+int lf_bind_both_cached(lfgpu_ctx* c, int field, size_t n0, const uint64_t r[2], const void* d_in, void* d_out, size_t n, const void* d_hc,
+                        const void* d_vc, int hand, void* d_hc_out, void* d_vc_out, const u32* d_off_cached) {
+  if (!c || !r || n0 == 0 || n == 0 || !d_in || !d_out || d_in == d_out || !d_hc || !d_vc || !d_hc_out || !d_vc_out || !d_off_cached)
+    return lf_fail(c, LFGPU_ERR_ARG, "bind_both_cached: bad argument");
+  const u32 nbD = (u32)(((n0 + 1) / 2 + SC_THREADS - 1) / SC_THREADS), nbH = (u32)((n + SC_THREADS - 1) / SC_THREADS);
+  const elt_t rr{r[0], r[1]};
+  DISPATCH_FIELD(field, bind_both_kernel, dim3(nbD + nbH), dim3(SC_THREADS), nbD, n0, rr, (const elt_t*)d_in, (elt_t*)d_out, n, (const uint2*)d_hc,
+                 (const elt_t*)d_vc, hand ? 1 : 0, d_off_cached, (uint2*)d_hc_out, (elt_t*)d_vc_out);
+  LF_HIP(c, hipGetLastError());
   return LFGPU_OK;
 }
 

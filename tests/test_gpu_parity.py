@@ -410,6 +410,35 @@ def test_raw_eq2(G, field, logn, n):
     assert (G.from_dev(d, np.uint64, (n, 2)) == want).all()
 
 
+_EQ_FUSED_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import gpu_util as G, oracle_lib as ol
+o = ol.oracle()
+for field in (ol.GF, ol.FP):
+    for logn, n in ((6, 64), (6, 33), (7, 128), (11, 1500), (13, 8192), (16, 40001), (16, 1 << 16)):
+        rng = np.random.default_rng(100 * logn + field + n)
+        G0, G1 = ol.rand_elts(rng, logn, field), ol.rand_elts(rng, logn, field)
+        alpha = ol.rand_elts(rng, 1, field)[0]
+        want = np.zeros((n, 2), dtype=np.uint64)
+        o.lfo_raw_eq2(field, logn, n, ol.P(G0), ol.P(G1), ol.elt(alpha), ol.P(want))
+        d = torch.zeros(n * 16, dtype=torch.uint8, device='cuda')
+        G.gpu().raw_eq2(field, logn, n, G0, G1, alpha, d.data_ptr())
+        assert (G.from_dev(d, np.uint64, (n, 2)) == want).all(), (field, logn, n)
+print('OK')
+"""
+
+
+def test_raw_eq2_fused_launch():
+    """raw_eq2_fused_kernel (factor tables + combination in one launch; the default only in throughput mode)
+    == Eqs::raw_eq2, both fields, ragged n, up to its limit of 2^16 entries.  The switch is read once per process: a child."""
+    import os, subprocess, sys
+    e = dict(os.environ, LFGPU_EQ_FUSED="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", _EQ_FUSED_CHILD, here], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 # ---------------------------------------------------------------- K5 / K6 Merkle
 @pytest.mark.parametrize("field,nrow,ld,col0,ncols", [(GF, 1, 8, 0, 8), (GF, 2, 8, 1, 1), (GF, 20, 4096, 909, 3187),
                                                       (GF, 150, 8192, 1819, 6373), (GF, 7, 64, 13, 51),

@@ -48,6 +48,16 @@ CASES = [
     ("32", {"LFGPU_SC_TEST_DROP": "5", "LFGPU_SC_PLACE_MS": "20"}),
     ("1 fp128", {"LFGPU_SC_TEST_DROP": "1", "LFGPU_SC_PLACE_MS": "20"}),
     ("sig", {"LFGPU_P256_TEST_DROP": "1", "LFGPU_SC_PLACE_MS": "20", "LFGPU_P256_GRID_MAX": "65536", "LFGPU_P256_PER_WG": "128"}),
+    # dispatch-saving paths: the EQ factor tables and their combination in ONE launch (default only with >= 6
+    # provers on the device: forced here, both fields, and forced off), Dense::bind + HQuad::bind_h in two launches instead of
+    # one, and both with the per-launch kernels all the way (every round-hand through bind_both_kernel from the second proof on)
+    ("1", {"LFGPU_EQ_FUSED": "1"}),
+    ("32", {"LFGPU_EQ_FUSED": "1"}),
+    ("1 fp128", {"LFGPU_EQ_FUSED": "1"}),
+    ("32", {"LFGPU_EQ_FUSED": "0", "LFGPU_SC_BIND_SPLIT": "1"}),
+    ("32", {"LFGPU_SC_MODE": "off", "LFGPU_EQ_FUSED": "1"}),
+    ("1 fp128", {"LFGPU_SC_MODE": "off"}),
+    ("32", {"LFGPU_SC_MODE": "off", "LFGPU_SC_BIND_SPLIT": "1"}),
 ]
 
 
@@ -56,7 +66,7 @@ CASES = [
 def test_proof_bytes_under_every_driver(args, env):
     e = dict(os.environ)
     for k in list(e):
-        if k.startswith("LFGPU_SC_") or k.startswith("LFGPU_P256_") or k.startswith("LFGPU_CU_"):
+        if k.startswith("LFGPU_SC_") or k.startswith("LFGPU_P256_") or k.startswith("LFGPU_CU_") or k.startswith("LFGPU_EQ_"):
             del e[k]
     e.update(env)
     r = subprocess.run([sys.executable, CHILD] + args.split(), env=e, capture_output=True, text=True, timeout=300)
