@@ -680,6 +680,9 @@ __device__ __forceinline__ int sc_grid_barrier_ex(ScGridSync* gs, u32 G, u32& ge
     __syncthreads();
     return 0;
   }
+  // every storing wave: its stores are acknowledged before thread 0 releases for them (a workgroup barrier orders nothing in
+  // memory, and the agent-scope release below writes back what has reached the L2)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     // one release (with the arrival), one acquire (after the wait): every further fence is an L2 write-back or
