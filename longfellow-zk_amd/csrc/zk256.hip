@@ -385,6 +385,8 @@ __device__ __forceinline__ int g256_barrier_ex(Grid256Sync* gs, u32 G, u32& gen,
     __syncthreads();
     return 0;
   }
+  // every storing wave: its stores are acknowledged before thread 0 releases for them (as in sc_grid_barrier_ex, sumcheck.hip)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     u32 ab = 0;
